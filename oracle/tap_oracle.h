@@ -1,0 +1,148 @@
+/*
+ * tap_oracle.h -- CPU oracle for the Transport-and-Pack environment hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C, single-threaded-per-env, voxel-level
+ * restatement of the reference's (Juzhan/TAP-Net) Python algorithm.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (tap-net_amd/, libtapenv.so) never links, imports or calls anything in oracle/.
+ *
+ * Parity status: PINNED.  The oracle is checked (tests/test_oracle_golden.py) against
+ * golden vectors produced by importing the reference itself in the build container
+ * (tests/golden/make_golden.py, outputs committed under tests/golden/), and -- where
+ * /root/reference exists -- live against the reference (tests/test_oracle_vs_reference.py).
+ *
+ * Every function cites the reference file:line it restates.  Unlike the HIP kernels
+ * (which carry only the height-map), the oracle keeps the reference's full state: the
+ * voxel grid `container`, the height-map, the placed-block history and MACS's
+ * per-level free-space lists, and manipulates them the way the Python does.
+ */
+#ifndef TAP_ORACLE_H
+#define TAP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* packing strategy (tools.py:3617-3620, 3679-3690) */
+enum { ORC_LB_GREEDY = 0, ORC_MACS = 1 /* 'MACS' and 'MUL' run the same 2D function */ };
+
+/* flag word = the string tests the reference performs on reward_type */
+enum {
+    ORC_F_HARD     = 1 << 0, /* reward_type.endswith('hard')   tools.py:2113,2580 */
+    ORC_F_USE_P    = 1 << 1, /* 'P' in reward_type              tools.py:2135,2600 */
+    ORC_F_USE_S    = 1 << 2, /* 'S' in reward_type              tools.py:2138,2602 */
+    ORC_F_MCS_ZERO = 1 << 3, /* reward_type.startswith('mcs')   tools.py:2709      */
+    ORC_F_MCS_TIE  = 1 << 4  /* 'mcs' in reward_type            tools.py:2718      */
+};
+
+/* Container.calc_ratio formula selector (tools.py:3907-3966) */
+enum {
+    ORC_R_C = 0,       /* 'comp'                          -> C / 3          */
+    ORC_R_CxS,         /* 'soft','hard'                   -> C*S / 3        */
+    ORC_R_CP,          /* 'pyrm'                          -> (C+P) / 3      */
+    ORC_R_CPxS,        /* 'pyrm-soft/hard','mcs-soft/hard'-> (C+P)*S / 3    */
+    ORC_R_CPS,         /* all 'C+P(+S)-*' types etc.      -> (C+P+S) / 3    */
+    ORC_R_2CPS,        /* 'pyrm-*-SUM'                    -> (2C+P+S) / 3   */
+    ORC_R_CxPxS,       /* 'CPS'                           -> C*P*S / 3      */
+    ORC_R_CP_HALF      /* 'C+P-lb-soft'                   -> (C+P) / 2      tools.py:3961-3962 */
+};
+
+/* feature returned by add_new_block (tools.py:3716-3744) */
+enum { ORC_FEAT_FULL = 0, ORC_FEAT_ZERO = 1, ORC_FEAT_DIFF = 2 };
+
+/* error codes (negative) */
+enum {
+    ORC_OK = 0,
+    ORC_E_ARG = -1,        /* bad argument (dim, size < 1, too many blocks) */
+    ORC_E_HEIGHT = -2,     /* placement reaches above H: the reference raises IndexError
+                              (tools.py:2109) or silently clips voxels (tools.py:2169) */
+    ORC_E_REF_RAISES = -3, /* the reference would raise a Python exception here */
+    ORC_E_CAP = -4         /* internal capacity exceeded */
+};
+
+typedef struct {
+    int32_t D;          /* 2 | 3 */
+    int32_t W, L, H;    /* container_size; L = 1 when D == 2 */
+    int32_t n_max;      /* blocks_num */
+    int32_t strategy;   /* ORC_LB_GREEDY | ORC_MACS */
+    int32_t flags;      /* ORC_F_* */
+    int32_t ratio_mode; /* ORC_R_* */
+    int32_t feature;    /* ORC_FEAT_* */
+} orc_desc;
+
+typedef struct orc_env orc_env;
+
+/* tools.Container.__init__ (tools.py:3611-3661) */
+orc_env *orc_env_new(const orc_desc *d);
+void     orc_env_free(orc_env *e);
+/* tools.Container.clear_container (tools.py:3858-3885) */
+void     orc_env_clear(orc_env *e);
+/* tools.Container.add_new_block (tools.py:3663-3744).  `block` = D ints.
+ * feature_out (nullable): FULL/ZERO -> W*L ints; DIFF -> W-1 ints (2D) or 2*W*L ints (3D). */
+int      orc_env_add_block(orc_env *e, const int32_t *block, int32_t *feature_out);
+/* tools.Container.get_heightmap (tools.py:3824-3856) */
+void     orc_env_feature(const orc_env *e, int32_t *feature_out);
+/* tools.Container.calc_CPS / calc_ratio (tools.py:3887-3966) */
+void     orc_env_cps(const orc_env *e, double cps[3]);
+double   orc_env_ratio(const orc_env *e);
+
+/* state accessors */
+const int32_t *orc_env_heightmap(const orc_env *e); /* W*L, x-major */
+const int32_t *orc_env_positions(const orc_env *e); /* n_max*D */
+const uint8_t *orc_env_stable(const orc_env *e);    /* n_max */
+const int32_t *orc_env_container(const orc_env *e); /* W*L*H voxels, numpy (W,(L),H) order */
+int64_t  orc_env_valid(const orc_env *e);
+int64_t  orc_env_empty(const orc_env *e);
+int32_t  orc_env_count(const orc_env *e);           /* current_blocks_num */
+int32_t  orc_env_error(const orc_env *e);           /* sticky first error */
+int32_t  orc_feature_len(const orc_desc *d);
+
+/* predicates, exposed for the exhaustive pin tests */
+/* tools.is_stable_2d (tools.py:839-868); support[i] != 0 means supported */
+int orc_is_stable_2d(const int32_t *support, int obj_left, int obj_width);
+/* tools.is_stable (tools.py:710-765) on a support mask: mask[i*by+j] != 0 iff the voxel under
+ * footprint cell (i,j) is > 0.  z == 0 is handled by the caller. */
+int orc_is_stable_3d_mask(int bx, int by, const uint8_t *mask);
+
+/* ---- batched drivers (loops over envs; nthreads > 1 uses OpenMP when compiled in) ---- */
+
+/* B independent episodes from empty containers: blocks (B,n,D) int32 in placement order.
+ * Outputs (all nullable): positions (B,n,D), stable (B,n), features (B,n,feat_len),
+ * heightmaps (B,n,W*L) after every step, ratio64 (B,) = Container.calc_ratio(),
+ * cps (B,3), counters (B,3) = valid, empty, current_blocks_num, errs (B,).
+ * Returns the number of envs that hit an error. */
+int orc_run_episodes(const orc_desc *d, int B, int n, const int32_t *blocks,
+                     int32_t *positions, uint8_t *stable, int32_t *features,
+                     int32_t *heightmaps, double *ratio64, double *cps, int64_t *counters,
+                     int32_t *errs, int nthreads);
+
+/* tools.calc_positions_lb_greedy (tools.py:2393-2449): one episode, returns the UN-normalised
+ * ratio C+P+S and scores = [valid, box, empty, stable_num, max_h]. */
+int orc_calc_positions_lb_greedy(const orc_desc *d, int n, const int32_t *blocks,
+                                 int32_t *positions, uint8_t *stable, double *ratio,
+                                 int64_t scores[5]);
+
+/* pack.reward (pack.py:378-473): gather blocks by tour, full episode per env, -(C+P+S) as fp32.
+ * static_ (B, static_rows, nR) fp32; tour (B, n) int64; reward_out (B,) fp32. */
+int orc_reward(const orc_desc *d, int B, int n, int nR, int static_rows, const float *static_,
+               const int64_t *tour, float *reward_out, int nthreads);
+
+/* ---- precedence tensors (pack.py:276-376, model.py:297-307) ---- */
+
+/* initial mask, model.py:297-307.  dynamic (B, rows, nR) fp32, rows = 3n ('bot') or n. */
+void orc_initial_mask(int B, int n, int nR, int rows, const float *dynamic, float *mask_out);
+/* pack.update_dynamic, pack.py:333-376.  update_time = 1 | 3.  static_ (B, static_rows, nR). */
+void orc_update_dynamic(int B, int n, int nR, int rows, int update_time, int static_rows,
+                        const float *dyn_in, const float *static_, const int64_t *ptr,
+                        float *dyn_out);
+/* pack.update_mask, pack.py:276-331.  R = rotate_types.  Outputs: new_mask (current) and
+ * chosen_mask (persistent). */
+void orc_update_mask(int B, int n, int R, int rows, const float *mask_in, const float *dynamic,
+                     const int64_t *ptr, float *current_out, float *mask_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAP_ORACLE_H */

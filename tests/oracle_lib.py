@@ -1,0 +1,263 @@
+"""ctypes front-end for the CPU oracle (oracle/libtap_oracle.so).
+
+Test infrastructure: imported only by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+_LIB_PATH = os.path.join(ORACLE_DIR, "libtap_oracle.so")
+
+LB_GREEDY, MACS = 0, 1
+F_HARD, F_USE_P, F_USE_S, F_MCS_ZERO, F_MCS_TIE = 1, 2, 4, 8, 16
+R_C, R_CxS, R_CP, R_CPxS, R_CPS, R_2CPS, R_CxPxS, R_CP_HALF = range(8)
+FEAT = {"full": 0, "zero": 1, "diff": 2}
+
+_RATIO_TABLE = {  # tools.py:3919-3957
+    "comp": R_C, "soft": R_CxS, "hard": R_CxS, "pyrm": R_CP,
+    "pyrm-soft": R_CPxS, "pyrm-hard": R_CPxS, "mcs-soft": R_CPxS, "mcs-hard": R_CPxS,
+    "pyrm-soft-sum": R_CPS, "pyrm-soft-SUM": R_2CPS, "pyrm-hard-sum": R_CPS,
+    "pyrm-hard-SUM": R_2CPS, "CPS": R_CxPxS,
+}
+
+
+class Desc(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in
+                ("D", "W", "L", "H", "n_max", "strategy", "flags", "ratio_mode", "feature")]
+
+
+def build(force=False):
+    src = [os.path.join(ORACLE_DIR, f) for f in ("tap_oracle.c", "tap_oracle.h", "Makefile")]
+    if (force or not os.path.exists(_LIB_PATH)
+            or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src)):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_env_new.restype = C.c_void_p
+        L.orc_env_new.argtypes = [C.POINTER(Desc)]
+        L.orc_env_free.argtypes = [C.c_void_p]
+        L.orc_env_clear.argtypes = [C.c_void_p]
+        L.orc_env_add_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_env_feature.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_cps.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_env_ratio.restype = C.c_double
+        L.orc_env_ratio.argtypes = [C.c_void_p]
+        for name, rt in (("heightmap", C.POINTER(C.c_int32)), ("positions", C.POINTER(C.c_int32)),
+                         ("stable", C.POINTER(C.c_uint8)), ("container", C.POINTER(C.c_int32)),
+                         ("valid", C.c_int64), ("empty", C.c_int64), ("count", C.c_int32),
+                         ("error", C.c_int32)):
+            f = getattr(L, "orc_env_" + name)
+            f.restype = rt
+            f.argtypes = [C.c_void_p]
+        L.orc_feature_len.argtypes = [C.POINTER(Desc)]
+        L.orc_is_stable_2d.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_is_stable_3d_mask.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.orc_run_episodes.argtypes = [C.POINTER(Desc), C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int]
+        L.orc_calc_positions_lb_greedy.argtypes = [C.POINTER(Desc), C.c_int] + [C.c_void_p] * 5
+        L.orc_reward.argtypes = [C.POINTER(Desc), C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_initial_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
+        L.orc_update_dynamic.argtypes = [C.c_int] * 6 + [C.c_void_p] * 4
+        L.orc_update_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
+        _lib = L
+    return _lib
+
+
+def make_desc(container_size, blocks_num, reward_type, heightmap_type="diff",
+              packing_strategy="LB_GREEDY"):
+    """Same arguments as tools.Container.__init__ (tools.py:3611)."""
+    D = len(container_size)
+    W = int(container_size[0])
+    L = int(container_size[1]) if D == 3 else 1
+    H = int(container_size[-1])
+    # tools.py:3617-3620: the reward string overrides the strategy
+    if reward_type in ("C+P+S-mul-soft", "C+P+S-mul-hard"):
+        packing_strategy = "MUL"
+    elif reward_type in ("C+P+S-mcs-soft", "C+P+S-mcs-hard"):
+        packing_strategy = "MACS"
+    strategy = MACS if packing_strategy in ("MACS", "MUL") else LB_GREEDY
+    flags = 0
+    if reward_type.endswith("hard"):
+        flags |= F_HARD
+    if "P" in reward_type:
+        flags |= F_USE_P
+    if "S" in reward_type:
+        flags |= F_USE_S
+    if reward_type.startswith("mcs"):
+        flags |= F_MCS_ZERO
+    if "mcs" in reward_type:
+        flags |= F_MCS_TIE
+    if reward_type == "C+P-lb-soft":
+        rm = R_CP_HALF
+    else:
+        rm = _RATIO_TABLE.get(reward_type, R_CPS)
+    return Desc(D, W, L, H, int(blocks_num), strategy, flags, rm, FEAT[heightmap_type])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Env:
+    """One reference-shaped Container backed by the oracle."""
+
+    def __init__(self, container_size, blocks_num, reward_type, heightmap_type="diff",
+                 packing_strategy="LB_GREEDY"):
+        self.desc = make_desc(container_size, blocks_num, reward_type, heightmap_type, packing_strategy)
+        self._h = lib().orc_env_new(C.byref(self.desc))
+        if not self._h:
+            raise ValueError("oracle rejected the container description")
+        self.flen = lib().orc_feature_len(C.byref(self.desc))
+        self.D = self.desc.D
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_env_free(self._h)
+            self._h = None
+
+    def add_new_block(self, block):
+        blk = np.ascontiguousarray(np.asarray(block).astype(np.int32))
+        feat = np.zeros(max(self.flen, 1), np.int32)
+        rc = lib().orc_env_add_block(self._h, _p(blk), _p(feat))
+        return rc, self._shape_feature(feat[:self.flen])
+
+    def _shape_feature(self, f):
+        d = self.desc
+        if d.D == 3:
+            return f.reshape((2, d.W, d.L)) if d.feature == 2 else f.reshape((d.W, d.L))
+        return f
+
+    def clear(self):
+        lib().orc_env_clear(self._h)
+
+    def calc_ratio(self):
+        return lib().orc_env_ratio(self._h)
+
+    @property
+    def heightmap(self):
+        d = self.desc
+        a = np.ctypeslib.as_array(lib().orc_env_heightmap(self._h), (d.W * d.L,)).copy()
+        return a.reshape((d.W, d.L)) if d.D == 3 else a
+
+    @property
+    def positions(self):
+        d = self.desc
+        return np.ctypeslib.as_array(lib().orc_env_positions(self._h), (d.n_max, d.D)).copy()
+
+    @property
+    def stable(self):
+        return np.ctypeslib.as_array(lib().orc_env_stable(self._h), (self.desc.n_max,)).astype(bool)
+
+    @property
+    def container(self):
+        d = self.desc
+        shape = (d.W, d.L, d.H) if d.D == 3 else (d.W, d.H)
+        return np.ctypeslib.as_array(lib().orc_env_container(self._h), shape).copy()
+
+    @property
+    def valid_size(self):
+        return lib().orc_env_valid(self._h)
+
+    @property
+    def empty_size(self):
+        return lib().orc_env_empty(self._h)
+
+    @property
+    def error(self):
+        return lib().orc_env_error(self._h)
+
+
+def run_episodes(desc, blocks, nthreads=1, want_features=True, want_heightmaps=True):
+    """blocks: (B, n, D) ints -> dict of per-step / final outputs for B fresh episodes."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    B, n, D = blocks.shape
+    assert D == desc.D
+    fl = lib().orc_feature_len(C.byref(desc))
+    cells = desc.W * desc.L
+    out = dict(
+        positions=np.zeros((B, n, D), np.int32), stable=np.zeros((B, n), np.uint8),
+        features=np.zeros((B, n, fl), np.int32) if want_features else None,
+        heightmaps=np.zeros((B, n, cells), np.int32) if want_heightmaps else None,
+        ratio=np.zeros(B, np.float64), cps=np.zeros((B, 3), np.float64),
+        counters=np.zeros((B, 3), np.int64), errs=np.zeros(B, np.int32))
+    nerr = lib().orc_run_episodes(C.byref(desc), B, n, _p(blocks), _p(out["positions"]),
+                                  _p(out["stable"]), _p(out["features"]), _p(out["heightmaps"]),
+                                  _p(out["ratio"]), _p(out["cps"]), _p(out["counters"]),
+                                  _p(out["errs"]), nthreads)
+    out["nerr"] = nerr
+    return out
+
+
+def calc_positions_lb_greedy(blocks, container_size, reward_type):
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    n, D = blocks.shape
+    desc = make_desc(container_size, n, reward_type, "full", "LB_GREEDY")
+    pos = np.zeros((n, D), np.int32)
+    st = np.zeros(n, np.uint8)
+    ratio = C.c_double()
+    scores = np.zeros(5, np.int64)
+    rc = lib().orc_calc_positions_lb_greedy(C.byref(desc), n, _p(blocks), _p(pos), _p(st),
+                                            C.byref(ratio), _p(scores))
+    return rc, pos, st.astype(bool), ratio.value, scores
+
+
+def reward(static, tour, reward_type, container_width, container_height, nthreads=1):
+    static = np.ascontiguousarray(static, dtype=np.float32)
+    tour = np.ascontiguousarray(tour, dtype=np.int64)
+    B, rows, nR = static.shape
+    n = tour.shape[1]
+    D = rows - 1
+    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    desc = make_desc(cs, n, reward_type, "full", "LB_GREEDY")
+    out = np.zeros(B, np.float32)
+    nerr = lib().orc_reward(C.byref(desc), B, n, nR, rows, _p(static), _p(tour), _p(out), nthreads)
+    return nerr, out
+
+
+def initial_mask(dynamic, n):
+    dynamic = np.ascontiguousarray(dynamic, dtype=np.float32)
+    B, rows, nR = dynamic.shape
+    out = np.zeros((B, nR), np.float32)
+    lib().orc_initial_mask(B, n, nR, rows, _p(dynamic), _p(out))
+    return out
+
+
+def update_dynamic(dynamic, static, ptr, n, update_time=3):
+    dynamic = np.ascontiguousarray(dynamic, dtype=np.float32)
+    static = np.ascontiguousarray(static, dtype=np.float32)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    B, rows, nR = dynamic.shape
+    out = np.empty_like(dynamic)
+    lib().orc_update_dynamic(B, n, nR, rows, update_time, static.shape[1], _p(dynamic), _p(static),
+                             _p(ptr), _p(out))
+    return out
+
+
+def update_mask(mask, dynamic, ptr, n, R):
+    mask = np.ascontiguousarray(mask, dtype=np.float32)
+    dynamic = np.ascontiguousarray(dynamic, dtype=np.float32)
+    ptr = np.ascontiguousarray(ptr, dtype=np.int64)
+    B, rows, nR = dynamic.shape
+    cur = np.empty_like(mask)
+    new = np.empty_like(mask)
+    lib().orc_update_mask(B, n, R, rows, _p(mask), _p(dynamic), _p(ptr), _p(cur), _p(new))
+    return cur, new
+
+
+def is_stable_3d_mask(bx, by, mask):
+    m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
+    return bool(lib().orc_is_stable_3d_mask(bx, by, _p(m)))
