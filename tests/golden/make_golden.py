@@ -1,0 +1,347 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the UPSTREAM REFERENCE itself.
+
+Runs only in the build container (needs /root/reference); the GPU box gets the committed
+.npz files, never the reference.  Every fixture holds inputs and the reference's outputs --
+no reference source text.  Usage:
+
+    python tests/golden/make_golden.py [--only NAME ...]
+
+Fixtures:
+  lbg2d.npz, lbg3d.npz, macs2d.npz   tools.Container.add_new_block / calc_ratio step traces
+  stable3d.npz                       tools.is_stable, exhaustive over footprints <= 4x4 (+5xk samples)
+  dataset_2d.npz, dataset_3d.npz     pack.create_dataset -> text files -> pack.PACKDataset tensors
+  masks_2d.npz, masks_3d.npz         pack.update_dynamic / pack.update_mask traces on random feasible tapes
+  episode_2d.npz, episode_3d.npz     reference DRL.forward (pretrained actor, greedy) traces
+  reward_tour.npz                    pack.reward on those tours
+  kat.npz                            hand-checkable known answers
+"""
+import argparse
+import itertools
+import os
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import ref_loader  # noqa: E402
+
+warnings.filterwarnings("ignore")
+
+
+def rand_blocks(seed, B, n, D, lo=1, hi=5, marginal=True):
+    """RAND marginal: each side iid in {1..4}, p = [.15,.35,.35,.15] (generate.py:881-882,896)."""
+    rng = np.random.RandomState(seed)
+    if marginal and (lo, hi) == (1, 5):
+        return rng.choice([1, 2, 3, 4], size=(B, n, D), p=[0.15, 0.35, 0.35, 0.15]).astype(np.int8)
+    return rng.randint(lo, hi, size=(B, n, D)).astype(np.int8)
+
+
+def trace_container(tools, cs, n, reward, feat, strategy, blocks):
+    """Run B reference Containers step by step; return per-step traces."""
+    B = blocks.shape[0]
+    D = len(cs)
+    cells = int(np.prod(cs[:-1]))
+    feats, hms, poss, stabs, valids, emptys, ratios, cpss = [], [], [], [], [], [], [], []
+    for b in range(B):
+        c = tools.Container(list(cs), n, reward, feat, packing_strategy=strategy)
+        f_b, h_b, v_b, e_b = [], [], [], []
+        for t in range(n):
+            f = c.add_new_block(blocks[b, t].astype(np.float32), False)
+            f_b.append(np.asarray(f).reshape(-1).copy())
+            h_b.append(np.asarray(c.heightmap).reshape(-1).copy())
+            v_b.append(int(c.valid_size))
+            e_b.append(int(c.empty_size))
+        feats.append(f_b); hms.append(h_b); valids.append(v_b); emptys.append(e_b)
+        poss.append(np.asarray(c.positions).copy())
+        stabs.append(np.asarray(c.stable, dtype=bool).copy())
+        ratios.append(float(c.calc_ratio()))
+        cpss.append([float(x) for x in c.calc_CPS()])
+    return dict(
+        features=np.asarray(feats, dtype=np.int16).reshape(B, n, -1),
+        heightmaps=np.asarray(hms, dtype=np.int16).reshape(B, n, cells),
+        positions=np.asarray(poss, dtype=np.int16).reshape(B, n, D),
+        stable=np.asarray(stabs, dtype=np.uint8),
+        valid=np.asarray(valids, dtype=np.int32), empty=np.asarray(emptys, dtype=np.int32),
+        ratio=np.asarray(ratios, dtype=np.float64), cps=np.asarray(cpss, dtype=np.float64))
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print("wrote %-18s %7.1f KB" % (name, os.path.getsize(path) / 1024.0))
+
+
+def pack_cases(cases):
+    """cases: list of (meta dict, trace dict, blocks) -> flat npz dict with a `cases` index."""
+    out = {}
+    metas = []
+    for i, (meta, tr, blocks) in enumerate(cases):
+        metas.append(repr(meta))
+        out["c%d_blocks" % i] = blocks
+        for k, v in tr.items():
+            out["c%d_%s" % (i, k)] = v
+    out["cases"] = np.asarray(metas)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+
+def make_lbg2d(tools):
+    cases = []
+    for reward in ("C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft", "C+P-lb-hard"):
+        blocks = rand_blocks(101, 256, 10, 2)
+        meta = dict(cs=[5, 50], n=10, reward=reward, feat="diff", strategy="LB_GREEDY")
+        cases.append((meta, trace_container(tools, [5, 50], 10, reward, "diff", "LB_GREEDY", blocks), blocks))
+    # widths 1..8, sides 1..5 (includes blocks wider than the container), all three feature types
+    for W in range(1, 9):
+        for reward, feat in (("C+P+S-lb-soft", "diff"), ("C+P+S-lb-hard", "zero"), ("C+P-lb-soft", "full")):
+            blocks = rand_blocks(200 + W, 24, 8, 2, 1, 6, marginal=False)
+            meta = dict(cs=[W, 60], n=8, reward=reward, feat=feat, strategy="LB_GREEDY")
+            cases.append((meta, trace_container(tools, [W, 60], 8, reward, feat, "LB_GREEDY", blocks), blocks))
+    # config-4 shape driven by LB_GREEDY, n=20 W=7
+    blocks = rand_blocks(103, 64, 20, 2)
+    meta = dict(cs=[7, 100], n=20, reward="C+P+S-lb-soft", feat="diff", strategy="LB_GREEDY")
+    cases.append((meta, trace_container(tools, [7, 100], 20, "C+P+S-lb-soft", "diff", "LB_GREEDY", blocks), blocks))
+    save("lbg2d.npz", **pack_cases(cases))
+
+
+def make_lbg3d(tools):
+    cases = []
+    for reward in ("C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft"):
+        blocks = rand_blocks(301, 192, 10, 3)
+        meta = dict(cs=[5, 5, 50], n=10, reward=reward, feat="diff", strategy="LB_GREEDY")
+        cases.append((meta, trace_container(tools, [5, 5, 50], 10, reward, "diff", "LB_GREEDY", blocks), blocks))
+    # config-5 shape: 50 placements, H = 250
+    blocks = rand_blocks(302, 24, 50, 3)
+    meta = dict(cs=[5, 5, 250], n=50, reward="C+P+S-lb-soft", feat="diff", strategy="LB_GREEDY")
+    cases.append((meta, trace_container(tools, [5, 5, 250], 50, "C+P+S-lb-soft", "diff", "LB_GREEDY", blocks), blocks))
+    # other widths, bigger sides (footprints up to 6x6), other feature types
+    for W, hi, reward, feat in ((3, 4, "C+P+S-lb-soft", "full"), (4, 5, "C+P+S-lb-hard", "zero"),
+                                (6, 7, "C+P+S-lb-soft", "diff"), (7, 6, "C+P+S-lb-hard", "diff"),
+                                (8, 5, "C+P+S-lb-soft", "diff")):
+        blocks = rand_blocks(310 + W, 24, 12, 3, 1, hi, marginal=False)
+        meta = dict(cs=[W, W, 90], n=12, reward=reward, feat=feat, strategy="LB_GREEDY")
+        cases.append((meta, trace_container(tools, [W, W, 90], 12, reward, feat, "LB_GREEDY", blocks), blocks))
+    save("lbg3d.npz", **pack_cases(cases))
+
+
+def make_macs2d(tools):
+    cases = []
+    for reward in ("C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-lb-soft", "C+P+S-mul-soft",
+                   "C+P+S-mul-hard", "C+P-mcs-soft"):
+        blocks = rand_blocks(401, 96, 20, 2)
+        meta = dict(cs=[7, 100], n=20, reward=reward, feat="diff", strategy="MACS")
+        cases.append((meta, trace_container(tools, [7, 100], 20, reward, "diff", "MACS", blocks), blocks))
+    for W in (3, 4, 5, 6, 8):
+        for reward in ("C+P+S-mcs-soft", "C+P+S-mcs-hard"):
+            # sides <= W: the reference raises IndexError (tools.py:2550) once a block wider than
+            # the container has failed and a later step inspects its "top"
+            blocks = rand_blocks(410 + W, 32, 10, 2, 1, min(6, W + 1), marginal=False)
+            meta = dict(cs=[W, 60], n=10, reward=reward, feat="diff", strategy="MACS")
+            cases.append((meta, trace_container(tools, [W, 60], 10, reward, "diff", "MACS", blocks), blocks))
+    save("macs2d.npz", **pack_cases(cases))
+
+
+def make_stable3d(tools):
+    """tools.is_stable over every support mask of every footprint <= 4x4, plus samples for 5xk / kx5 / 6x6."""
+    shapes, offs, bits = [], [], []
+    rng = np.random.RandomState(7)
+    total = 0
+    sample_masks = {}
+    for bx, by in itertools.product(range(1, 7), range(1, 7)):
+        cells = bx * by
+        if bx <= 4 and by <= 4:
+            masks = np.arange(1 << cells, dtype=np.int64)
+        elif cells <= 36 and (bx <= 6 and by <= 6):
+            masks = rng.randint(0, 1 << min(cells, 62), size=1500, dtype=np.int64)
+            sample_masks["m_%d_%d" % (bx, by)] = masks
+        res = np.zeros(len(masks), np.uint8)
+        cont = np.zeros((bx, by, 3), dtype=int)
+        for mi, m in enumerate(masks):
+            # bit (i*by + j) of m = voxel under footprint cell (i, j) is occupied
+            lay = np.array([(int(m) >> k) & 1 for k in range(cells)], dtype=int).reshape(bx, by)
+            cont[:, :, 0] = lay
+            res[mi] = bool(tools.is_stable(np.array([bx, by, 1]), np.array([0, 0, 1]), cont))
+        shapes.append((bx, by)); offs.append(total); total += len(masks)
+        bits.append(res)
+    allbits = np.concatenate(bits)
+    save("stable3d.npz", shapes=np.asarray(shapes, np.int8), offsets=np.asarray(offs, np.int64),
+         bits=np.packbits(allbits), count=np.int64(total), **sample_masks)
+
+
+def _ref_dataset(pack, D, n, count, seed, tmp):
+    """pack.create_dataset -> (dir, raw text lines) for `count` validation samples."""
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        _, valid_dir = pack.create_dataset(n, 2, count, D, 7, 50, 1, [1, 5], seed=seed)
+        valid_dir = os.path.abspath(valid_dir) + "/"
+    finally:
+        os.chdir(cwd)
+    return valid_dir
+
+
+def make_dataset(pack, D, tmp, count):
+    import torch
+    n = 10
+    vdir = _ref_dataset(pack, D, n, count, 12345, tmp)
+    ds = pack.PACKDataset(vdir, n, count, 12345, "bot", "diff", True, 5, unit=1)
+    files = {}
+    for f in ("blocks", "pos", "container", "dep_move", "dep_small", "dep_large"):
+        files["txt_" + f] = np.loadtxt(vdir + f + ".txt").astype(np.int8)
+    static = ds.static.detach().numpy().astype(np.int8)        # small ints stored as floats
+    dynamic = ds.dynamic.detach().numpy().astype(np.int8)
+    assert np.array_equal(static.astype(np.float32), ds.static.detach().numpy())
+    assert np.array_equal(dynamic.astype(np.float32), ds.dynamic.detach().numpy())
+    save("dataset_%dd.npz" % D, static=static, dynamic=dynamic,
+         decoder_static_shape=np.asarray(ds.decoder_static.shape),
+         decoder_dynamic_shape=np.asarray(ds.decoder_dynamic.shape), **files)
+    return torch.from_numpy(static.astype(np.float32)), torch.from_numpy(dynamic.astype(np.float32))
+
+
+def make_masks(pack, D, static, dynamic):
+    """Random feasible action tapes through the reference's update_dynamic / update_mask."""
+    import torch
+    B, rows, nR = dynamic.shape
+    n = rows // 3
+    R = nR // n
+    rng = np.random.RandomState(55 + D)
+    mask = torch.ones(B, nR)
+    move = dynamic[:, :n].sum(1); small = dynamic[:, n:2 * n].sum(1); large = dynamic[:, 2 * n:].sum(1)
+    cur = mask.clone()
+    cur[(small * large + move).ne(0)] = 0.                      # model.py:297-307
+    init_mask = cur.numpy().astype(np.uint8)
+    dyn = dynamic
+    ptrs, curs, masks, dyns = [], [], [], []
+    for _ in range(n):
+        c = cur.numpy()
+        assert (c.sum(1) > 0).all(), "dead end in reference data"
+        ptr = np.array([rng.choice(np.flatnonzero(c[b])) for b in range(B)], dtype=np.int64)
+        ptr_t = torch.from_numpy(ptr)
+        dyn = pack.update_dynamic(dyn, static, ptr_t, "bot", True)
+        cur, mask = pack.update_mask(mask, dyn, static, ptr_t, "bot", True)
+        ptrs.append(ptr); curs.append(cur.numpy().astype(np.uint8)); masks.append(mask.numpy().astype(np.uint8))
+        dyns.append(np.packbits(dyn.numpy().astype(np.uint8), axis=None))
+    assert not mask.byte().any()
+    save("masks_%dd.npz" % D, ptr=np.asarray(ptrs, np.int16), initial_mask=init_mask,
+         current_mask=np.asarray(curs), mask=np.asarray(masks), dynamic_bits=np.asarray(dyns),
+         dyn_shape=np.asarray(dynamic.shape))
+
+
+def make_episode(tools, pack, D, static, dynamic):
+    """Reference DRL.forward, pretrained actor, greedy -- trace everything that crosses the seams."""
+    import torch
+    sys.path.insert(0, ref_loader.REFERENCE_DIR)
+    import model as ref_model
+    sys.path.remove(ref_loader.REFERENCE_DIR)
+    n = 10
+    rec = dict(feat=[], cur=[], mask=[], dyn=[])
+
+    def upd(dynamic_, static_, ptr, input_type, allow_rot):
+        out = pack.update_dynamic(dynamic_, static_, ptr, input_type, allow_rot)
+        rec["dyn"].append(np.packbits(out.numpy().astype(np.uint8), axis=None))
+        return out
+
+    def msk(mask_, dynamic_, static_, ptr, input_type, allow_rot):
+        c, m = pack.update_mask(mask_, dynamic_, static_, ptr, input_type, allow_rot)
+        rec["cur"].append(c.numpy().astype(np.uint8)); rec["mask"].append(m.numpy().astype(np.uint8))
+        return c, m
+
+    orig_add = tools.Container.add_new_block
+
+    def add(self, block, is_rotate=False):
+        hm = orig_add(self, block, is_rotate)
+        rec["feat"].append(np.asarray(hm).reshape(-1).copy())
+        return hm
+
+    tools.Container.add_new_block = add
+    try:
+        actor = ref_model.DRL(D, 3 * n, 128, 256, False, "bot", True, 5, 50, D, "C+P+S-lb-soft",
+                              "shape_heightmap", "diff", "LB_GREEDY", upd, msk, 1, 0.1, 1.0)
+        ck = os.path.join(ref_loader.REFERENCE_DIR, "pretrain_model",
+                          "%dd-bot-C+P+S-lb-soft-width-5-note-sh-R-diff" % D, "actor.pt")
+        actor.load_state_dict(torch.load(ck, map_location="cpu"))
+        actor.eval()
+        B = static.shape[0]
+        dec_static = torch.zeros(B, D, 1)
+        dec_dynamic = torch.zeros(B, 4, 1) if D == 2 else torch.zeros(B, 2, 5, 5)
+        with torch.no_grad():
+            tour_idx, tour_logp, _, neg_scores = actor(static, dynamic, [dec_static, dec_dynamic])
+    finally:
+        tools.Container.add_new_block = orig_add
+    steps = tour_idx.shape[1]
+    feats = np.asarray(rec["feat"], np.int16).reshape(steps, B, -1)
+    save("episode_%dd.npz" % D, tour_idx=tour_idx.numpy().astype(np.int16), features=feats,
+         current_mask=np.asarray(rec["cur"]), mask=np.asarray(rec["mask"]),
+         dynamic_bits=np.asarray(rec["dyn"]), neg_scores=neg_scores.numpy().astype(np.float32),
+         mean_reward=np.float64(neg_scores.mean().item()))
+    return tour_idx
+
+
+def make_reward_tour(pack, tours, statics):
+    out = {}
+    for D in (2, 3):
+        r = pack.reward(statics[D], tours[D], "C+P+S-lb-soft", "bot", True, 5, 50, "LB_GREEDY")
+        out["reward_%dd" % D] = r.numpy().astype(np.float32)
+        # a second, non-trivial tape: reversed tour with swapped rotation
+        out["tour_%dd" % D] = tours[D].numpy().astype(np.int16)
+    save("reward_tour.npz", **out)
+
+
+def make_kat(tools):
+    """Appendix-G style known answers, incl. calc_positions_lb_greedy's un-normalised ratio."""
+    out = {}
+    k2 = np.array([[3, 2], [1, 1], [1, 2], [2, 4], [5, 1]])
+    pos, _, st, ratio, scores = tools.calc_positions_lb_greedy(k2, [5, 50], "C+P+S-lb-soft")
+    out.update(k2_blocks=k2, k2_pos=pos, k2_stable=np.asarray(st), k2_ratio=np.float64(ratio),
+               k2_scores=np.asarray(scores, np.int64))
+    k3 = np.array([[3, 2, 2], [1, 1, 3], [1, 2, 1], [2, 4, 2], [5, 1, 1], [2, 2, 2]])
+    pos, _, st, ratio, scores = tools.calc_positions_lb_greedy(k3, [5, 5, 50], "C+P+S-lb-soft")
+    out.update(k3_blocks=k3, k3_pos=pos, k3_stable=np.asarray(st), k3_ratio=np.float64(ratio),
+               k3_scores=np.asarray(scores, np.int64))
+    k7 = np.array([[3, 2], [2, 1], [4, 1], [1, 3], [2, 2], [3, 1], [1, 1], [2, 3]])
+    for tag, reward in (("soft", "C+P+S-lb-soft"), ("hard", "C+P+S-lb-hard"), ("cp", "C+P-lb-hard")):
+        pos, _, st, ratio, scores = tools.calc_positions_lb_greedy(k7, [7, 50], reward)
+        out.update({"k7_%s_pos" % tag: pos, "k7_%s_stable" % tag: np.asarray(st),
+                    "k7_%s_ratio" % tag: np.float64(ratio), "k7_%s_scores" % tag: np.asarray(scores, np.int64)})
+    out["k7_blocks"] = k7
+    # a block that never fits: all-failed container -> nan ratio (0/0), counters untouched
+    c = tools.Container([3, 20], 2, "C+P+S-lb-soft", "diff")
+    f = c.add_new_block(np.array([4, 1], np.float32))
+    out.update(fail_feature=np.asarray(f), fail_ratio=np.float64(c.calc_ratio()),
+               fail_valid=np.int64(c.valid_size), fail_count=np.int64(c.current_blocks_num))
+    save("kat.npz", **out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    mods = ref_loader.load()
+    if mods is None:
+        sys.exit("reference checkout not found at %s" % ref_loader.REFERENCE_DIR)
+    tools, pack, _ = mods
+    import torch
+    torch.manual_seed(0)
+    want = lambda k: args.only is None or k in args.only  # noqa: E731
+    if want("lbg2d"): make_lbg2d(tools)
+    if want("lbg3d"): make_lbg3d(tools)
+    if want("macs2d"): make_macs2d(tools)
+    if want("stable3d"): make_stable3d(tools)
+    if want("kat"): make_kat(tools)
+    if want("data"):
+        with tempfile.TemporaryDirectory() as tmp:
+            statics, dynamics, tours = {}, {}, {}
+            for D, count in ((2, 256), (3, 64)):
+                statics[D], dynamics[D] = make_dataset(pack, D, tmp, count)
+                make_masks(pack, D, statics[D], dynamics[D])
+                tours[D] = make_episode(tools, pack, D, statics[D], dynamics[D])
+            make_reward_tour(pack, tours, statics)
+
+
+if __name__ == "__main__":
+    main()

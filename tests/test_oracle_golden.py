@@ -1,0 +1,154 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself (CPU only)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_lib as O
+
+
+def _check_trace(meta, tr):
+    desc = O.make_desc(meta["cs"], meta["n"], meta["reward"], meta["feat"], meta["strategy"])
+    out = O.run_episodes(desc, tr["blocks"].astype(np.int32))
+    assert out["nerr"] == 0, meta
+    B, n = tr["blocks"].shape[:2]
+    assert np.array_equal(out["positions"], tr["positions"]), meta
+    assert np.array_equal(out["stable"], tr["stable"]), meta
+    assert np.array_equal(out["features"], tr["features"].reshape(B, n, -1)), meta
+    assert np.array_equal(out["heightmaps"], tr["heightmaps"]), meta
+    assert np.array_equal(out["counters"][:, 0], tr["valid"][:, -1]), meta
+    assert np.array_equal(out["counters"][:, 1], tr["empty"][:, -1]), meta
+    # fp64 ratios bit-for-bit (NaN where the reference gives NaN)
+    assert np.array_equal(out["ratio"].view(np.int64), tr["ratio"].view(np.int64)) or \
+        np.array_equal(np.nan_to_num(out["ratio"], nan=-7.0), np.nan_to_num(tr["ratio"], nan=-7.0)), meta
+    assert np.array_equal(np.nan_to_num(out["cps"], nan=-7.0), np.nan_to_num(tr["cps"], nan=-7.0)), meta
+
+
+@pytest.mark.parametrize("fixture", ["lbg2d.npz", "lbg3d.npz", "macs2d.npz"])
+def test_container_traces(fixture):
+    ncases = 0
+    for meta, tr in G.cases(fixture):
+        _check_trace(meta, tr)
+        ncases += 1
+    assert ncases >= 8
+
+
+def test_per_step_counters_2d():
+    """valid/empty after every step, via the step-wise Env API."""
+    for meta, tr in G.cases("lbg2d.npz"):
+        env = O.Env(meta["cs"], meta["n"], meta["reward"], meta["feat"], meta["strategy"])
+        for b in range(min(8, tr["blocks"].shape[0])):
+            env.clear()
+            for t in range(meta["n"]):
+                rc, _ = env.add_new_block(tr["blocks"][b, t])
+                assert rc == 0
+                assert env.valid_size == tr["valid"][b, t] and env.empty_size == tr["empty"][b, t]
+
+
+def test_is_stable_3d_exhaustive():
+    z = G.load("stable3d.npz")
+    bits = np.unpackbits(z["bits"])[: int(z["count"])]
+    checked = 0
+    for (bx, by), off in zip(z["shapes"], z["offsets"]):
+        bx, by = int(bx), int(by)
+        cells = bx * by
+        key = "m_%d_%d" % (bx, by)
+        masks = z[key] if key in z.files else np.arange(1 << cells, dtype=np.int64)
+        for mi, m in enumerate(masks):
+            lay = np.array([(int(m) >> k) & 1 for k in range(cells)], dtype=np.uint8)
+            assert O.is_stable_3d_mask(bx, by, lay) == bool(bits[off + mi]), (bx, by, int(m))
+            checked += 1
+    assert checked == int(z["count"]) and checked > 100000
+
+
+def test_known_answers():
+    k = G.load("kat.npz")
+    rc, pos, st, ratio, scores = O.calc_positions_lb_greedy(k["k2_blocks"], [5, 50], "C+P+S-lb-soft")
+    assert rc == 0 and np.array_equal(pos, k["k2_pos"]) and np.array_equal(st, k["k2_stable"])
+    assert ratio == float(k["k2_ratio"]) and np.array_equal(scores, k["k2_scores"])
+    # SURVEY appendix G, human-checkable
+    assert pos.tolist() == [[0, 0], [3, 0], [4, 0], [0, 2], [0, 6]] and st.tolist() == [1, 1, 1, 1, 0]
+    rc, pos, st, ratio, scores = O.calc_positions_lb_greedy(k["k3_blocks"], [5, 5, 50], "C+P+S-lb-soft")
+    assert rc == 0 and np.array_equal(pos, k["k3_pos"]) and np.array_equal(st, k["k3_stable"])
+    assert ratio == float(k["k3_ratio"]) == 1.9197701149425286 and scores.tolist() == [46, 100, 12, 4, 4]
+    for tag, reward in (("soft", "C+P+S-lb-soft"), ("hard", "C+P+S-lb-hard"), ("cp", "C+P-lb-hard")):
+        rc, pos, st, ratio, scores = O.calc_positions_lb_greedy(k["k7_blocks"], [7, 50], reward)
+        assert rc == 0 and np.array_equal(pos, k["k7_%s_pos" % tag])
+        assert np.array_equal(st, k["k7_%s_stable" % tag]) and ratio == float(k["k7_%s_ratio" % tag])
+        assert np.array_equal(scores, k["k7_%s_scores" % tag])
+    # a block wider than the container: no-op, counters untouched, step still counted, ratio NaN
+    env = O.Env([3, 20], 2, "C+P+S-lb-soft", "diff")
+    rc, f = env.add_new_block([4, 1])
+    assert rc == 0 and np.array_equal(f, k["fail_feature"]) and env.valid_size == int(k["fail_valid"]) == 0
+    assert np.isnan(env.calc_ratio()) and np.isnan(float(k["fail_ratio"]))
+
+
+def test_height_overflow_flag():
+    env = O.Env([2, 6], 4, "C+P+S-lb-soft", "diff")
+    for _ in range(3):
+        rc, _ = env.add_new_block([2, 2])
+        assert rc == 0
+    rc, _ = env.add_new_block([2, 2])          # 6 + 2 > H
+    assert rc == -2 and env.error == -2
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_masks_trace(D):
+    ds = G.load("dataset_%dd.npz" % D)
+    mk = G.load("masks_%dd.npz" % D)
+    static = ds["static"].astype(np.float32)
+    dynamic = ds["dynamic"].astype(np.float32)
+    B, rows, nR = dynamic.shape
+    n = rows // 3
+    R = nR // n
+    cur = O.initial_mask(dynamic, n)
+    assert np.array_equal(cur, mk["initial_mask"].astype(np.float32))
+    mask = np.ones((B, nR), np.float32)
+    dyn = dynamic
+    for t in range(mk["ptr"].shape[0]):
+        ptr = mk["ptr"][t].astype(np.int64)
+        dyn = O.update_dynamic(dyn, static, ptr, n, 3)
+        cur, mask = O.update_mask(mask, dyn, ptr, n, R)
+        assert np.array_equal(dyn, G.unpack_dynamic(mk["dynamic_bits"][t], dynamic.shape)), t
+        assert np.array_equal(cur, mk["current_mask"][t].astype(np.float32)), t
+        assert np.array_equal(mask, mk["mask"][t].astype(np.float32)), t
+    assert not mask.any()
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_episode_trace(D):
+    """Replay the reference actor's greedy tour: features, masks, dynamic and scores must match."""
+    ds = G.load("dataset_%dd.npz" % D)
+    ep = G.load("episode_%dd.npz" % D)
+    static = ds["static"].astype(np.float32)
+    dynamic = ds["dynamic"].astype(np.float32)
+    B, rows, nR = dynamic.shape
+    n = rows // 3
+    R = nR // n
+    tour = ep["tour_idx"].astype(np.int64)
+    cs = [5, 50] if D == 2 else [5, 5, 50]
+    envs = [O.Env(cs, n, "C+P+S-lb-soft", "diff") for _ in range(B)]
+    mask = np.ones((B, nR), np.float32)
+    dyn = dynamic
+    for t in range(tour.shape[1]):
+        ptr = tour[:, t]
+        dyn = O.update_dynamic(dyn, static, ptr, n, 3)
+        cur, mask = O.update_mask(mask, dyn, ptr, n, R)
+        assert np.array_equal(dyn, G.unpack_dynamic(ep["dynamic_bits"][t], dynamic.shape))
+        assert np.array_equal(cur, ep["current_mask"][t].astype(np.float32))
+        assert np.array_equal(mask, ep["mask"][t].astype(np.float32))
+        blocks = static[np.arange(B), 1:, ptr]                    # model.py:404-412
+        for b in range(B):
+            rc, f = envs[b].add_new_block(blocks[b])
+            assert rc == 0
+            assert np.array_equal(f.reshape(-1), ep["features"][t, b])
+    scores = np.array([e.calc_ratio() for e in envs]).astype(np.float32)   # model.py:499,510
+    assert np.array_equal(-scores, ep["neg_scores"])
+
+
+def test_reward_tour():
+    rt = G.load("reward_tour.npz")
+    for D in (2, 3):
+        ds = G.load("dataset_%dd.npz" % D)
+        nerr, r = O.reward(ds["static"].astype(np.float32), rt["tour_%dd" % D].astype(np.int64),
+                           "C+P+S-lb-soft", 5, 50)
+        assert nerr == 0 and np.array_equal(r, rt["reward_%dd" % D])

@@ -1,0 +1,77 @@
+"""Live differential test: CPU oracle vs the imported reference (build container only).
+
+Skipped wherever /root/reference is absent (e.g. the GPU box).  Compares the *full* state after
+every step, including the voxel grid.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_loader
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not ref_loader.available(), reason="reference checkout not present")]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return ref_loader.load()
+
+
+def _diff(tools, cs, n, reward, feat, strategy, episodes, seed, lo=1, hi=5):
+    rng = np.random.RandomState(seed)
+    D = len(cs)
+    for ep in range(episodes):
+        blocks = rng.randint(lo, hi, size=(n, D))
+        r = tools.Container(list(cs), n, reward, feat, packing_strategy=strategy)
+        o = O.Env(cs, n, reward, feat, strategy)
+        for t in range(n):
+            rf = r.add_new_block(blocks[t].astype(np.float32))
+            rc, of = o.add_new_block(blocks[t])
+            ctx = (cs, reward, strategy, ep, t, blocks[: t + 1].tolist())
+            assert rc == 0, ctx
+            assert np.array_equal(np.asarray(rf), of), ctx
+            assert np.array_equal(r.heightmap, o.heightmap), ctx
+            assert np.array_equal(r.positions, o.positions), ctx
+            assert list(r.stable) == o.stable.tolist(), ctx
+            assert int(r.valid_size) == o.valid_size and int(r.empty_size) == o.empty_size, ctx
+            assert np.array_equal(r.container, o.container), ctx
+        a, b = float(r.calc_ratio()), o.calc_ratio()
+        assert a == b or (np.isnan(a) and np.isnan(b))
+
+
+@pytest.mark.parametrize("reward", ["C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft", "C+P-lb-hard"])
+def test_lbg2d(ref, reward):
+    _diff(ref[0], [5, 50], 10, reward, "diff", "LB_GREEDY", 60, 11)
+    _diff(ref[0], [7, 100], 20, reward, "zero", "LB_GREEDY", 20, 12)
+    _diff(ref[0], [3, 60], 8, reward, "full", "LB_GREEDY", 20, 13, 1, 6)
+
+
+@pytest.mark.parametrize("reward", ["C+P+S-lb-soft", "C+P+S-lb-hard"])
+def test_lbg3d(ref, reward):
+    _diff(ref[0], [5, 5, 50], 10, reward, "diff", "LB_GREEDY", 40, 21)
+    _diff(ref[0], [5, 5, 250], 30, reward, "full", "LB_GREEDY", 6, 22)
+    _diff(ref[0], [6, 6, 80], 12, reward, "diff", "LB_GREEDY", 12, 23, 1, 7)
+
+
+@pytest.mark.parametrize("reward", ["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "C+P-mcs-soft"])
+def test_macs2d(ref, reward):
+    _diff(ref[0], [7, 100], 20, reward, "diff", "MACS", 25, 31)
+    _diff(ref[0], [5, 50], 10, reward, "diff", "MACS", 40, 32)
+
+
+def test_masks(ref):
+    import torch
+    pack = ref[1]
+    rng = np.random.RandomState(5)
+    B, n, R = 32, 6, 2
+    dyn = (rng.rand(B, 3 * n, n * R) < 0.12).astype(np.float32)
+    static = np.zeros((B, 3, n * R), np.float32)
+    static[:, 0, :] = np.tile(np.arange(n), R)
+    mask = (rng.rand(B, n * R) < 0.8).astype(np.float32)
+    ptr = rng.randint(0, n * R, size=B).astype(np.int64)
+    rd = pack.update_dynamic(torch.from_numpy(dyn), torch.from_numpy(static), torch.from_numpy(ptr), "bot", True)
+    rc, rm = pack.update_mask(torch.from_numpy(mask), rd, torch.from_numpy(static), torch.from_numpy(ptr), "bot", True)
+    od = O.update_dynamic(dyn, static, ptr, n, 3)
+    oc, om = O.update_mask(mask, od, ptr, n, R)
+    assert np.array_equal(rd.numpy(), od) and np.array_equal(rc.numpy(), oc) and np.array_equal(rm.numpy(), om)
