@@ -1,0 +1,312 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched Transport-and-Pack environment hot path on MI355X.
+
+One "step" = one full pass of the hot path over one batch of synthetic instances:
+    reset -> n x [ update_dynamic + update_mask (one launch) ; add_new_block (one launch) ]
+          -> calc_ratio (one launch) [-> all-gather of the (B,) reward vector when N > 1]
+i.e. what DRL.forward does around its policy network for one batch (model.py:294-515), with the
+actions replayed from a pre-computed feasible tape.  value = env-steps/s = (placements in all
+envs on all ranks) / wall time, inputs resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--batch B]
+                    [--no-graph] [--no-cpu-baseline] [--sweep]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import tap_net_amd as T                     # noqa: E402
+from tap_net_amd import _lib, synth         # noqa: E402
+from tap_net_amd import dist as tdist       # noqa: E402
+
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+
+CONFIGS = {
+    # name: (workload string, D, container, n, per-GPU batch, reward, strategy)
+    "c2": ("2D RAND nodes=10 container_width=5 LB_GREEDY batch=8192 on 1xMI355X (BASELINE configs[1])",
+           2, [5, 50], 10, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
+    "c3": ("3D RAND nodes=10 container_width=5x5 LB_GREEDY batch=4096 on 1xMI355X (BASELINE configs[2])",
+           3, [5, 5, 50], 10, 4096, "C+P+S-lb-soft", "LB_GREEDY"),
+    "c4": ("2D nodes=20 container_width=7 MACS batch=8192 on 1xMI355X (BASELINE configs[3], RAND-marginal blocks)",
+           2, [7, 100], 20, 8192, "C+P+S-mcs-soft", "MACS"),
+    "c5": ("3D nodes=50 container_width=5x5 H=250 LB_GREEDY batch=8192 per GPU (BASELINE configs[4] shard)",
+           3, [5, 5, 250], 50, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
+}
+
+
+def algorithmic_bytes(D, cs, n):
+    """SURVEY.md 8(d) per-env-step figures (int32 state as the neutral unit)."""
+    cells = int(np.prod(cs[:-1]))
+    flen = cs[0] - 1 if D == 2 else 2 * cells
+    env = (cells * 4 + D * 4 + 16) + (cells * 4 + 16 + D * 4 + 4 + flen * 4)
+    R = 2 if D == 2 else 6
+    nR = n * R
+    mask = (3 * n * nR * 4 + nR * 4 + 8) + (3 * n * nR * 4 + 2 * nR * 4)
+    return env, mask
+
+
+class HotPath(object):
+    """Pre-allocated buffers + direct C-ABI calls for one rank's share of the batch."""
+
+    def __init__(self, cfg, B, start, device, seed=12345):
+        _, D, cs, n, _, reward, strategy = cfg
+        self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
+        static, dynamic = synth.rand_instances(B, n, D, seed=seed, start=start)
+        tape = synth.random_feasible_tape(static, dynamic, n, seed=seed + 1, start=start)
+        self.static = static.to(device)
+        self.dynamic0 = dynamic.to(device)
+        self.tape = tape.t().contiguous().to(device)          # (n, B): one contiguous ptr row per step
+        self.R = static.shape[2] // n
+        self.nR, self.rows = static.shape[2], dynamic.shape[1]
+        self.env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        self.dyn = [torch.empty_like(self.dynamic0), torch.empty_like(self.dynamic0)]
+        self.cs0 = T.pack.dynamic_colsum(self.dynamic0, n).clone()
+        self.csb = [torch.empty_like(self.cs0), torch.empty_like(self.cs0)]
+        self.mask0 = torch.ones(B, self.nR, **f32)
+        self.maskb = [torch.empty(B, self.nR, **f32), torch.empty(B, self.nR, **f32)]
+        self.cur = torch.empty(B, self.nR, **f32)
+        self.feat = torch.empty(self.env._feature_shape(), **f32)
+        self.reward = torch.empty(B, **f32)
+        self.lib = _lib.lib()
+        self.ctx = _lib.ctx(device)
+        self.hook = None                                     # optional per-kernel timing hook
+
+    def _k(self, name, fn, *args):
+        stream = _lib.stream_of(self.device)
+        if self.hook:
+            self.hook(name, lambda: _lib.check(fn(*args, stream), self.ctx))
+        else:
+            _lib.check(fn(*args, stream), self.ctx)
+
+    def episode(self):
+        L, P, e = self.lib, _lib.ptr, self.env
+        d = C.byref(e.desc)
+        self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
+        dyn_in, cs_in, mask_in = self.dynamic0, self.cs0, self.mask0
+        for t in range(self.n):
+            ptr = self.tape[t]
+            o = t & 1
+            self._k("mask_step", L.tap_mask_step, self.ctx, self.B, self.n, self.R, self.rows, 3,
+                    P(dyn_in), P(self.static), self.static.shape[1], P(ptr), P(mask_in), P(cs_in),
+                    P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]))
+            dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
+            self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(self.static),
+                    self.static.shape[1], self.nR, P(ptr), None, P(self.feat))
+        self._k("ratio", L.tap_env_ratio, self.ctx, d, P(e._state), P(self.reward), None, None)
+
+
+def time_passes(hp, steps, warmup, use_graph, world):
+    dev = hp.device
+    handles = []
+
+    def one_pass(g):
+        if g is not None:
+            g.replay()
+        else:
+            hp.episode()
+        if world > 1:                                           # the only exchange: the reward vector
+            import torch.distributed as dist
+            out = [torch.empty_like(hp.reward) for _ in range(world)]
+            handles.append((dist.all_gather(out, hp.reward, async_op=True), out))
+
+    graph = None
+    if use_graph:
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):
+            hp.episode()                                        # warm the allocator / lazy init
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            hp.episode()
+    for _ in range(warmup):
+        one_pass(graph)
+    for h, _ in handles:
+        h.wait()
+    handles.clear()
+    tdist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one_pass(graph)
+    for h, _ in handles:
+        h.wait()
+    torch.cuda.synchronize(dev)
+    tdist.barrier()
+    dt = time.perf_counter() - t0
+    return tdist.max_over_ranks(dt, dev), graph
+
+
+def kernel_event_times(hp, steps):
+    """Per-launch durations with HIP events on the launch stream (torch.cuda.Event on torch's
+    current stream == the stream the kernels are enqueued on), over `steps` eager passes."""
+    recs = {}
+
+    def hook(name, launch):
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b.record()
+        recs.setdefault(name, []).append((a, b))
+
+    hp.hook = hook
+    try:
+        for _ in range(steps):
+            hp.episode()
+        torch.cuda.synchronize(hp.device)
+    finally:
+        hp.hook = None
+    # cost of an empty event pair, to show how much of a short kernel's figure is event overhead
+    pairs = []
+    for _ in range(64):
+        a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+        a.record(); b.record(); pairs.append((a, b))
+    torch.cuda.synchronize(hp.device)
+    empty_us = float(np.median([a.elapsed_time(b) for a, b in pairs]) * 1e3)
+    out = {}
+    for name, evs in recs.items():
+        us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+        out[name] = dict(launches=len(us), avg_us=float(us.mean()), med_us=float(np.median(us)),
+                         total_us=float(us.sum()))
+    return out, empty_us
+
+
+def cpu_baseline(cfg, budget_s=12.0):
+    """The oracle (C port of the reference algorithm) over the same pass, on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    _, D, cs, n, B, reward, strategy = cfg
+    B = min(B, 4096)
+    static, dynamic = synth.rand_instances(B, n, D, seed=12345)
+    tape = synth.random_feasible_tape(static, dynamic, n, seed=12346).numpy()
+    st, dyn0 = static.numpy(), dynamic.numpy()
+    R = st.shape[2] // n
+    blocks = np.stack([st[np.arange(B), 1:, tape[:, t]] for t in range(n)], axis=1).astype(np.int32)
+    desc = O.make_desc(cs, n, reward, "diff", strategy)
+    O.lib()
+    done, t0 = 0, time.perf_counter()
+    while True:
+        dyn, mask = dyn0, np.ones((B, st.shape[2]), np.float32)
+        O.initial_mask(dyn, n)
+        for t in range(n):
+            dyn = O.update_dynamic(dyn, st, tape[:, t], n, 3)
+            _, mask = O.update_mask(mask, dyn, tape[:, t], n, R)
+        r = O.run_episodes(desc, blocks, nthreads=1, want_heightmaps=False)
+        assert r["nerr"] == 0
+        done += B * n
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return dict(value=done / el, unit="env-steps/s", cores=1, kind="port",
+                sample="%d passes of B=%d envs x n=%d (masks + placements + ratio), %.1f s, "
+                       "oracle/libtap_oracle.so single thread" % (done // (B * n), B, n, el))
+
+
+def load_traffic(name):
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(name)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
+    args = ap.parse_args()
+
+    rank, world, local = tdist.init_from_env()
+    if world != args.gpus and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: libtapenv has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    cfg = CONFIGS[args.config]
+    name, D, cs, n, B, reward, strategy = cfg
+    if args.batch:
+        B = args.batch
+        cfg = (name, D, cs, n, B, reward, strategy)
+    hp = HotPath(cfg, B, rank * B, dev)
+    use_graph = not args.no_graph
+    dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
+    hp.env.check()
+    total_steps = B * world * n * args.steps
+    value = total_steps / dt
+
+    out = None
+    if rank == 0:
+        kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)))
+        env_b, mask_b = algorithmic_bytes(D, cs, n)
+        per_launch = {"env_step": env_b * B, "mask_step": mask_b * B}
+        dom = max(("env_step", "mask_step"), key=lambda k: kt[k]["total_us"])
+        ach = per_launch[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
+        kernels = {}
+        for k in ("mask_step", "env_step", "ratio", "reset"):
+            kernels[k] = dict(avg_us=round(kt[k]["avg_us"], 3), launches_per_pass=kt[k]["launches"] // max(3, min(args.steps, 20)))
+            if k in per_launch:
+                kernels[k]["alg_bytes_per_launch"] = per_launch[k]
+                kernels[k]["alg_GBps"] = round(per_launch[k] / (kt[k]["avg_us"] * 1e-6) / 1e9, 2)
+        out = {
+            "metric": "env-steps/s (batch placements) 2D n=10 LB_GREEDY; 1/2/4/8 GPU + CPU ref",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "i32 height-maps / f64 candidate scores / f32 masks",
+            "data": "synthetic",
+            "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "container": cs,
+                       "reward_type": reward, "packing_strategy": strategy,
+                       "pass": "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
+                       "launch": "hipGraph replay" if use_graph else "eager"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(args.config + ":" + dom),
+                         "alg_bytes_per_env_step": mask_b if dom == "mask_step" else env_b,
+                         "units_per_launch": B, "avg_launch_us": kt[dom]["avg_us"],
+                         "event_pair_overhead_us": empty_us},
+            "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg)
+        if args.sweep:
+            for b in (8192, 32768, 131072, 524288, 2097152):
+                try:
+                    h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev)
+                    d2, _ = time_passes(h2, 10, 3, use_graph, 1)
+                    k2, _ = kernel_event_times(h2, 3)
+                    print("sweep B=%d: %.3e env-steps/s; env_step %.1f us (%.0f GB/s alg), mask_step %.1f us (%.0f GB/s alg)" % (
+                        b, b * n * 10 / d2, k2["env_step"]["avg_us"], env_b * b / k2["env_step"]["avg_us"] / 1e3,
+                        k2["mask_step"]["avg_us"], mask_b * b / k2["mask_step"]["avg_us"] / 1e3), file=sys.stderr)
+                    del h2
+                except Exception as ex:  # out of memory at the top end is fine
+                    print("sweep B=%d failed: %s" % (b, ex), file=sys.stderr)
+                    break
+        print(json.dumps(out))
+    tdist.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,187 @@
+/*
+ * tapenv.h -- C ABI of libtapenv.so: the MI355X (gfx950) batched Transport-and-Pack environment.
+ *
+ * This is the drop-in boundary for the reference's (Juzhan/TAP-Net) packing hot path.  The
+ * reference has no FFI -- its seams are plain Python callables and one class -- so every entry
+ * point below names the reference symbol (file:line) it replaces; INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Plain C: pointers and sizes only, no torch / HIP types.  `stream` is a hipStream_t passed
+ *     as void* (NULL = the null stream).  Every call is asynchronous on `stream` unless it says
+ *     "synchronous".
+ *   - All data pointers are DEVICE pointers; the caller owns every buffer (e.g. torch tensors).
+ *     The library allocates nothing per call and keeps no reference to caller memory.
+ *   - Return value: TAP_OK (0) or a negative TAP_E_* code; tap_last_error(ctx) gives a message.
+ *   - A tap_ctx is bound to one device and is not thread-safe; distinct contexts are independent.
+ *   - There is no CPU fallback: without a HIP device tap_ctx_create fails with TAP_E_NODEVICE.
+ *
+ * Per-env state is an opaque device blob of tap_env_state_bytes(desc) bytes holding only the
+ * height-map, four counters, an error word and the placement history (layout: DESIGN.md).
+ */
+#ifndef TAPENV_H
+#define TAPENV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TAP_ABI_VERSION 1
+
+typedef struct tap_ctx tap_ctx;
+
+enum {
+    TAP_OK = 0,
+    TAP_E_INVALID = -1,     /* bad argument */
+    TAP_E_UNSUPPORTED = -2, /* valid in the reference, not implemented here (e.g. > 64 cells) */
+    TAP_E_HIP = -3,         /* HIP runtime error */
+    TAP_E_OVERFLOW = -4,    /* a placement reached above H (reference: IndexError tools.py:2109 /
+                               silent clipping tools.py:2169) */
+    TAP_E_NODEVICE = -5,    /* no usable HIP device */
+    TAP_E_STEPS = -6        /* add_new_block called more than blocks_num times (tools.py:3677) */
+};
+
+/* packing strategy, tools.py:3617-3620 / 3679-3690 */
+enum { TAP_LB_GREEDY = 0, TAP_MACS = 1 /* 'MACS' and 'MUL' */ };
+
+/* flag word: the string tests the reference performs on reward_type */
+enum {
+    TAP_F_HARD = 1 << 0,     /* reward_type.endswith('hard')  tools.py:2113 */
+    TAP_F_USE_P = 1 << 1,    /* 'P' in reward_type             tools.py:2135 */
+    TAP_F_USE_S = 1 << 2,    /* 'S' in reward_type             tools.py:2138 */
+    TAP_F_MCS_ZERO = 1 << 3, /* reward_type.startswith('mcs')  tools.py:2709 */
+    TAP_F_MCS_TIE = 1 << 4   /* 'mcs' in reward_type           tools.py:2718 */
+};
+
+/* Container.calc_ratio formula, tools.py:3907-3966 */
+enum {
+    TAP_R_C = 0, TAP_R_CxS, TAP_R_CP, TAP_R_CPxS, TAP_R_CPS, TAP_R_2CPS, TAP_R_CxPxS,
+    TAP_R_CP_HALF /* 'C+P-lb-soft' -> (C+P)/2, every other mode divides by 3 */
+};
+
+/* heightmap_type, tools.py:3716-3744 */
+enum { TAP_FEAT_FULL = 0, TAP_FEAT_ZERO = 1, TAP_FEAT_DIFF = 2 };
+
+/* element type of the `blocks` argument */
+enum { TAP_DT_F32 = 0, TAP_DT_I32 = 1 };
+
+typedef struct tap_env_desc {
+    int32_t B;          /* number of containers stepped in lock-step */
+    int32_t D;          /* 2 | 3 */
+    int32_t W, L, H;    /* container_size; L = 1 when D == 2 */
+    int32_t n_max;      /* blocks_num */
+    int32_t strategy;   /* TAP_LB_GREEDY | TAP_MACS */
+    int32_t flags;      /* TAP_F_* */
+    int32_t ratio_mode; /* TAP_R_* */
+    int32_t feature;    /* TAP_FEAT_* */
+} tap_env_desc;
+
+/* ---- library / context ---------------------------------------------------------------- */
+
+int tap_abi_version(void);
+const char *tap_status_string(int status);
+/* synchronous.  device = HIP ordinal. */
+int tap_ctx_create(int device, tap_ctx **out);
+void tap_ctx_destroy(tap_ctx *ctx);
+const char *tap_last_error(const tap_ctx *ctx);
+
+/* ---- tools.Container, batched --------------------------------------------------------- */
+
+/* Fill `d` from the arguments of tools.Container.__init__ (tools.py:3611-3661), performing its
+ * string tests once on the host: container_size = D ints, reward_type e.g. "C+P+S-lb-soft",
+ * heightmap_type "full"|"zero"|"diff", packing_strategy "LB_GREEDY"|"MACS"|"MUL" (the reward
+ * string overrides it exactly as tools.py:3617-3620 does).  Host only, no device work. */
+int tap_env_desc_init(tap_env_desc *d, int B, int D, const int32_t *container_size, int blocks_num,
+                      const char *reward_type, const char *heightmap_type,
+                      const char *packing_strategy);
+
+/* bytes of device memory the caller must provide for the state blob (256-byte aligned) */
+size_t tap_env_state_bytes(const tap_env_desc *d);
+/* floats per env returned by step/feature: W*L (full/zero), W-1 (2D diff), 2*W*L (3D diff) */
+int tap_env_feature_len(const tap_env_desc *d);
+
+/* tools.Container.__init__ state / clear_container (tools.py:3629-3655, 3858-3885) */
+int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream);
+
+/* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy
+ * 2027-2351, is_stable_2d 839-868, is_stable 710-765; model.py:451-465 is the loop it replaces).
+ *   blocks      (B, D) TAP_DT_F32 | TAP_DT_I32, one block per env; f32 is truncated like
+ *               block.astype(int) (tools.py:3689)
+ *   active      (B,) uint8 or NULL: envs with 0 are not stepped and only report their feature
+ *               (the 'mul' input types' idle container, model.py:419-427)
+ *   feature_out (B, feature_len) f32 or NULL: what add_new_block returns, already in the layout
+ *               model.py:456-465 builds ((B,W-1,1) / (B,2,W,L) for 'diff') */
+int tap_env_step(tap_ctx *ctx, const tap_env_desc *d, void *state, const void *blocks,
+                 int blocks_dtype, const uint8_t *active, float *feature_out, void *stream);
+
+/* Same, with the gather of model.py:404-412 fused in: block[k] = static_[b, 1+k, ptr[b]].
+ * static_ (B, static_rows, nR) f32, ptr (B,) int64. */
+int tap_env_step_gather(tap_ctx *ctx, const tap_env_desc *d, void *state, const float *static_,
+                        int static_rows, int nR, const int64_t *ptr, const uint8_t *active,
+                        float *feature_out, void *stream);
+
+/* tools.Container.get_heightmap (tools.py:3824-3856): the feature of the current state */
+int tap_env_feature(tap_ctx *ctx, const tap_env_desc *d, const void *state, float *feature_out,
+                    void *stream);
+
+/* tools.Container.calc_ratio / calc_CPS (tools.py:3887-3966; model.py:499-510 stores it as fp32).
+ * ratio_out (B,) f32, ratio64_out (B,) f64, cps_out (B,3) f64 -- each nullable. */
+int tap_env_ratio(tap_ctx *ctx, const tap_env_desc *d, const void *state, float *ratio_out,
+                  double *ratio64_out, double *cps_out, void *stream);
+
+/* Container attributes in the reference's layouts (all nullable):
+ * heightmap (B, W*L) i32; positions (B, n_max, D) i32; stable (B, n_max) u8;
+ * counters (B, 4) i32 = valid_size, empty_size, sum(stable), current_blocks_num. */
+int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32_t *heightmap_out,
+                   int32_t *positions_out, uint8_t *stable_out, int32_t *counters_out,
+                   void *stream);
+
+/* Synchronous.  Returns TAP_OK, or TAP_E_OVERFLOW / TAP_E_STEPS if any env has raised its sticky
+ * error word; *n_bad_out (host, nullable) = number of such envs. */
+int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32_t *n_bad_out,
+                  void *stream);
+
+/* pack.reward (pack.py:378-473) == tools.calc_positions_lb_greedy (tools.py:2393-2449) per env:
+ * the whole episode in one launch.  static_ (B, static_rows, nR) f32, tour (B, n) int64,
+ * reward_out (B,) f32 = -(C+P+S) un-normalised; positions_out (B, n, D) i32 and stable_out
+ * (B, n) u8 nullable.  d->B is ignored (B given here); no state blob is needed. */
+int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const float *static_,
+                       int static_rows, int nR, const int64_t *tour, float *reward_out,
+                       int32_t *positions_out, uint8_t *stable_out, void *stream);
+
+/* ---- precedence tensors (pack.py:276-376, model.py:297-307) --------------------------- */
+/* dynamic is (B, rows, nR) f32 with rows = 3n ('bot', 'mul') or n ('simple', 'rot'); nR = n*R.
+ * colsum is a (B, 3, nR) f32 shadow of the three per-section column sums of a dynamic tensor
+ * (move / small / large, pack.py:324-326); sections beyond `rows` sum to 0. */
+
+/* colsum_out = column sums of dynamic */
+int tap_dyn_colsum(tap_ctx *ctx, int B, int n, int nR, int rows, const float *dynamic,
+                   float *colsum_out, void *stream);
+
+/* pack.update_dynamic (pack.py:333-376): dyn_out = dyn_in with rows real + n*i (i < update_rows)
+ * zeroed, real = (long)static_[b, 0, ptr[b]].  Out of place.  If colsum_in/out are given the
+ * shadow is updated incrementally (no reduction). */
+int tap_update_dynamic(tap_ctx *ctx, int B, int n, int nR, int rows, int update_rows,
+                       const float *dyn_in, const float *static_, int static_rows,
+                       const int64_t *ptr, float *dyn_out, const float *colsum_in,
+                       float *colsum_out, void *stream);
+
+/* pack.update_mask (pack.py:276-331) from the column sums of the (already updated) dynamic.
+ * ptr == NULL gives the initial mask of model.py:297-307 (mask_in may then be NULL = ones).
+ * current_out = new_mask.float(), mask_out = chosen_mask. */
+int tap_update_mask(tap_ctx *ctx, int B, int n, int R, const float *mask_in, const float *colsum,
+                    const int64_t *ptr, float *current_out, float *mask_out, void *stream);
+
+/* update_dynamic + update_mask in one launch (what model.py:376-386 does per step). */
+int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
+                  const float *dyn_in, const float *static_, int static_rows, const int64_t *ptr,
+                  const float *mask_in, const float *colsum_in, float *dyn_out, float *colsum_out,
+                  float *current_out, float *mask_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAPENV_H */

@@ -1,0 +1,521 @@
+// env.hip -- tools.Container for B containers in lock-step: context, descriptor, reset, step,
+// feature, ratio, export, check, and the whole-episode reward kernel.  gfx950 only.
+#include "tap_common.h"
+#include "tap_place.h"
+
+// =============================================================================================
+// context / descriptor (host)
+// =============================================================================================
+
+extern "C" int tap_abi_version(void) { return TAP_ABI_VERSION; }
+
+extern "C" const char *tap_status_string(int s)
+{
+    switch (s) {
+    case TAP_OK: return "ok";
+    case TAP_E_INVALID: return "invalid argument";
+    case TAP_E_UNSUPPORTED: return "unsupported configuration";
+    case TAP_E_HIP: return "HIP runtime error";
+    case TAP_E_OVERFLOW: return "placement above container height";
+    case TAP_E_NODEVICE: return "no HIP device";
+    case TAP_E_STEPS: return "more add_new_block calls than blocks_num";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int tap_ctx_create(int device, tap_ctx **out)
+{
+    if (!out) return TAP_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return TAP_E_NODEVICE;
+    if (device < 0 || device >= n) return TAP_E_INVALID;
+    tap_ctx *c = new tap_ctx();
+    c->device = device;
+    c->err[0] = 0;
+    *out = c;
+    return TAP_OK;
+}
+
+extern "C" void tap_ctx_destroy(tap_ctx *ctx) { delete ctx; }
+
+extern "C" const char *tap_last_error(const tap_ctx *ctx) { return ctx ? ctx->err : ""; }
+
+static bool str_ends(const char *s, const char *suf)
+{
+    size_t a = strlen(s), b = strlen(suf);
+    return a >= b && strcmp(s + a - b, suf) == 0;
+}
+
+extern "C" int tap_env_desc_init(tap_env_desc *d, int B, int D, const int32_t *cs, int blocks_num,
+                                 const char *reward, const char *hm_type, const char *strategy)
+{
+    if (!d || !cs || !reward || !hm_type || !strategy) return TAP_E_INVALID;
+    if (D != 2 && D != 3) return TAP_E_INVALID;
+    memset(d, 0, sizeof(*d));
+    d->B = B; d->D = D;
+    d->W = cs[0]; d->L = D == 3 ? cs[1] : 1; d->H = cs[D - 1];
+    d->n_max = blocks_num;
+    // tools.py:3617-3620: the reward string overrides the strategy
+    const char *st = strategy;
+    if (!strcmp(reward, "C+P+S-mul-soft") || !strcmp(reward, "C+P+S-mul-hard")) st = "MUL";
+    else if (!strcmp(reward, "C+P+S-mcs-soft") || !strcmp(reward, "C+P+S-mcs-hard")) st = "MACS";
+    if (!strcmp(st, "MACS") || !strcmp(st, "MUL")) d->strategy = TAP_MACS;
+    else if (!strcmp(st, "LB_GREEDY")) d->strategy = TAP_LB_GREEDY;
+    else return TAP_E_UNSUPPORTED; // 'LB' (legacy) and the pack-net back-ends are out of scope
+    if (str_ends(reward, "hard")) d->flags |= TAP_F_HARD;          // tools.py:2113
+    if (strchr(reward, 'P')) d->flags |= TAP_F_USE_P;              // tools.py:2135
+    if (strchr(reward, 'S')) d->flags |= TAP_F_USE_S;              // tools.py:2138
+    if (!strncmp(reward, "mcs", 3)) d->flags |= TAP_F_MCS_ZERO;    // tools.py:2709
+    if (strstr(reward, "mcs")) d->flags |= TAP_F_MCS_TIE;          // tools.py:2718
+    // tools.py:3919-3964
+    struct { const char *name; int mode; } table[] = {
+        {"comp", TAP_R_C}, {"soft", TAP_R_CxS}, {"hard", TAP_R_CxS}, {"pyrm", TAP_R_CP},
+        {"pyrm-soft", TAP_R_CPxS}, {"pyrm-hard", TAP_R_CPxS}, {"mcs-soft", TAP_R_CPxS},
+        {"mcs-hard", TAP_R_CPxS}, {"pyrm-soft-sum", TAP_R_CPS}, {"pyrm-soft-SUM", TAP_R_2CPS},
+        {"pyrm-hard-sum", TAP_R_CPS}, {"pyrm-hard-SUM", TAP_R_2CPS}, {"CPS", TAP_R_CxPxS},
+        {"C+P-lb-soft", TAP_R_CP_HALF}};
+    d->ratio_mode = TAP_R_CPS;
+    for (auto &t : table) if (!strcmp(reward, t.name)) d->ratio_mode = t.mode;
+    if (!strcmp(hm_type, "full")) d->feature = TAP_FEAT_FULL;
+    else if (!strcmp(hm_type, "zero")) d->feature = TAP_FEAT_ZERO;
+    else if (!strcmp(hm_type, "diff")) d->feature = TAP_FEAT_DIFF;
+    else return TAP_E_INVALID;
+    return TAP_OK;
+}
+
+int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
+{
+    if (!d) return tap_fail(ctx, TAP_E_INVALID, "null descriptor");
+    if ((d->D != 2 && d->D != 3) || d->B < 0 || d->W < 1 || d->L < 1 || d->H < 1 || d->n_max < 1 ||
+        (d->D == 2 && d->L != 1))
+        return tap_fail(ctx, TAP_E_INVALID, "bad descriptor B=%d D=%d W=%d L=%d H=%d n=%d", d->B,
+                        d->D, d->W, d->L, d->H, d->n_max);
+    if (tap_group_size(d) == 0)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 64 lanes per container", d->W * d->L);
+    if (d->D == 3 && (d->W > 8 || d->L > 8))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "3D footprints wider than 8 are not supported");
+    if (d->H > 4000 || d->n_max > 4096)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "H or blocks_num too large for the 32-bit sort key");
+    if (d->strategy != TAP_LB_GREEDY && d->strategy != TAP_MACS)
+        return tap_fail(ctx, TAP_E_INVALID, "bad strategy %d", d->strategy);
+    if (d->strategy == TAP_MACS && d->D != 2)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS/MUL is implemented for 2D only");
+    return TAP_OK;
+}
+
+extern "C" size_t tap_env_state_bytes(const tap_env_desc *d)
+{
+    if (!d || d->B < 0 || d->W < 1 || d->L < 1 || d->n_max < 1) return 0;
+    return tap_env_layout(d, nullptr, nullptr);
+}
+
+extern "C" int tap_env_feature_len(const tap_env_desc *d)
+{
+    if (!d) return 0;
+    if (d->feature == TAP_FEAT_DIFF) return d->D == 2 ? d->W - 1 : 2 * d->W * d->L;
+    return d->W * d->L;
+}
+
+extern "C" int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
+    TAP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, tap_env_layout(d, nullptr, nullptr), (hipStream_t)stream));
+    return TAP_OK;
+}
+
+// =============================================================================================
+// device: feature writer (tools.py:3716-3744), shared by step and get_heightmap
+// =============================================================================================
+
+// s = group's LDS slice with the CURRENT height-map (barrier'd); writes this lane's share
+template <int D, int G>
+__device__ __forceinline__ void tap_write_feature(int feature, int W, int L, const int *s, int cell,
+                                                  int hm, float *out /* env's row */)
+{
+    const int cells = W * L;
+    const bool incell = cell < cells;
+    if (feature == TAP_FEAT_DIFF) {
+        if (D == 2) {
+            if (cell < W - 1) out[cell] = (float)(s[cell + 1] - hm);               // :3739-3743
+        } else if (incell) {
+            const int x = cell / L, y = cell - x * L;
+            out[cell] = (float)(x > 0 ? hm - s[cell - L] : 0);                      // :3723-3725
+            out[cells + cell] = (float)(y > 0 ? hm - s[cell - 1] : 0);              // :3728-3730
+        }
+    } else if (feature == TAP_FEAT_ZERO) {
+        const int mn = group_min<G>(incell ? hm : INT_MAX);                         // :3719
+        if (incell) out[cell] = (float)(hm - mn);
+    } else if (incell) {
+        out[cell] = (float)hm;                                                      // :3717
+    }
+}
+
+// =============================================================================================
+// K1/K2: one lock-step placement for B containers
+// =============================================================================================
+
+template <int D, int G>
+__global__ void __launch_bounds__(TAP_BLOCK) k_env_step(StepArgs a)
+{
+    __shared__ int s_old[TAP_BLOCK];
+    __shared__ int s_new[TAP_BLOCK];
+    const int tid = threadIdx.x, grp = tid / G, cell = tid % G;
+    const int env = blockIdx.x * (TAP_BLOCK / G) + grp;
+    const int B = a.d.B, W = a.d.W, L = a.d.L, cells = W * L;
+    const bool ev = env < B, incell = cell < cells;
+    const int gl0 = (tid & 63) - cell; // first lane of this group inside the wave
+
+    int hm = (ev && incell) ? a.v.hm[(size_t)env * cells + cell] : 0;
+    const int cv = (ev && cell < 4) ? a.v.cnt[(size_t)env * 4 + cell] : 0;
+    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
+
+    int dims[3] = {1, 1, 1};
+    bool act = ev;
+    if (ev) {
+        if (a.static_) { // gather of model.py:404-412
+            const long p = (long)a.ptr[env];
+            for (int k = 0; k < D; ++k)
+                dims[k] = (int)a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
+        } else if (a.blocks_dtype == TAP_DT_F32) {
+            for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)a.blocks)[(size_t)env * D + k];
+        } else {
+            for (int k = 0; k < D; ++k) dims[k] = ((const int32_t *)a.blocks)[(size_t)env * D + k];
+        }
+        if (a.active) act = a.active[env] != 0;
+    }
+    const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
+
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }       // tools.py:3677 IndexError
+    if (act && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
+
+    s_old[tid] = hm;
+    __syncthreads();
+    const PlaceCfg cfg = {W, L, a.d.H, a.d.flags};
+    const int step = cnt.count;
+    const Placement pl = tap_place<D, G>(cfg, s_old + grp * G, cell, hm, cnt, err, bx, by, bz, do_step);
+    err = group_or<G>(err);
+
+    s_new[tid] = hm;
+    __syncthreads();
+    if (ev) {
+        if (incell) a.v.hm[(size_t)env * cells + cell] = hm;
+        if (a.feature_out)
+            tap_write_feature<D, G>(a.d.feature, W, L, s_new + grp * G, cell, hm,
+                                    a.feature_out + (size_t)env * a.flen);
+        if (cell == 0) {
+            if (do_step) {
+                reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+                int32_t *pp = a.v.pos + (size_t)step * D * B + env;
+                pp[0] = pl.x;
+                if (D == 3) { pp[B] = pl.y; pp[2 * (size_t)B] = pl.z; } else pp[B] = pl.z;
+                a.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
+            }
+            if (err) a.v.err[env] |= err;
+        }
+    } else if (a.d.feature == TAP_FEAT_ZERO) {
+        (void)group_min<G>(INT_MAX); // keep the cross-lane op convergent for tail groups
+    }
+}
+
+template <int D, int G> static int launch_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
+{
+    const int epb = TAP_BLOCK / G;
+    const int grid = (a.d.B + epb - 1) / epb;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL((k_env_step<D, G>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    TAP_LAUNCH_CHECK(ctx, "k_env_step");
+    return TAP_OK;
+}
+
+#define TAP_DISPATCH_DG(fn, d, ...)                                                          \
+    do {                                                                                     \
+        const int G_ = tap_group_size(d);                                                    \
+        if ((d)->D == 2) {                                                                   \
+            if (G_ == 8) return fn<2, 8>(__VA_ARGS__);                                       \
+            if (G_ == 16) return fn<2, 16>(__VA_ARGS__);                                     \
+            if (G_ == 32) return fn<2, 32>(__VA_ARGS__);                                     \
+            return fn<2, 64>(__VA_ARGS__);                                                   \
+        } else {                                                                             \
+            if (G_ == 8) return fn<3, 8>(__VA_ARGS__);                                       \
+            if (G_ == 16) return fn<3, 16>(__VA_ARGS__);                                     \
+            if (G_ == 32) return fn<3, 32>(__VA_ARGS__);                                     \
+            return fn<3, 64>(__VA_ARGS__);                                                   \
+        }                                                                                    \
+    } while (0)
+
+int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st); // macs.hip
+
+static int step_common(tap_ctx *ctx, const tap_env_desc *d, void *state, StepArgs &a, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
+    a.d = *d;
+    tap_env_layout(d, state, &a.v);
+    a.flen = tap_env_feature_len(d);
+    if (d->strategy == TAP_MACS) return tap_macs2d_step(ctx, a, (hipStream_t)stream);
+    TAP_DISPATCH_DG(launch_step, d, ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int tap_env_step(tap_ctx *ctx, const tap_env_desc *d, void *state, const void *blocks,
+                            int blocks_dtype, const uint8_t *active, float *feature_out,
+                            void *stream)
+{
+    if (!blocks) return tap_fail(ctx, TAP_E_INVALID, "null blocks");
+    if (blocks_dtype != TAP_DT_F32 && blocks_dtype != TAP_DT_I32)
+        return tap_fail(ctx, TAP_E_INVALID, "bad blocks_dtype %d", blocks_dtype);
+    StepArgs a = {};
+    a.blocks = blocks; a.blocks_dtype = blocks_dtype; a.active = active; a.feature_out = feature_out;
+    return step_common(ctx, d, state, a, stream);
+}
+
+extern "C" int tap_env_step_gather(tap_ctx *ctx, const tap_env_desc *d, void *state,
+                                   const float *static_, int static_rows, int nR,
+                                   const int64_t *ptr, const uint8_t *active, float *feature_out,
+                                   void *stream)
+{
+    if (!static_ || !ptr || !d || static_rows < 1 + d->D || nR < 1)
+        return tap_fail(ctx, TAP_E_INVALID, "bad gather arguments");
+    StepArgs a = {};
+    a.static_ = static_; a.static_rows = static_rows; a.nR = nR; a.ptr = ptr;
+    a.active = active; a.feature_out = feature_out;
+    return step_common(ctx, d, state, a, stream);
+}
+
+// =============================================================================================
+// get_heightmap / calc_ratio / attribute export / error check
+// =============================================================================================
+
+template <int D, int G>
+__global__ void __launch_bounds__(TAP_BLOCK) k_env_feature(tap_env_desc d, EnvView v, float *out, int flen)
+{
+    __shared__ int s[TAP_BLOCK];
+    const int tid = threadIdx.x, grp = tid / G, cell = tid % G;
+    const int env = blockIdx.x * (TAP_BLOCK / G) + grp;
+    const int cells = d.W * d.L;
+    const bool ev = env < d.B;
+    const int hm = (ev && cell < cells) ? v.hm[(size_t)env * cells + cell] : 0;
+    s[tid] = hm;
+    __syncthreads();
+    // out-of-range groups run the writer on a dummy row so cross-lane ops stay convergent
+    float dummy;
+    (void)dummy;
+    if (ev) tap_write_feature<D, G>(d.feature, d.W, d.L, s + grp * G, cell, hm, out + (size_t)env * flen);
+    else if (d.feature == TAP_FEAT_ZERO) (void)group_min<G>(INT_MAX);
+}
+
+template <int D, int G>
+static int launch_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, hipStream_t st)
+{
+    const int epb = TAP_BLOCK / G, grid = (d->B + epb - 1) / epb;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL((k_env_feature<D, G>), dim3(grid), dim3(TAP_BLOCK), 0, st, *d, v, out,
+                       tap_env_feature_len(d));
+    TAP_LAUNCH_CHECK(ctx, "k_env_feature");
+    return TAP_OK;
+}
+
+extern "C" int tap_env_feature(tap_ctx *ctx, const tap_env_desc *d, const void *state,
+                               float *feature_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state || !feature_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    EnvView v;
+    tap_env_layout(d, const_cast<void *>(state), &v);
+    TAP_DISPATCH_DG(launch_feature, d, ctx, d, v, feature_out, (hipStream_t)stream);
+}
+
+// tools.py:3887-3966, one thread per env
+__global__ void __launch_bounds__(TAP_BLOCK) k_env_ratio(tap_env_desc d, EnvView v, float *r32,
+                                                         double *r64, double *cps)
+{
+    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    if (env >= d.B) return;
+    const int cells = d.W * d.L;
+    const int4 c = reinterpret_cast<const int4 *>(v.cnt)[env];
+    double C = 0.0, P = 0.0, S = 0.0;
+    if (c.w != 0) {                                               // :3888-3889
+        int height = 0;
+        for (int i = 0; i < cells; ++i) height = max(height, v.hm[(size_t)env * cells + i]);
+        const long long box = (long long)d.W * d.L * height;      // :3893-3896
+        C = (double)c.x / (double)box;                            // :3902
+        P = (double)c.x / (double)(c.y + c.x);                    // :3903
+        S = (double)c.z / (double)c.w;                            // :3904
+    }
+    double r;
+    switch (d.ratio_mode) {                                       // :3919-3964
+    case TAP_R_C: r = C / 3; break;
+    case TAP_R_CxS: r = (C * S) / 3; break;
+    case TAP_R_CP: r = (C + P) / 3; break;
+    case TAP_R_CPxS: r = ((C + P) * S) / 3; break;
+    case TAP_R_2CPS: r = ((2 * C + P) + S) / 3; break;
+    case TAP_R_CxPxS: r = ((C * P) * S) / 3; break;
+    case TAP_R_CP_HALF: r = (C + P) / 2; break;
+    default: r = ((C + P) + S) / 3; break;
+    }
+    if (r32) r32[env] = (float)r;                                 // model.py:499,510 fp32 store
+    if (r64) r64[env] = r;
+    if (cps) { cps[(size_t)env * 3] = C; cps[(size_t)env * 3 + 1] = P; cps[(size_t)env * 3 + 2] = S; }
+}
+
+extern "C" int tap_env_ratio(tap_ctx *ctx, const tap_env_desc *d, const void *state,
+                             float *ratio_out, double *ratio64_out, double *cps_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
+    EnvView v;
+    tap_env_layout(d, const_cast<void *>(state), &v);
+    const int grid = (d->B + TAP_BLOCK - 1) / TAP_BLOCK;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL(k_env_ratio, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, *d, v,
+                       ratio_out, ratio64_out, cps_out);
+    TAP_LAUNCH_CHECK(ctx, "k_env_ratio");
+    return TAP_OK;
+}
+
+__global__ void __launch_bounds__(TAP_BLOCK) k_env_export(tap_env_desc d, EnvView v, int32_t *hm,
+                                                          int32_t *pos, uint8_t *st, int32_t *cnt)
+{
+    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    if (env >= d.B) return;
+    const int cells = d.W * d.L, D = d.D, n = d.n_max;
+    const size_t B = (size_t)d.B;
+    if (hm) for (int i = 0; i < cells; ++i) hm[(size_t)env * cells + i] = v.hm[(size_t)env * cells + i];
+    if (pos) for (int t = 0; t < n * D; ++t) pos[(size_t)env * n * D + t] = v.pos[(size_t)t * B + env];
+    if (st) for (int t = 0; t < n; ++t) st[(size_t)env * n + t] = v.stable[(size_t)t * B + env];
+    if (cnt) for (int k = 0; k < 4; ++k) cnt[(size_t)env * 4 + k] = v.cnt[(size_t)env * 4 + k];
+}
+
+extern "C" int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *state,
+                              int32_t *heightmap_out, int32_t *positions_out, uint8_t *stable_out,
+                              int32_t *counters_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
+    EnvView v;
+    tap_env_layout(d, const_cast<void *>(state), &v);
+    const int grid = (d->B + TAP_BLOCK - 1) / TAP_BLOCK;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL(k_env_export, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, *d, v,
+                       heightmap_out, positions_out, stable_out, counters_out);
+    TAP_LAUNCH_CHECK(ctx, "k_env_export");
+    return TAP_OK;
+}
+
+extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *state,
+                             int32_t *n_bad_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
+    EnvView v;
+    tap_env_layout(d, const_cast<void *>(state), &v);
+    int32_t *host = new int32_t[d->B > 0 ? d->B : 1];
+    hipError_t e = hipMemcpyAsync(host, v.err, (size_t)d->B * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) {
+        delete[] host;
+        return tap_fail(ctx, TAP_E_HIP, "error-word readback failed: %s", hipGetErrorString(e));
+    }
+    int bad = 0, bits = 0;
+    for (int i = 0; i < d->B; ++i) if (host[i]) { ++bad; bits |= host[i]; }
+    delete[] host;
+    if (n_bad_out) *n_bad_out = bad;
+    if (bits & 1) return tap_fail(ctx, TAP_E_OVERFLOW, "%d container(s) exceeded height H=%d", bad, d->H);
+    if (bits & 2) return tap_fail(ctx, TAP_E_STEPS, "%d container(s) stepped more than blocks_num=%d times", bad, d->n_max);
+    if (bits & 4) return tap_fail(ctx, TAP_E_INVALID, "%d container(s) were given a block side < 1", bad);
+    return TAP_OK;
+}
+
+// =============================================================================================
+// K6: whole episode per env in one launch -- pack.reward / tools.calc_positions_lb_greedy
+// =============================================================================================
+
+struct EpisodeArgs {
+    tap_env_desc d;
+    int B, n;
+    const float *static_;
+    int static_rows, nR;
+    const int64_t *tour;
+    float *reward_out;
+    int32_t *pos_out;
+    uint8_t *stable_out;
+};
+
+template <int D, int G>
+__global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
+{
+    __shared__ int s[TAP_BLOCK];
+    const int tid = threadIdx.x, grp = tid / G, cell = tid % G;
+    const int env = blockIdx.x * (TAP_BLOCK / G) + grp;
+    const int W = a.d.W, L = a.d.L, n = a.n;
+    const bool ev = env < a.B, incell = cell < W * L;
+    const PlaceCfg cfg = {W, L, a.d.H, a.d.flags};
+    int hm = 0, err = 0;
+    Counters cnt = {0, 0, 0, 0};
+    for (int t = 0; t < n; ++t) {
+        int dims[3] = {1, 1, 1};
+        if (ev) { // pack.py:441-444 gather by tour, :454-455 rows 1..D, tools.py:2415 astype('int')
+            const long p = (long)a.tour[(size_t)env * n + t];
+            for (int k = 0; k < D; ++k)
+                dims[k] = (int)a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
+        }
+        const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
+        const bool ok = ev && bx >= 1 && by >= 1 && bz >= 1;
+        s[tid] = hm;
+        __syncthreads();
+        const Placement pl = tap_place<D, G>(cfg, s + grp * G, cell, hm, cnt, err, bx, by, bz, ok);
+        __syncthreads();
+        if (ev && cell == 0) {
+            if (a.pos_out) {
+                int32_t *pp = a.pos_out + ((size_t)env * n + t) * D;
+                pp[0] = pl.x;
+                if (D == 3) { pp[1] = pl.y; pp[2] = pl.z; } else pp[1] = pl.z;
+            }
+            if (a.stable_out) a.stable_out[(size_t)env * n + t] = (uint8_t)pl.stab;
+        }
+    }
+    const int gmax = group_max<G>(incell ? hm : 0);
+    err = group_or<G>(err);
+    if (ev && cell == 0) {
+        // tools.py:2434-2445: un-normalised C + P + S, S over blocks_num; pack.py:471-473 fp32, negated
+        const long long box = (long long)gmax * W * L;
+        const double C = (double)cnt.valid / (double)box;
+        const double P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
+        const double S = (double)cnt.nstable / (double)n;
+        // the reference raises on a height overflow; here the reward becomes NaN
+        a.reward_out[env] = err ? __int_as_float(0x7fc00000) : -(float)((C + P) + S);
+    }
+}
+
+template <int D, int G> static int launch_episode(tap_ctx *ctx, const EpisodeArgs &a, hipStream_t st)
+{
+    const int epb = TAP_BLOCK / G, grid = (a.B + epb - 1) / epb;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL((k_episode<D, G>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    TAP_LAUNCH_CHECK(ctx, "k_episode");
+    return TAP_OK;
+}
+
+extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, int n,
+                                  const float *static_, int static_rows, int nR,
+                                  const int64_t *tour, float *reward_out, int32_t *positions_out,
+                                  uint8_t *stable_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (d->strategy != TAP_LB_GREEDY)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
+    if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
+        return tap_fail(ctx, TAP_E_INVALID, "bad episode arguments");
+    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, reward_out, positions_out, stable_out};
+    TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
+}

@@ -1,0 +1,199 @@
+// masks.hip -- the precedence tensors: pack.update_dynamic (pack.py:333-376), pack.update_mask
+// (pack.py:276-331) and the initial mask (model.py:297-307).  gfx950 only.
+//
+// `dynamic` is (B, rows, nR) fp32.  One wavefront owns one env's (rows x nR) slab and streams it
+// with 16-byte loads/stores (1 KiB per wave instruction, fully coalesced): the step is an
+// out-of-place copy with three rows zeroed, so it is HBM-bound (2 * rows*nR*4 bytes per env).
+// The three per-section column sums update_mask needs are kept in a (B, 3, nR) shadow that is
+// updated incrementally (sum_new = sum_old - zeroed row), so the slab is never reduced again
+// after tap_dyn_colsum built the shadow once.
+#include "tap_common.h"
+
+constexpr int WAVE = 64;
+constexpr int ENVS_PER_BLOCK = TAP_BLOCK / WAVE;
+
+// ---- full reduction: colsum[b, s, j] = sum_i dynamic[b, s*n + i, j] -------------------------
+__global__ void __launch_bounds__(TAP_BLOCK) k_dyn_colsum(int B, int n, int nR, int rows,
+                                                          const float *__restrict__ dyn,
+                                                          float *__restrict__ cs)
+{
+    const int env = blockIdx.x * ENVS_PER_BLOCK + threadIdx.x / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (env >= B) return;
+    const float *slab = dyn + (size_t)env * rows * nR;
+    for (int j = lane; j < nR; j += WAVE) {
+        for (int s = 0; s < 3; ++s) {
+            float acc = 0.f;
+            for (int i = s * n; i < (s + 1) * n && i < rows; ++i) acc += slab[(size_t)i * nR + j];
+            cs[((size_t)env * 3 + s) * nR + j] = acc;
+        }
+    }
+}
+
+struct MaskArgs {
+    int B, n, R, nR, rows, update_rows, static_rows;
+    const float *dyn_in;
+    float *dyn_out;
+    const float *static_;
+    const int64_t *ptr;
+    const float *mask_in;
+    const float *cs_in;
+    float *cs_out;
+    float *cur_out;
+    float *mask_out;
+};
+
+// mask math for one column: pack.py:318-329
+__device__ __forceinline__ void mask_column(const MaskArgs &a, int env, int j, long real_m,
+                                            float move, float small, float large)
+{
+    float keep = a.mask_in ? a.mask_in[(size_t)env * a.nR + j] : 1.f;
+    if (a.ptr)
+        for (int r = 0; r < a.R; ++r)
+            if (j == real_m + (long)a.n * r) keep = 0.f;            // :320-321
+    if (a.mask_out) a.mask_out[(size_t)env * a.nR + j] = keep;    // chosen_mask
+    const float dm = small * large + move;                        // :327-328
+    if (a.cur_out) a.cur_out[(size_t)env * a.nR + j] = dm != 0.f ? 0.f : keep; // :329
+}
+
+// ---- fused step: copy-with-zeroed-rows + incremental column sums + both masks ----------------
+template <int VEC>
+__global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
+{
+    const int env = blockIdx.x * ENVS_PER_BLOCK + threadIdx.x / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (env >= a.B) return;
+    const int nR = a.nR, rows = a.rows;
+    const size_t slab = (size_t)rows * nR;
+    const long p = a.ptr ? (long)a.ptr[env] : 0;
+    // pack.py:339: block id read from row 0 of `static` as float -> long
+    const long real = (a.ptr && a.static_) ? (long)a.static_[(size_t)env * a.static_rows * nR + p] : -1;
+
+    if (a.dyn_out) {
+        // flat ranges [lo_i, hi_i) of the rows to clear (pack.py:372-374)
+        long lo[3], hi[3];
+        for (int i = 0; i < 3; ++i) {
+            const long r = real + (long)a.n * i;
+            const bool on = i < a.update_rows && real >= 0 && r < rows;
+            lo[i] = on ? r * nR : -1;
+            hi[i] = on ? (r + 1) * nR : -1;
+        }
+        const float *src = a.dyn_in + (size_t)env * slab;
+        float *dst = a.dyn_out + (size_t)env * slab;
+        if (VEC == 4) {
+            const int nchunk = (int)(slab / 4);
+            const float4 *s4 = reinterpret_cast<const float4 *>(src);
+            float4 *d4 = reinterpret_cast<float4 *>(dst);
+#pragma unroll 4
+            for (int q = lane; q < nchunk; q += WAVE) {
+                float4 v = s4[q];
+                const long f = (long)q * 4; // nR % 4 == 0: a chunk never straddles two rows
+                if ((f >= lo[0] && f < hi[0]) || (f >= lo[1] && f < hi[1]) || (f >= lo[2] && f < hi[2]))
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                d4[q] = v;
+            }
+        } else {
+            for (long f = lane; f < (long)slab; f += WAVE) {
+                float v = src[f];
+                if ((f >= lo[0] && f < hi[0]) || (f >= lo[1] && f < hi[1]) || (f >= lo[2] && f < hi[2])) v = 0.f;
+                dst[f] = v;
+            }
+        }
+    }
+
+    if (a.cs_out || a.cur_out || a.mask_out) {
+        long real_m = p;
+        while (real_m >= a.n) real_m -= a.n;                      // pack.py:314-316
+        for (int j = lane; j < nR; j += WAVE) {
+            float sum[3];
+            for (int s = 0; s < 3; ++s) {
+                float v = a.cs_in[((size_t)env * 3 + s) * nR + j];
+                const long r = real + (long)a.n * s;
+                if (a.dyn_out && s < a.update_rows && real >= 0 && r < rows)
+                    v -= a.dyn_in[(size_t)env * slab + (size_t)r * nR + j]; // the row being cleared
+                sum[s] = v;
+                if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + j] = v;
+            }
+            mask_column(a, env, j, real_m, sum[0], sum[1], sum[2]);
+        }
+    }
+}
+
+static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)
+{
+    const int grid = (a.B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    if (grid == 0) return TAP_OK;
+    const bool vec = (a.nR % 4 == 0) && a.dyn_out &&
+                     ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
+    if (vec) hipLaunchKernelGGL(k_mask_step<4>, dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL(k_mask_step<1>, dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    TAP_LAUNCH_CHECK(ctx, "k_mask_step");
+    return TAP_OK;
+}
+
+static int check_shape(tap_ctx *ctx, int B, int n, int nR, int rows)
+{
+    if (B < 0 || n < 1 || nR < 1 || rows < 1 || nR % n != 0)
+        return tap_fail(ctx, TAP_E_INVALID, "bad mask shape B=%d n=%d nR=%d rows=%d", B, n, nR, rows);
+    return TAP_OK;
+}
+
+extern "C" int tap_dyn_colsum(tap_ctx *ctx, int B, int n, int nR, int rows, const float *dynamic,
+                              float *colsum_out, void *stream)
+{
+    int rc = check_shape(ctx, B, n, nR, rows);
+    if (rc) return rc;
+    if (!dynamic || !colsum_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    const int grid = (B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL(k_dyn_colsum, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, B, n, nR,
+                       rows, dynamic, colsum_out);
+    TAP_LAUNCH_CHECK(ctx, "k_dyn_colsum");
+    return TAP_OK;
+}
+
+extern "C" int tap_update_dynamic(tap_ctx *ctx, int B, int n, int nR, int rows, int update_rows,
+                                  const float *dyn_in, const float *static_, int static_rows,
+                                  const int64_t *ptr, float *dyn_out, const float *colsum_in,
+                                  float *colsum_out, void *stream)
+{
+    int rc = check_shape(ctx, B, n, nR, rows);
+    if (rc) return rc;
+    if (!dyn_in || !static_ || !ptr || !dyn_out || static_rows < 1 || update_rows < 0 || update_rows > 3)
+        return tap_fail(ctx, TAP_E_INVALID, "bad update_dynamic arguments");
+    if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "update_dynamic is out of place (pack.py:370)");
+    if ((colsum_in == nullptr) != (colsum_out == nullptr))
+        return tap_fail(ctx, TAP_E_INVALID, "colsum_in and colsum_out go together");
+    MaskArgs a = {B, n, nR / n, nR, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                  nullptr, colsum_in, colsum_out, nullptr, nullptr};
+    return launch_mask_step(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int tap_update_mask(tap_ctx *ctx, int B, int n, int R, const float *mask_in,
+                               const float *colsum, const int64_t *ptr, float *current_out,
+                               float *mask_out, void *stream)
+{
+    if (B < 0 || n < 1 || R < 1) return tap_fail(ctx, TAP_E_INVALID, "bad mask shape");
+    if (!colsum || (!current_out && !mask_out)) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    if (ptr && !mask_in) return tap_fail(ctx, TAP_E_INVALID, "update_mask needs mask_in");
+    MaskArgs a = {B, n, R, n * R, 3 * n, 0, 0, nullptr, nullptr, nullptr, ptr, mask_in, colsum,
+                  nullptr, current_out, mask_out};
+    return launch_mask_step(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
+                             const float *dyn_in, const float *static_, int static_rows,
+                             const int64_t *ptr, const float *mask_in, const float *colsum_in,
+                             float *dyn_out, float *colsum_out, float *current_out,
+                             float *mask_out, void *stream)
+{
+    int rc = check_shape(ctx, B, n, n * R, rows);
+    if (rc) return rc;
+    if (!dyn_in || !static_ || !ptr || !mask_in || !colsum_in || !dyn_out || !colsum_out ||
+        !current_out || !mask_out || static_rows < 1 || update_rows < 0 || update_rows > 3)
+        return tap_fail(ctx, TAP_E_INVALID, "bad mask_step arguments");
+    if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "mask_step is out of place (pack.py:370)");
+    MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                  mask_in, colsum_in, colsum_out, current_out, mask_out};
+    return launch_mask_step(ctx, a, (hipStream_t)stream);
+}

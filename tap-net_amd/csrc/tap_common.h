@@ -1,0 +1,105 @@
+// tap_common.h -- host-side plumbing shared by the libtapenv translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "tapenv.h"
+
+struct tap_ctx {
+    int device;
+    char err[512];
+};
+
+inline int tap_fail(tap_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define TAP_HIP_CHECK(ctx, expr)                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return tap_fail(ctx, TAP_E_HIP, "%s failed: %s (%s:%d)", #expr,                  \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                      \
+    } while (0)
+
+#define TAP_LAUNCH_CHECK(ctx, what)                                                          \
+    do {                                                                                     \
+        hipError_t e_ = hipGetLastError();                                                   \
+        if (e_ != hipSuccess)                                                                \
+            return tap_fail(ctx, TAP_E_HIP, "launch of %s failed: %s", what,                 \
+                            hipGetErrorString(e_));                                          \
+    } while (0)
+
+constexpr int TAP_BLOCK = 256; // threads per workgroup (4 wave64)
+
+// ---- state blob layout -------------------------------------------------------------------
+// hm      int32 [B][cells]        height-map, env-major (a lane group reads one env's row)
+// cnt     int32 [B][4]            valid_size, empty_size, sum(stable), current_blocks_num
+// err     int32 [B]               sticky error bits (1 = overflow, 2 = too many steps)
+// pos     int32 [n_max*D][B]      positions, step-major so one lock-step is one coalesced row
+// stable  uint8 [n_max][B]
+// blk     int32 [n_max*D][B]      placed block sizes (MACS history only)
+struct EnvView {
+    int32_t *hm;
+    int32_t *cnt;
+    int32_t *err;
+    int32_t *pos;
+    uint8_t *stable;
+    int32_t *blk;
+};
+
+inline size_t tap_align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
+{
+    const size_t B = (size_t)d->B, cells = (size_t)d->W * d->L, nD = (size_t)d->n_max * d->D;
+    size_t off = 0;
+    char *p = static_cast<char *>(base);
+    auto take = [&](size_t bytes) { size_t o = off; off = tap_align256(off + bytes); return o; };
+    size_t o_hm = take(B * cells * 4), o_cnt = take(B * 16), o_err = take(B * 4);
+    size_t o_pos = take(nD * B * 4), o_st = take((size_t)d->n_max * B);
+    size_t o_blk = d->strategy == TAP_MACS ? take(nD * B * 4) : 0;
+    if (v) {
+        v->hm = reinterpret_cast<int32_t *>(p + o_hm);
+        v->cnt = reinterpret_cast<int32_t *>(p + o_cnt);
+        v->err = reinterpret_cast<int32_t *>(p + o_err);
+        v->pos = reinterpret_cast<int32_t *>(p + o_pos);
+        v->stable = reinterpret_cast<uint8_t *>(p + o_st);
+        v->blk = d->strategy == TAP_MACS ? reinterpret_cast<int32_t *>(p + o_blk) : nullptr;
+    }
+    return off;
+}
+
+// arguments of one lock-step placement launch (env.hip, macs.hip)
+struct StepArgs {
+    tap_env_desc d;
+    EnvView v;
+    const void *blocks;   // (B, D) f32 | i32, or null when gathering
+    int blocks_dtype;
+    const float *static_; // gather source (B, static_rows, nR)
+    int static_rows, nR;
+    const int64_t *ptr;
+    const uint8_t *active;
+    float *feature_out;
+    int flen;
+};
+
+int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d);
+// lanes per env: smallest of 8/16/32/64 that holds W*L cells, 0 if unsupported
+inline int tap_group_size(const tap_env_desc *d)
+{
+    const int cells = d->W * d->L;
+    return cells <= 8 ? 8 : cells <= 16 ? 16 : cells <= 32 ? 32 : cells <= 64 ? 64 : 0;
+}

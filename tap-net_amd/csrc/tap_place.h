@@ -1,0 +1,305 @@
+// tap_place.h -- device code: one LB_GREEDY placement for one container, G lanes per container.
+//
+// Mapping (CDNA4, wave64): a container ("env") owns a group of G = 8/16/32/64 consecutive lanes
+// of one wavefront; lane `cell` of the group owns height-map cell (x, y) = (cell / L, cell % L).
+// A 256-thread workgroup therefore steps 256/G envs and a launch of B envs has B*G/256 >= 256
+// workgroups at the BASELINE batch sizes.  Every left-bottom corner candidate is evaluated by the
+// lane that owns its cell, in parallel; the reference's "first maximum in (z, y, class, x) order"
+// argmax (tools.py:2081, 2161-2162, 2250, 2262) becomes a log2(G)-step butterfly over
+// (ratio desc, key asc).  The height-map slice of the group is staged in LDS so that footprint
+// scans are LDS reads, not global reads.
+//
+// Only the height-map and four counters are carried (the reference's voxel
+// grid is redundant); the oracle keeps the voxels, and the parity tests compare the two.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cstdint>
+
+#include "tapenv.h"
+
+typedef unsigned long long u64;
+
+struct PlaceCfg {
+    int W, L, H, flags;
+};
+
+struct Counters {
+    int valid, empty, nstable, count;
+};
+
+struct Placement {
+    int placed; // group-uniform
+    int x, y, z, stab;
+};
+
+// ---- cross-lane helpers (all lanes of the group must be active) ----------------------------
+template <int G> __device__ __forceinline__ int group_max(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, G));
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_min(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, G));
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_or(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v |= __shfl_xor(v, o, G);
+    return v;
+}
+
+// ---- stability predicates on a support mask ------------------------------------------------
+// `eq` marks the footprint cells whose column top equals the placement level z (the cells that
+// carry the block); every other footprint cell is lower.
+
+// tools.is_stable_2d (tools.py:839-868): bit i = column x+i.  The centre x + bx/2 must lie
+// strictly inside (first supported, last supported + 1)  <=>  2*lead < bx and 2*trail < bx.
+__device__ __forceinline__ int tap_stable2d(int bx, u64 eq)
+{
+    const int lead = __ffsll((long long)eq) - 1;
+    const int trail = bx - 1 - (63 - __clzll((long long)eq));
+    return (2 * lead < bx) && (2 * trail < bx);
+}
+
+// tools.py:736-744 / 755-762, doubled coordinates
+__device__ __forceinline__ int tap_line_rule(int cx, int cy, int p0x, int p0y, int p1x, int p1y)
+{
+    const int a = cx - p0x, b = cy - p0y, c = cx - p1x, d = cy - p1y;
+    if (b == 0 || d == 0) return (b == d) && ((a < 0) != (c < 0));
+    return (a * d == c * b) && ((a < 0) != (c < 0)) && ((b < 0) != (d < 0));
+}
+
+// tools.is_stable (tools.py:710-765) for z > 0: bit (i*8 + j) = footprint cell (i, j) supports.
+// The reference builds scipy's convex hull and asks matplotlib's Path.contains_point (Agg
+// crossing test, CCW polygon).  For a convex polygon only the two hull edges that straddle the
+// horizontal through the centre can toggle, so the answer is "centre.x lies in [xmin, xmax]",
+// the intersection of the hull with that line under Agg's half-open rule (y >= ty counts as
+// above).  xmin/xmax are extrema of pairwise segment intercepts, which turns into sign tests on
+// integer cross products -- no hull, no arrays.  Validated against the reference on all 75 018
+// masks of footprints <= 4x4 and 30 000 sampled masks up to 6x6 (tests/golden/stable3d.npz).
+__device__ inline int tap_stable3d(int bx, int by, u64 m)
+{
+    const int k = __popcll(m);
+    if (2 * k > bx * by) return 1; // :730
+    if (k <= 1) return 0;          // :732
+    const int tx = bx - 1, ty = by - 1; // centre, doubled, footprint-local
+    const int b0 = __ffsll((long long)m) - 1;
+    const int p0x = 2 * (b0 >> 3), p0y = 2 * (b0 & 7);
+    u64 rest = m & (m - 1);
+    const int b1 = __ffsll((long long)rest) - 1;
+    const int p1x = 2 * (b1 >> 3), p1y = 2 * (b1 & 7);
+    if (k == 2) return tap_line_rule(tx, ty, p0x, p0y, p1x, p1y); // :734-744
+    // all collinear -> qhull raises -> segment rule on (first min-x point, first max-x point)
+    bool col = true;
+    for (u64 r = rest & (rest - 1); r; r &= r - 1) {
+        const int b = __ffsll((long long)r) - 1;
+        const int px = 2 * (b >> 3), py = 2 * (b & 7);
+        if ((p1x - p0x) * (py - p0y) - (p1y - p0y) * (px - p0x) != 0) col = false;
+    }
+    if (col) { // :750-762
+        const int imax = (63 - __clzll((long long)m)) >> 3;
+        const int jlo = __ffsll((long long)((m >> (8 * imax)) & 0xffull)) - 1;
+        return tap_line_rule(tx, ty, p0x, p0y, 2 * imax, 2 * jlo);
+    }
+    bool le = false, ge = false; // exists pair with intercept <= tx / >= tx   (:764-765)
+    for (u64 mu = m; mu; mu &= mu - 1) {
+        const int bu = __ffsll((long long)mu) - 1;
+        const int ux = 2 * (bu >> 3), uy = 2 * (bu & 7);
+        if (uy < ty) continue; // upper set: y >= ty
+        for (u64 ml = m; ml; ml &= ml - 1) {
+            const int bl = __ffsll((long long)ml) - 1;
+            const int lx = 2 * (bl >> 3), ly = 2 * (bl & 7);
+            if (ly >= ty) continue; // lower set: y < ty
+            const int g = (ty - uy) * (lx - ux) - (tx - ux) * (ly - uy);
+            le |= g >= 0;
+            ge |= g <= 0;
+        }
+    }
+    return le && ge;
+}
+
+// ---- footprint scan over the group's LDS slice ---------------------------------------------
+// -> mx = max height, eq = cells at that height (2D: bit i; 3D: bit i*8+j), sum = sum of heights
+template <int D>
+__device__ __forceinline__ void tap_scan(const int *s, int L, int x, int y, int bx, int by,
+                                         int &mx, u64 &eq, int &sum)
+{
+    mx = -1; eq = 0; sum = 0;
+    if (D == 2) {
+        for (int i = 0; i < bx; ++i) {
+            const int h = s[x + i];
+            sum += h;
+            if (h > mx) { mx = h; eq = 1ull << i; }
+            else if (h == mx) eq |= 1ull << i;
+        }
+    } else {
+        for (int i = 0; i < bx; ++i)
+            for (int j = 0; j < by; ++j) {
+                const int h = s[(x + i) * L + y + j];
+                sum += h;
+                const u64 bit = 1ull << (i * 8 + j);
+                if (h > mx) { mx = h; eq = bit; }
+                else if (h == mx) eq |= bit;
+            }
+    }
+}
+
+// C+P+S of one settled candidate, fp64 in the reference's operation order
+// (tools.py:2124-2140 / 2300-2315; ratio = (c + p) + s at :2161).
+__device__ __forceinline__ double tap_score(const PlaceCfg &c, const Counters &cnt, int vol,
+                                            int gmax, int z, int bz, int emp, int stab)
+{
+    const int valid2 = cnt.valid + vol;
+    const int height = max(gmax, z + bz);
+    const double C = (double)valid2 / (double)((long long)height * c.W * c.L);
+    const double P = (c.flags & TAP_F_USE_P) ? (double)valid2 / (double)(emp + valid2) : 0.0;
+    const double S = (c.flags & TAP_F_USE_S)
+                         ? (double)(cnt.nstable + stab) / (double)(cnt.count + 1) : 0.0;
+    return (C + P) + S;
+}
+
+// ---- one placement -------------------------------------------------------------------------
+// s        : the group's LDS slice holding the current height-map (written + barrier'd by caller)
+// cell     : lane index inside the group; hm : this lane's cell height (updated on commit)
+// do_step  : group-uniform; false leaves the env untouched
+// err      : per-lane error bits, OR-reduced by the caller (1 = height overflow)
+template <int D, int G>
+__device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell, int &hm,
+                                      Counters &cnt, int &err, int bx, int by, int bz,
+                                      bool do_step)
+{
+    const int W = c.W, L = c.L;
+    const int x = (D == 2) ? cell : cell / L;
+    const int y = (D == 2) ? 0 : cell - x * L;
+    const bool incell = cell < W * L;
+    const bool hard = (c.flags & TAP_F_HARD) != 0;
+    const int vol = bx * by * bz;
+    const int gmax = group_max<G>(incell ? hm : 0);
+
+    // left-bottom corners from the height-map (tools.py:2067-2078 2D; 2219-2246 3D, appendix B)
+    bool corner = false;
+    int cls = 0;
+    if (incell) {
+        if (D == 2) {
+            corner = (x == 0) || (hm != s[cell - 1]);
+        } else {
+            const int h = hm;
+            const int hxm = x > 0 ? s[cell - L] : 0;                // hm[x-1, y]
+            const int hym = y > 0 ? s[cell - 1] : 0;                // hm[x, y-1]
+            const int hxym = (x > 0 && y > 0) ? s[cell - L - 1] : 0; // hm[x-1, y-1]
+            const int hxmm = x > 1 ? s[cell - 2 * L] : 0;           // hm[x-2, y]
+            const int dx = x > 0 ? h - hxm : 0;                     // hm_diff_x[x, y]
+            const int dx_ym = (x > 0 && y > 0) ? hym - hxym : 0;    // hm_diff_x[x, y-1]
+            const int dx_xm = x > 1 ? hxm - hxmm : 0;               // hm_diff_x[x-1, y]
+            const int dy = y > 0 ? h - hym : 0;                     // hm_diff_y[x, y]
+            const int dy_xm = (x > 0 && y > 0) ? hxm - hxym : 0;    // hm_diff_y[x-1, y]
+            const bool rej1 = (y > 0) && (dx_ym != 0) && (h == hym) && (dx == dx_ym); // :2234-2237
+            const bool c1 = (dx != 0) && !rej1;
+            const bool rej2 = (x > 0) && (dy_xm != 0) && (h == hxm) && (dx == dx_xm); // :2241-2244 (sic dx)
+            const bool c2 = !c1 && (dy != 0) && !rej2;
+            if (cell == 0) { corner = true; cls = 0; }
+            else if (c1) { corner = true; cls = 1; }
+            else if (c2) { corner = true; cls = 2; }
+        }
+    }
+    const bool cand = do_step && corner && (x + bx <= W) && (y + by <= L); // :2076, :2255-2256
+
+    Placement res = {0, 0, 0, 0, 0};
+    int emp_w = 0;
+
+    if (!hard) {
+        // soft: every in-bounds corner settles on itself (z = max of its footprint)
+        double ratio = -1.0;
+        int key = INT_MAX, z = 0, stab = 0, emp = 0;
+        if (cand) {
+            int mx, sum; u64 eq;
+            tap_scan<D>(s, L, x, y, bx, by, mx, eq, sum);
+            z = mx;
+            if (z >= c.H) err |= 1;                               // :2109 would raise IndexError
+            stab = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d(bx, by, eq));
+            emp = cnt.empty + bx * by * z - sum;                  // :2132-2134
+            ratio = tap_score(c, cnt, vol, gmax, z, bz, emp, stab);
+            key = ((z * L + y) * 3 + cls) * W + x;                // sort order (z, y, class, x)
+        }
+        int wl = (int)(threadIdx.x & 63);
+#pragma unroll
+        for (int o = G / 2; o > 0; o >>= 1) {
+            const double r2 = __shfl_xor(ratio, o, G);
+            const int k2 = __shfl_xor(key, o, G);
+            const int w2 = __shfl_xor(wl, o, G);
+            if (r2 > ratio || (r2 == ratio && k2 < key)) { ratio = r2; key = k2; wl = w2; }
+        }
+        res.placed = ratio > 0.0;
+        res.x = __shfl(x, wl);
+        res.y = __shfl(y, wl);
+        res.z = __shfl(z, wl);
+        res.stab = __shfl(stab, wl);
+        emp_w = __shfl(emp, wl);
+    } else {
+        // hard: the reference walks the sorted corner list sequentially with a shared `visited`
+        // set, sliding each block until it is supported, free and stable (tools.py:2100-2121,
+        // 2284-2297, 2320-2327).  All lanes of the group run the walk redundantly in lock-step,
+        // so no broadcast is needed afterwards.
+        int z0 = 0;
+        if (cand) { int sum; u64 eq; tap_scan<D>(s, L, x, y, bx, by, z0, eq, sum); }
+        const int mykey = cand ? ((z0 * L + y) * 3 + cls) * W + x : INT_MAX;
+        int last = -1, vis_z = -1;
+        u64 visited = 0;
+        double best = -1.0;
+        for (int it = 0; it < G; ++it) { // wave-uniform trip count: shuffles stay convergent
+            const int kmin = group_min<G>(mykey > last ? mykey : INT_MAX);
+            if (kmin == INT_MAX) continue;
+            last = kmin;
+            const int X0 = kmin % W;
+            int t = kmin / W;
+            t /= 3;
+            const int Y0 = t % L, z = t / L;
+            if (z != vis_z) { vis_z = z; visited = 0; }
+            bool ok = false;
+            int sx = 0, sy = 0, sstab = 0, semp = 0;
+            for (int _x = X0; _x + bx <= W && !ok; ++_x)
+                for (int _y = Y0; _y + by <= L && !ok; ++_y) {
+                    const u64 pbit = 1ull << (_x * L + _y);
+                    if (visited & pbit) continue;                 // :2105
+                    int mx, sum; u64 eq;
+                    tap_scan<D>(s, L, _x, _y, bx, by, mx, eq, sum);
+                    if (z > 0 && mx < z) continue;                // :2106 nothing underneath
+                    visited |= pbit;                              // :2107
+                    if (z >= c.H) { err |= 1; continue; }         // :2109 IndexError
+                    if (mx > z) continue;                         // :2109 not free
+                    const int st = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d(bx, by, eq));
+                    if (!st) continue;                            // :2112-2114 hard rejects
+                    ok = true; sx = _x; sy = _y; sstab = st;
+                    semp = cnt.empty + bx * by * z - sum;
+                }
+            if (ok) {
+                const double r = tap_score(c, cnt, vol, gmax, z, bz, semp, sstab);
+                if (r > best) { // first maximum in list order
+                    best = r; res.placed = 1; res.x = sx; res.y = sy; res.z = z; res.stab = sstab; emp_w = semp;
+                }
+            }
+        }
+    }
+
+    // commit (tools.py:2167-2174); a failed placement leaves everything but the step counter
+    if (do_step) {
+        if (res.placed) {
+            if (incell && x >= res.x && x < res.x + bx && y >= res.y && y < res.y + by) hm = res.z + bz;
+            cnt.valid += vol;
+            cnt.empty = emp_w;
+            cnt.nstable += res.stab;
+            if (res.z + bz > c.H) err |= 1;                       // :2169 numpy clips silently
+        } else {
+            res.x = res.y = res.z = res.stab = 0;
+        }
+        cnt.count += 1;                                           // tools.py:3713
+    }
+    return res;
+}

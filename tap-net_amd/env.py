@@ -1,0 +1,297 @@
+"""Batched counterpart of the reference's ``tools.Container`` (tools.py:3607-3966).
+
+``BatchedContainer`` steps B containers in lock-step on one MI355X through libtapenv's HIP
+kernels; ``Container`` is the per-env facade with the reference's own method surface
+(``add_new_block`` / ``get_heightmap`` / ``calc_ratio`` / ``clear_container`` and the attributes
+rolling.py reads), implemented as a BatchedContainer of one.  Neither has a CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+class BatchedContainer(object):
+    """B target containers: height-maps + counters in HBM, stepped by one kernel launch.
+
+    Constructor arguments after ``batch_size`` are those of tools.Container.__init__
+    (tools.py:3611-3612); ``initial_container_size`` / ``max_height`` are accepted and stored only
+    (the reference uses them for drawing).
+    """
+
+    def __init__(self, batch_size, container_size, blocks_num, reward_type, heightmap_type='full',
+                 initial_container_size=None, max_height=None, packing_strategy='LB_GREEDY',
+                 device='cuda'):
+        self.device = _lib.resolve_device(device)
+        self.batch_size = int(batch_size)
+        self.container_size = [int(v) for v in container_size]
+        self.block_dim = len(self.container_size)
+        self.blocks_num = int(blocks_num)
+        self.reward_type = reward_type
+        self.heightmap_type = heightmap_type
+        self.initial_container_size = initial_container_size
+        self.max_height = 2 * self.container_size[0] if max_height is None else max_height  # tools.py:3624-3627
+        self.desc = _lib.make_desc(self.batch_size, self.container_size, blocks_num, reward_type,
+                                   heightmap_type, packing_strategy)
+        # tools.py:3617-3620: the reward string may override the strategy
+        if reward_type in ('C+P+S-mul-soft', 'C+P+S-mul-hard'):
+            packing_strategy = 'MUL'
+        elif reward_type in ('C+P+S-mcs-soft', 'C+P+S-mcs-hard'):
+            packing_strategy = 'MACS'
+        self.packing_strategy = packing_strategy
+        self._ctx = _lib.ctx(self.device)
+        nbytes = _lib.lib().tap_env_state_bytes(C.byref(self.desc))
+        self._state = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=self.device)
+        self._flen = _lib.lib().tap_env_feature_len(C.byref(self.desc))
+        self.reset()
+
+    # ---- plumbing ---------------------------------------------------------------------------
+    def _call(self, fn, *args):
+        with torch.cuda.device(self.device):
+            _lib.check(fn(self._ctx, C.byref(self.desc), *args, _lib.stream_of(self.device)), self._ctx)
+
+    def _feature_shape(self):
+        d = self.desc
+        if d.D == 2:
+            return (self.batch_size, self._flen, 1)              # model.py:456-458 .unsqueeze(2)
+        if self.heightmap_type == 'diff':
+            return (self.batch_size, 2, d.W, d.L)                # model.py:461-463
+        return (self.batch_size, 1, d.W, d.L)                    # model.py:464-465 .unsqueeze(1)
+
+    def _new_feature(self):
+        return torch.empty(self._feature_shape(), dtype=torch.float32, device=self.device)
+
+    def _as_active(self, active):
+        if active is None:
+            return None
+        a = torch.as_tensor(active, device=self.device)
+        return a.to(torch.uint8).contiguous()
+
+    # ---- tools.Container surface, batched ---------------------------------------------------
+    def reset(self):
+        """clear_container for every env (tools.py:3858-3885)."""
+        self._call(_lib.lib().tap_env_reset, _lib.ptr(self._state))
+
+    clear_container = reset
+
+    def add_new_blocks(self, blocks, active=None, want_feature=True):
+        """add_new_block for all envs (tools.py:3663-3744): ``blocks`` (B, D) float32/int32 tensor
+        (or anything torch.as_tensor accepts).  Returns the heightmap feature in the layout
+        model.py:456-465 feeds the decoder, or None if ``want_feature`` is False."""
+        blocks = torch.as_tensor(blocks, device=self.device)
+        if blocks.dim() == 3 and blocks.shape[-1] == 1:          # decoder_static (B, D, 1), model.py:404-412
+            blocks = blocks.squeeze(-1)
+        if tuple(blocks.shape) != (self.batch_size, self.block_dim):
+            raise ValueError("blocks must be (%d, %d), got %s" % (self.batch_size, self.block_dim, tuple(blocks.shape)))
+        if blocks.dtype == torch.int32:
+            dt = _lib.TAP_DT_I32
+        else:
+            blocks = blocks.to(torch.float32)
+            dt = _lib.TAP_DT_F32
+        blocks = blocks.contiguous()
+        act = self._as_active(active)
+        feat = self._new_feature() if want_feature else None
+        self._call(_lib.lib().tap_env_step, _lib.ptr(self._state), _lib.ptr(blocks), dt,
+                   _lib.ptr(act), _lib.ptr(feat))
+        return feat
+
+    def add_new_blocks_gather(self, static, ptr, active=None, want_feature=True, out=None):
+        """Same, with the gather of model.py:404-412 fused: block = static[b, 1:1+D, ptr[b]]."""
+        if static.dtype != torch.float32 or not static.is_contiguous() or static.device != self.device:
+            static = static.to(device=self.device, dtype=torch.float32).contiguous()
+        ptr = ptr.to(device=self.device, dtype=torch.int64).contiguous()
+        act = self._as_active(active)
+        feat = out if out is not None else (self._new_feature() if want_feature else None)
+        self._call(_lib.lib().tap_env_step_gather, _lib.ptr(self._state), _lib.ptr(static),
+                   static.shape[1], static.shape[2], _lib.ptr(ptr), _lib.ptr(act), _lib.ptr(feat))
+        return feat
+
+    def get_heightmaps(self):
+        """get_heightmap for all envs (tools.py:3824-3856), same layout as add_new_blocks."""
+        feat = self._new_feature()
+        self._call(_lib.lib().tap_env_feature, _lib.ptr(self._state), _lib.ptr(feat))
+        return feat
+
+    def calc_ratios(self, out=None):
+        """calc_ratio for all envs as the fp32 tensor model.py:499-510 builds."""
+        r = out if out is not None else torch.empty(self.batch_size, dtype=torch.float32, device=self.device)
+        self._call(_lib.lib().tap_env_ratio, _lib.ptr(self._state), _lib.ptr(r), None, None)
+        return r
+
+    def calc_ratios64(self):
+        r = torch.empty(self.batch_size, dtype=torch.float64, device=self.device)
+        self._call(_lib.lib().tap_env_ratio, _lib.ptr(self._state), None, _lib.ptr(r), None)
+        return r
+
+    def calc_CPS(self):
+        """(B, 3) float64 tensor of C, P, S (tools.py:3887-3905)."""
+        cps = torch.empty(self.batch_size, 3, dtype=torch.float64, device=self.device)
+        self._call(_lib.lib().tap_env_ratio, _lib.ptr(self._state), None, None, _lib.ptr(cps))
+        return cps
+
+    def check(self):
+        """Synchronises; raises TapOverflowError (an IndexError, like the reference) if any env
+        was pushed above its height, TapError for other sticky errors."""
+        n_bad = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            st = _lib.lib().tap_env_check(self._ctx, C.byref(self.desc), _lib.ptr(self._state),
+                                          C.byref(n_bad), _lib.stream_of(self.device))
+        _lib.check(st, self._ctx)
+
+    # ---- attributes -------------------------------------------------------------------------
+    def _export(self, hm=False, pos=False, st=False, cnt=False):
+        d, B = self.desc, self.batch_size
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=self.device)  # noqa: E731
+        o_hm = mk((B, d.W * d.L), torch.int32) if hm else None
+        o_pos = mk((B, d.n_max, d.D), torch.int32) if pos else None
+        o_st = mk((B, d.n_max), torch.uint8) if st else None
+        o_cnt = mk((B, 4), torch.int32) if cnt else None
+        self._call(_lib.lib().tap_env_export, _lib.ptr(self._state), _lib.ptr(o_hm), _lib.ptr(o_pos),
+                   _lib.ptr(o_st), _lib.ptr(o_cnt))
+        return o_hm, o_pos, o_st, o_cnt
+
+    @property
+    def heightmap(self):
+        hm = self._export(hm=True)[0]
+        d = self.desc
+        return hm.view(self.batch_size, d.W, d.L) if d.D == 3 else hm
+
+    @property
+    def positions(self):
+        return self._export(pos=True)[1]
+
+    @property
+    def stable(self):
+        return self._export(st=True)[2].bool()
+
+    @property
+    def counters(self):
+        """(B, 4) int32: valid_size, empty_size, sum(stable), current_blocks_num."""
+        return self._export(cnt=True)[3]
+
+    @property
+    def valid_size(self):
+        return self.counters[:, 0]
+
+    @property
+    def empty_size(self):
+        return self.counters[:, 1]
+
+    @property
+    def current_blocks_num(self):
+        return self.counters[:, 3]
+
+    def state_dict(self):
+        return {'state': self._state.clone(), 'desc': bytes(self.desc)}
+
+    def load_state_dict(self, sd):
+        if sd['desc'] != bytes(self.desc):
+            raise ValueError("state_dict was saved for a different container description")
+        self._state.copy_(sd['state'])
+
+
+class Container(object):
+    """Drop-in for ``tools.Container`` (tools.py:3607): one container, numpy in / numpy out, the
+    placement computed by the same HIP kernels (a BatchedContainer with batch_size 1)."""
+
+    def __init__(self, container_size, blocks_num, reward_type, heightmap_type='full',
+                 initial_container_size=None, max_height=None, packing_strategy='LB_GREEDY',
+                 device='cuda'):
+        self._b = BatchedContainer(1, container_size, blocks_num, reward_type, heightmap_type,
+                                   initial_container_size, max_height, packing_strategy, device)
+        self.reward_type = reward_type
+        self.block_dim = self._b.block_dim
+        self.blocks_num = int(blocks_num)
+        self.container_size = container_size
+        self.initial_container_size = initial_container_size
+        self.packing_strategy = self._b.packing_strategy
+        self.heightmap_type = heightmap_type
+        self.max_height = self._b.max_height
+        self.blocks = []
+        self.rotate_state = [False] * self.blocks_num
+        self.bounding_box = np.zeros(self.block_dim)
+
+    def _shape(self, feat):
+        a = feat.detach().cpu().numpy().astype(np.int64)
+        if self.block_dim == 2:
+            return a.reshape(-1)
+        return a.reshape(a.shape[1:]) if self.heightmap_type == 'diff' else a.reshape(a.shape[2:])
+
+    def add_new_block(self, block, is_rotate=False):
+        n = len(self.blocks)
+        if n >= self.blocks_num:
+            raise IndexError("list assignment index out of range")   # tools.py:3677
+        self.rotate_state[n] = is_rotate
+        self.blocks.append(np.asarray(block))
+        blk = torch.as_tensor(np.asarray(block, dtype=np.float32).reshape(1, -1))
+        feat = self._b.add_new_blocks(blk)
+        self._b.check()
+        return self._shape(feat)
+
+    def get_heightmap(self, is_full=None):
+        if is_full is not None:
+            return self.heightmap
+        return self._shape(self._b.get_heightmaps())
+
+    def calc_CPS(self):
+        c, p, s = self._b.calc_CPS()[0].tolist()
+        return c, p, s
+
+    def calc_ratio(self):
+        return float(self._b.calc_ratios64()[0].item())
+
+    def clear_container(self):
+        self._b.reset()
+        self.blocks = []
+        self.rotate_state = [False] * self.blocks_num
+        self.bounding_box = np.zeros(self.block_dim)
+
+    @property
+    def heightmap(self):
+        return self._b.heightmap[0].cpu().numpy().astype(np.int64)
+
+    @property
+    def positions(self):
+        return self._b.positions[0].cpu().numpy().astype(np.int64)
+
+    @property
+    def stable(self):
+        return [bool(v) for v in self._b.stable[0].tolist()]
+
+    @property
+    def valid_size(self):
+        return int(self._b.counters[0, 0].item())
+
+    @property
+    def empty_size(self):
+        return int(self._b.counters[0, 1].item())
+
+    @property
+    def current_blocks_num(self):
+        return int(self._b.counters[0, 3].item())
+
+    @property
+    def container(self):
+        """Voxel grid rebuilt from the placement history (block ids, -1 for covered holes), the
+        array tools.py keeps at self.container; the kernels themselves never materialise it."""
+        grid = np.zeros(self.container_size, dtype=np.int64)
+        pos, st_blocks = self.positions, [np.asarray(b).astype(int) for b in self.blocks]
+        hm = np.zeros(self.container_size[:-1], dtype=np.int64)
+        placed_any = np.zeros(len(st_blocks), dtype=bool)
+        # a failed placement leaves position 0 and does not touch the height-map; replay to tell
+        for i, b in enumerate(st_blocks):
+            p = pos[i]
+            sl = tuple(slice(int(p[k]), int(p[k]) + int(b[k])) for k in range(self.block_dim - 1))
+            if any(int(p[k]) + int(b[k]) > self.container_size[k] for k in range(self.block_dim - 1)):
+                continue
+            z = int(p[-1])
+            if hm[sl].size == 0 or int(hm[sl].max()) != z:
+                continue
+            placed_any[i] = True
+            under = grid[sl + (slice(0, z),)]
+            under[under == 0] = -1
+            grid[sl + (slice(z, z + int(b[-1])),)] = i + 1
+            hm[sl] = z + int(b[-1])
+        return grid

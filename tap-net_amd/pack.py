@@ -1,0 +1,301 @@
+"""Device counterparts of the reference's ``pack.py`` seams, same names and signatures:
+
+* ``update_dynamic`` (pack.py:333-376) and ``update_mask`` (pack.py:276-331) -- the callables
+  trainer.py:475-476 injects into ``DRL`` as ``update_fn`` / ``mask_fn``;
+* ``reward`` (pack.py:378-473) -- ``kwargs['reward_fn']``;
+* ``PACKDataset`` (pack.py:25-273) -- the ``Dataset`` the trainer wraps in a ``DataLoader``.
+
+All tensors stay on the ROCm device; results are fresh tensors (the input ``dynamic`` is never
+mutated: the trainer re-uses it for the critic, trainer.py:214).
+"""
+import itertools
+import math
+import weakref
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import _lib
+
+_UPDATE_ROWS = {  # pack.py:338-357
+    'simple': 1, 'rot': 1, 'rot-old': 1, 'bot': 3, 'bot-rot': 3, 'use-static': 3, 'use-pnet': 3,
+    'mul': 3, 'mul-with': 3,
+}
+
+
+def _block_dim(static, input_type):
+    if input_type not in _UPDATE_ROWS:
+        raise ValueError("unknown input_type %r" % (input_type,))
+    return int(static.shape[1]) - (2 if input_type in ('mul', 'mul-with') else 1)   # pack.py:288-302
+
+
+def _rotate_types(block_dim, allow_rot):
+    return math.factorial(block_dim) if allow_rot else 1                           # pack.py:306-309
+
+
+def _f32c(t):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+# ---- (B, 3, nR) column-sum shadow of a dynamic tensor -------------------------------------------
+# update_mask only needs the per-section column sums of `dynamic` (pack.py:324-326).  update_dynamic
+# produces them for its output as a by-product (old sums minus the zeroed rows), so the mask_fn
+# that follows it in model.py:376-384 does not have to read the 3n x nR slab again.
+_shadow = {}
+
+
+def _shadow_put(dynamic, colsum):
+    key = id(dynamic)
+    _shadow[key] = (weakref.ref(dynamic, lambda _r, k=key: _shadow.pop(k, None)), dynamic._version, colsum)
+
+
+def _shadow_get(dynamic):
+    hit = _shadow.get(id(dynamic))
+    if hit is not None and hit[0]() is dynamic and hit[1] == dynamic._version:
+        return hit[2]
+    return None
+
+
+def dynamic_colsum(dynamic, blocks_num):
+    """(B, 3, nR) float32 column sums of the move / small / large sections of ``dynamic``."""
+    cs = _shadow_get(dynamic)
+    if cs is not None:
+        return cs
+    dyn = _f32c(dynamic)
+    B, rows, nR = dyn.shape
+    cs = torch.empty(B, 3, nR, dtype=torch.float32, device=dyn.device)
+    c = _lib.ctx(dyn.device)
+    with torch.cuda.device(dyn.device):
+        _lib.check(_lib.lib().tap_dyn_colsum(c, B, blocks_num, nR, rows, _lib.ptr(dyn), _lib.ptr(cs),
+                                             _lib.stream_of(dyn.device)), c)
+    _shadow_put(dynamic, cs)
+    return cs
+
+
+def update_dynamic(dynamic, static, chosen_idx, input_type, allow_rot):
+    """pack.update_dynamic (pack.py:333-376): zero the chosen block's rows, out of place."""
+    block_dim = _block_dim(static, input_type)
+    R = _rotate_types(block_dim, allow_rot)
+    dyn, st = _f32c(dynamic), _f32c(static)
+    B, rows, nR = dyn.shape
+    n = nR // R                                                                    # pack.py:367
+    ptr = chosen_idx.to(torch.int64).contiguous()
+    out = torch.empty_like(dyn)
+    cs_in = _shadow_get(dynamic)
+    cs_out = torch.empty_like(cs_in) if cs_in is not None else None
+    c = _lib.ctx(dyn.device)
+    with torch.cuda.device(dyn.device):
+        _lib.check(_lib.lib().tap_update_dynamic(
+            c, B, n, nR, rows, _UPDATE_ROWS[input_type], _lib.ptr(dyn), _lib.ptr(st), st.shape[1],
+            _lib.ptr(ptr), _lib.ptr(out), _lib.ptr(cs_in), _lib.ptr(cs_out),
+            _lib.stream_of(dyn.device)), c)
+    if cs_out is not None:
+        _shadow_put(out, cs_out)
+    return out
+
+
+def update_mask(mask, dynamic, static, chosen_idx, input_type, allow_rot):
+    """pack.update_mask (pack.py:276-331) -> (new_mask.float(), chosen_mask)."""
+    block_dim = _block_dim(static, input_type)
+    R = _rotate_types(block_dim, allow_rot)
+    nR = int(dynamic.shape[-1])
+    n = nR // R                                                                    # pack.py:311
+    cs = dynamic_colsum(dynamic, n)
+    m = _f32c(mask)
+    ptr = chosen_idx.to(torch.int64).contiguous()
+    B = m.shape[0]
+    cur = torch.empty_like(m)
+    new = torch.empty_like(m)
+    c = _lib.ctx(m.device)
+    with torch.cuda.device(m.device):
+        _lib.check(_lib.lib().tap_update_mask(c, B, n, R, _lib.ptr(m), _lib.ptr(cs), _lib.ptr(ptr),
+                                              _lib.ptr(cur), _lib.ptr(new), _lib.stream_of(m.device)), c)
+    return cur, new
+
+
+def initial_mask(dynamic, blocks_num):
+    """The mask DRL.forward builds before its loop (model.py:297-307) -> (current_mask, mask)."""
+    dyn = _f32c(dynamic)
+    B, rows, nR = dyn.shape
+    cs = dynamic_colsum(dynamic, blocks_num)
+    cur = torch.empty(B, nR, dtype=torch.float32, device=dyn.device)
+    mask = torch.empty(B, nR, dtype=torch.float32, device=dyn.device)
+    c = _lib.ctx(dyn.device)
+    with torch.cuda.device(dyn.device):
+        _lib.check(_lib.lib().tap_update_mask(c, B, blocks_num, nR // blocks_num, None, _lib.ptr(cs), None,
+                                              _lib.ptr(cur), _lib.ptr(mask), _lib.stream_of(dyn.device)), c)
+    return cur, mask
+
+
+class MaskStepper(object):
+    """update_dynamic + update_mask fused into one launch per step (model.py:376-386), for callers
+    that drive the episode loop themselves (tap-net_amd.rollout, bench.py)."""
+
+    def __init__(self, static, dynamic, input_type='bot', allow_rot=True):
+        self.static = _f32c(static)
+        self.dynamic = _f32c(dynamic)
+        self.block_dim = _block_dim(static, input_type)
+        self.R = _rotate_types(self.block_dim, allow_rot)
+        self.B, self.rows, self.nR = self.dynamic.shape
+        self.n = self.nR // self.R
+        self.update_rows = _UPDATE_ROWS[input_type]
+        self.colsum = dynamic_colsum(self.dynamic, self.n)
+        self.current_mask, self.mask = initial_mask(self.dynamic, self.n)
+
+    def step(self, ptr, dyn_out=None):
+        """-> (new_dynamic, current_mask, mask).  ``dyn_out`` lets a caller recycle buffers."""
+        ptr = ptr.to(torch.int64).contiguous()
+        out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
+        cs = torch.empty_like(self.colsum)
+        cur = torch.empty_like(self.mask)
+        new = torch.empty_like(self.mask)
+        c = _lib.ctx(out.device)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib().tap_mask_step(
+                c, self.B, self.n, self.R, self.rows, self.update_rows, _lib.ptr(self.dynamic),
+                _lib.ptr(self.static), self.static.shape[1], _lib.ptr(ptr), _lib.ptr(self.mask),
+                _lib.ptr(self.colsum), _lib.ptr(out), _lib.ptr(cs), _lib.ptr(cur), _lib.ptr(new),
+                _lib.stream_of(out.device)), c)
+        self.dynamic, self.colsum, self.current_mask, self.mask = out, cs, cur, new
+        return out, cur, new
+
+
+def reward(static, tour_indices, reward_type, input_type, allow_rot, container_width, container_height,
+           packing_strategy='LB_GREEDY'):
+    """pack.reward (pack.py:378-473): pack every env's blocks in tour order from an empty
+    container and return ``-scores`` (un-normalised C+P+S, tools.py:2442-2449), one launch."""
+    if input_type in ('mul', 'mul-with'):
+        raise NotImplementedError("reward() for the two-container input types is not implemented")
+    if packing_strategy in ('MACS', 'MUL'):
+        # pack.py:431 names tools.calc_positions_mus, which does not exist in the reference
+        raise AttributeError("module 'tools' has no attribute 'calc_positions_mus'")
+    block_dim = _block_dim(static, input_type)
+    R = _rotate_types(block_dim, allow_rot)
+    st = _f32c(static)
+    B, rows, nR = st.shape
+    n = nR // R                                                                    # pack.py:438
+    tour = tour_indices.to(torch.int64).contiguous()
+    steps = tour.shape[1]
+    if steps < n:
+        raise ValueError("tour shorter than blocks_num")
+    if steps > n:
+        tour = tour[:, :n].contiguous()                                            # pack.py:444 [:,:,:n]
+    cs = [container_width, container_height] if block_dim == 2 else \
+        [container_width, container_width, container_height]                       # pack.py:408-411
+    desc = _lib.make_desc(B, cs, n, reward_type, 'full', 'LB_GREEDY')
+    out = torch.empty(B, dtype=torch.float32, device=st.device)
+    import ctypes as C
+    c = _lib.ctx(st.device)
+    with torch.cuda.device(st.device):
+        _lib.check(_lib.lib().tap_episode_reward(c, C.byref(desc), B, n, _lib.ptr(st), rows, nR,
+                                                 _lib.ptr(tour), _lib.ptr(out), None, None,
+                                                 _lib.stream_of(st.device)), c)
+    return out
+
+
+class PACKDataset(Dataset):
+    """pack.PACKDataset (pack.py:25-273): the reference's six text files -> the four tensors of
+    ``__getitem__``.  Layouts: static (N, 1+D, n*R) with row 0 = block id and
+    column r*n+i = block i in rotation r; dynamic (N, 3n, n*R) = cat(move, small, large)."""
+
+    def __init__(self, data_file, blocks_num, num_samples, seed, input_type, heightmap_type, allow_rot,
+                 container_width, mix_data_file=None, unit=1, no_precedence=False):
+        super(PACKDataset, self).__init__()
+        if seed is None:
+            seed = np.random.randint(123456)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        n = int(blocks_num)
+
+        def load(prefix, name):
+            return np.loadtxt(prefix + name + '.txt').astype('float32')
+
+        names = ('dep_move', 'dep_small', 'dep_large', 'blocks', 'pos', 'container')
+        arr = {k: load(data_file, k) for k in names}
+        if mix_data_file is not None:                                              # pack.py:67-97
+            half = int(num_samples / 2)
+            rot_half = int(len(arr['blocks']) / 2)
+            mix = {k: load(mix_data_file, k) for k in names}
+            for k in ('dep_move', 'pos', 'container'):
+                arr[k] = np.vstack((arr[k][:half], mix[k][:half]))
+            for k in ('dep_small', 'dep_large', 'blocks'):
+                arr[k] = np.vstack((arr[k][:rot_half], mix[k][:rot_half]))
+
+        N = int(num_samples)
+        positions = torch.from_numpy(arr['pos']).view(N, -1, n)
+        D = positions.shape[1]
+        R_all = math.factorial(D)
+        deps_move = torch.from_numpy(arr['dep_move']).view(N, -1, n).transpose(2, 1)
+        # blocks.txt: R lines per sample, each dimension-major (D*n)  -> (N, D, R*n), column r*n+i
+        blocks = arr['blocks'].reshape(N, -1, D, n).transpose(0, 1, 3, 2).reshape(N, -1, D).transpose(0, 2, 1)
+        blocks = (torch.from_numpy(np.ascontiguousarray(blocks)) * unit).ceil()    # pack.py:123-125
+
+        def rot_deps(a):                                                           # pack.py:127-136
+            a = a.reshape(N, -1, n, n).transpose(0, 1, 3, 2).reshape(N, n * R_all, n).transpose(0, 2, 1)
+            return torch.from_numpy(np.ascontiguousarray(a))
+
+        small, large = rot_deps(arr['dep_small']), rot_deps(arr['dep_large'])
+        R = R_all
+        if not allow_rot:                                                          # pack.py:140-142
+            blocks = blocks[:, :, :n]
+            R = 1
+        index = torch.arange(n).view(1, 1, n).repeat(N, 1, R).float()              # pack.py:144-147
+        container_index = torch.from_numpy(arr['container']).unsqueeze(1).repeat(1, 1, R).float()
+        deps_move = deps_move.repeat(1, 1, R)
+        if no_precedence:                                                          # pack.py:175-178
+            deps_move, small, large = (torch.zeros_like(t) for t in (deps_move, small, large))
+
+        if input_type in ('simple', 'rot'):
+            self.static, self.dynamic = torch.cat((index, blocks), 1), deps_move
+        elif input_type == 'bot':
+            self.static = torch.cat((index, blocks), 1)
+            self.dynamic = torch.cat((deps_move, small, large), 1)
+        elif input_type in ('bot-rot', 'use-static', 'use-pnet'):
+            self.static = torch.cat((index, blocks), 1)
+            self.dynamic = torch.cat((deps_move, torch.zeros_like(small), torch.zeros_like(large)), 1)
+        elif input_type in ('mul', 'mul-with'):
+            self.static = torch.cat((index, blocks, container_index), 1)
+            self.dynamic = torch.cat((deps_move, small, large), 1)
+        elif input_type == 'rot-old':
+            self.static = torch.cat((index, blocks), 1)
+            self.dynamic = torch.cat((deps_move, torch.zeros_like(index)), 1)
+        else:
+            raise ValueError("unknown input_type %r" % (input_type,))
+        self.static = self.static.contiguous()
+        self.dynamic = self.dynamic.contiguous()
+
+        # decoder inputs (pack.py:231-264)
+        static_dim = D + (1 if input_type == 'mul-with' else 0)
+        hm_num = 1
+        if heightmap_type == 'diff':
+            hm_w = container_width * unit - 1 if D == 2 else container_width * unit
+            hm_num = 2 if D == 3 else 1
+        else:
+            hm_w = container_width * unit
+        hm_l = int(np.ceil(container_width * unit))
+        hm_w = int(np.ceil(hm_w))
+        if input_type in ('mul', 'mul-with'):
+            if D == 2:
+                hm_w *= 2
+            else:
+                hm_num *= 2
+        self.decoder_static = torch.zeros(N, static_dim, 1, requires_grad=True)
+        if D == 2:
+            self.decoder_dynamic = torch.zeros(N, hm_w, 1, requires_grad=True)
+        else:
+            self.decoder_dynamic = torch.zeros(N, hm_num, hm_w, hm_l, requires_grad=True)
+        self.num_samples = N
+
+    def __len__(self):
+        return self.num_samples
+
+    def __getitem__(self, idx):
+        return (self.static[idx], self.dynamic[idx], self.decoder_static[idx], self.decoder_dynamic[idx])
+
+
+def rotation_permutations(block_dim):
+    """Rotation r permutes a block's sides by itertools.permutations(range(D))[r] (generate.py:953-960)."""
+    return list(itertools.permutations(range(block_dim)))

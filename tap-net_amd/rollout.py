@@ -1,0 +1,72 @@
+"""The episode loop around the batched environment -- this package's counterpart of the loop in
+the reference's ``DRL.forward`` (model.py:342-515), with the policy network factored out.
+
+The reference interleaves its pointer network with a per-env Python loop and two host<->device
+copies per step (model.py:407-465).  Here a step is two kernel launches on the current stream
+(precedence update, placement) and nothing leaves the device until the caller asks.
+"""
+import torch
+
+from .env import BatchedContainer
+from .pack import MaskStepper
+
+
+class TapePolicy(object):
+    """Replays a recorded tour (B, steps) -- e.g. the reference actor's greedy choices."""
+
+    def __init__(self, tour):
+        self.tour = tour
+
+    def __call__(self, step, **_):
+        return self.tour[:, step]
+
+
+class RandomFeasiblePolicy(object):
+    """Uniformly random selectable column of ``current_mask`` (torch.multinomial on device)."""
+
+    def __init__(self, generator=None):
+        self.generator = generator
+
+    def __call__(self, step, current_mask, **_):
+        return torch.multinomial(current_mask, 1, generator=self.generator).squeeze(1)
+
+
+def run_episode(static, dynamic, policy, container_width, container_height,
+                reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
+                input_type='bot', allow_rot=True, env=None, record=False, steps=None):
+    """One episode for a batch (model.py:254-515 minus the network).
+
+    ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
+    returns ptr (B,) int64.  Returns a dict: tour_idx (B, steps), reward = -scores (B,) fp32
+    (model.py:515), env, and with ``record`` the per-step features / masks.
+    """
+    if input_type in ('mul', 'mul-with'):
+        raise NotImplementedError("two-container input types are not implemented in rollout")
+    masks = MaskStepper(static, dynamic, input_type, allow_rot)
+    B, n, D = masks.B, masks.n, masks.block_dim
+    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    if env is None:
+        env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy,
+                               device=masks.static.device)
+    else:
+        env.reset()
+    static_part = masks.static[:, 1:, :]
+    decoder_static = torch.zeros(B, D, 1, device=masks.static.device)
+    decoder_dynamic = torch.zeros(env._feature_shape(), device=masks.static.device)
+    tour, feats, curs, msks = [], [], [], []
+    for step in range(n if steps is None else steps):
+        ptr = policy(step=step, static=masks.static, dynamic=masks.dynamic,
+                     current_mask=masks.current_mask, mask=masks.mask,
+                     decoder_static=decoder_static, decoder_dynamic=decoder_dynamic)
+        ptr = ptr.to(torch.int64)
+        masks.step(ptr)                                           # model.py:376-386
+        decoder_static = torch.gather(static_part, 2, ptr.view(-1, 1, 1).expand(-1, D, 1))  # model.py:404-406
+        decoder_dynamic = env.add_new_blocks_gather(masks.static, ptr)                      # model.py:451-465
+        tour.append(ptr.unsqueeze(1))
+        if record:
+            feats.append(decoder_dynamic); curs.append(masks.current_mask); msks.append(masks.mask)
+    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -env.calc_ratios(), 'env': env,
+           'dynamic': masks.dynamic, 'mask': masks.mask}
+    if record:
+        out.update(features=feats, current_masks=curs, masks=msks)
+    return out

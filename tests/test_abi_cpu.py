@@ -1,0 +1,102 @@
+"""CPU-only checks of the product's host side: the C-ABI library loads, exports every symbol the
+header declares, parses reward strings like the reference, and refuses to run without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+import tap_net_amd as T
+from tap_net_amd import _lib
+
+REWARDS = ["C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft", "C+P-lb-hard", "C+P+S-mcs-soft",
+           "C+P+S-mcs-hard", "C+P+S-mul-soft", "C+P+S-mul-hard", "C+P-mcs-soft", "C+P-mul-hard",
+           "mcs-soft", "mcs-hard", "comp", "soft", "hard", "pyrm", "pyrm-soft", "pyrm-hard-SUM",
+           "pyrm-soft-sum", "CPS", "C+P+S-SL-soft"]
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    header = open(_lib.HEADER_PATH).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(tap_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libtapenv.so does not export %s" % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.tap_abi_version() == 1
+    assert lib.tap_status_string(-4) == b"placement above container height"
+
+
+@pytest.mark.parametrize("reward", REWARDS)
+@pytest.mark.parametrize("strategy", ["LB_GREEDY", "MACS"])
+def test_desc_matches_reference_string_tests(reward, strategy):
+    d = _lib.make_desc(7, [5, 50], 10, reward, "diff", strategy)
+    o = O.make_desc([5, 50], 10, reward, "diff", strategy)
+    for f in ("D", "W", "L", "H", "n_max", "strategy", "flags", "ratio_mode", "feature"):
+        assert getattr(d, f) == getattr(o, f), (reward, strategy, f)
+    assert d.B == 7
+    d3 = _lib.make_desc(1, [5, 6, 50], 10, reward, "full", strategy)
+    assert (d3.D, d3.W, d3.L, d3.H, d3.feature) == (3, 5, 6, 50, 0)
+
+
+def test_desc_rejects_unknown():
+    with pytest.raises(T.TapError):
+        _lib.make_desc(1, [5, 50], 10, "C+P+S-lb-soft", "diff", "LB")        # legacy strategy: out of scope
+    with pytest.raises(T.TapError):
+        _lib.make_desc(1, [5, 50], 10, "C+P+S-lb-soft", "nope", "LB_GREEDY")
+
+
+def test_state_and_feature_sizes():
+    lib = _lib.lib()
+    d = _lib.make_desc(8192, [5, 50], 10, "C+P+S-lb-soft", "diff", "LB_GREEDY")
+    nbytes = lib.tap_env_state_bytes(C.byref(d))
+    # hm 20 + counters 16 + err 4 + positions 80 + stable 10 bytes per env, sections 256-aligned
+    assert 8192 * 130 <= nbytes <= 8192 * 130 + 5 * 256
+    assert lib.tap_env_feature_len(C.byref(d)) == 4
+    d = _lib.make_desc(4096, [5, 5, 50], 10, "C+P+S-lb-soft", "diff", "LB_GREEDY")
+    assert lib.tap_env_feature_len(C.byref(d)) == 50
+    d = _lib.make_desc(4096, [5, 5, 50], 10, "C+P+S-lb-soft", "zero", "LB_GREEDY")
+    assert lib.tap_env_feature_len(C.byref(d)) == 25
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    with pytest.raises(T.TapError) as ei:
+        T.BatchedContainer(4, [5, 50], 10, "C+P+S-lb-soft", "diff")
+    assert ei.value.status == _lib.TAP_E_NODEVICE
+    with pytest.raises(T.TapError):
+        T.update_dynamic(torch.zeros(2, 30, 20), torch.zeros(2, 3, 20), torch.zeros(2, dtype=torch.long), "bot", True)
+
+
+def test_product_does_not_import_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(_lib.__file__)))
+    pkg = os.path.join(root, "tap-net_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "tap_oracle" not in text and "oracle_lib" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+
+
+def test_packdataset_layout(tmp_path):
+    """PACKDataset rebuilt from the reference's text files gives the reference's tensors."""
+    import golden_util as G
+    for D, N in ((2, 256), (3, 64)):
+        z = G.load("dataset_%dd.npz" % D)
+        d = tmp_path / ("d%d" % D)
+        d.mkdir()
+        for k in ("blocks", "pos", "container", "dep_move", "dep_small", "dep_large"):
+            np.savetxt(str(d / (k + ".txt")), z["txt_" + k], fmt="%d")
+        ds = T.PACKDataset(str(d) + "/", 10, N, 12345, "bot", "diff", True, 5, unit=1)
+        assert np.array_equal(ds.static.numpy(), z["static"].astype(np.float32))
+        assert np.array_equal(ds.dynamic.numpy(), z["dynamic"].astype(np.float32))
+        assert list(ds.decoder_static.shape) == z["decoder_static_shape"].tolist()
+        assert list(ds.decoder_dynamic.shape) == z["decoder_dynamic_shape"].tolist()
+        s, dy, ds_, dd = ds[3]
+        assert s.shape == (1 + D, 10 * (2 if D == 2 else 6)) and dy.shape[0] == 30
+        assert len(ds) == N
