@@ -35,7 +35,7 @@ class EnvDesc(C.Structure):
 
 
 _lib = None
-_lock = threading.Lock()
+_lock = threading.RLock()
 _ctxs = {}
 
 _vp, _i, _sz = C.c_void_p, C.c_int, C.c_size_t

@@ -262,12 +262,16 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
             t /= 3;
             const int Y0 = t % L, z = t / L;
             if (z != vis_z) { vis_z = z; visited = 0; }
+            // NOTE: the settle position is kept as ONE packed integer on purpose.  With separate
+            // x / y variables, hipcc 7.2 (-O3, gfx950) mis-compiled this walk when tap_place was
+            // inlined into k_episode's step loop (both came back 0); the packed form is exact and
+            // the parity tests (tests/test_gpu_parity.py, hard-mode cases) pin it.
             bool ok = false;
-            int sx = 0, sy = 0, sstab = 0, semp = 0;
-            for (int _x = X0; _x + bx <= W && !ok; ++_x)
-                for (int _y = Y0; _y + by <= L && !ok; ++_y) {
+            int spos = 0, sstab = 0, semp = 0;
+            for (int _x = X0; _x + bx <= W; ++_x) {
+                for (int _y = Y0; _y + by <= L; ++_y) {
                     const u64 pbit = 1ull << (_x * L + _y);
-                    if (visited & pbit) continue;                 // :2105
+                    if (ok || (visited & pbit)) continue;             // :2105 (and :2325 once settled)
                     int mx, sum; u64 eq;
                     tap_scan<D>(s, L, _x, _y, bx, by, mx, eq, sum);
                     if (z > 0 && mx < z) continue;                // :2106 nothing underneath
@@ -276,13 +280,15 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
                     if (mx > z) continue;                         // :2109 not free
                     const int st = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d(bx, by, eq));
                     if (!st) continue;                            // :2112-2114 hard rejects
-                    ok = true; sx = _x; sy = _y; sstab = st;
+                    ok = true; spos = _x * 64 + _y; sstab = st;
                     semp = cnt.empty + bx * by * z - sum;
                 }
+                if (ok) break;
+            }
             if (ok) {
                 const double r = tap_score(c, cnt, vol, gmax, z, bz, semp, sstab);
                 if (r > best) { // first maximum in list order
-                    best = r; res.placed = 1; res.x = sx; res.y = sy; res.z = z; res.stab = sstab; emp_w = semp;
+                    best = r; res.placed = 1; res.x = spos >> 6; res.y = spos & 63; res.z = z; res.stab = sstab; emp_w = semp;
                 }
             }
         }
