@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/prof_<tag>*/) into the tracked summaries under profiles/.
+
+    python profiles/summarize.py <tag> <config>      e.g.  r01 c2
+
+Inputs (written on the GPU box by the commands in profiles/README.md):
+    gpurun_out/prof_<tag>/<config>_kernel_stats.csv              rocprofv3 --kernel-trace --stats
+    gpurun_out/prof_<tag>_fetch/<config>_counter_collection.csv  rocprofv3 --kernel-trace --pmc FETCH_SIZE
+    gpurun_out/prof_<tag>_write/<config>_counter_collection.csv  rocprofv3 --kernel-trace --pmc WRITE_SIZE
+Outputs:
+    profiles/<tag>_<config>_kernel_stats.csv   copy of the --stats summary
+    profiles/<tag>_<config>_pmc_summary.csv    per-kernel mean FETCH_SIZE / WRITE_SIZE (KB, raw)
+    profiles/traffic.json                      per-launch HBM bytes used by bench.py's roofline.traffic
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of the bytes read, so bytes = (2*FETCH + WRITE) * 1024.
+(The 2x is confirmed here by k_dyn_colsum, whose compulsory read is the whole dynamic tensor.)
+"""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, cfg = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out")
+shutil.copy(os.path.join(src, "prof_%s" % tag, "%s_kernel_stats.csv" % cfg),
+            os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
+means = collections.defaultdict(dict)
+for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    path = os.path.join(src, "prof_%s_%s" % (tag, kind), "%s_counter_collection.csv" % cfg)
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        means[k][counter] = sum(v) / len(v)
+        means[k]["calls_" + counter] = len(v)
+with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.csv" % (tag, cfg)), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "calls", "FETCH_SIZE_KiB_mean_raw", "WRITE_SIZE_KiB_mean", "HBM_bytes_per_launch=(2*FETCH+WRITE)*1024"])
+    for k, m in sorted(means.items()):
+        fs, ws = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
+        w.writerow([k, m.get("calls_FETCH_SIZE", 0), "%.3f" % fs, "%.3f" % ws, int((2 * fs + ws) * 1024)])
+tpath = os.path.join(ROOT, "profiles", "traffic.json")
+traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+short = {"k_mask_step": "mask_step", "k_env_step": "env_step", "k_transition": "transition"}
+for k, m in means.items():
+    for pat, name in short.items():
+        if pat in k:
+            traffic["%s:%s" % (cfg, name)] = int((2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024)
+traffic["_source"] = "profiles/summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes per launch"
+json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+print(json.dumps(traffic, indent=1))
