@@ -58,7 +58,7 @@ def algorithmic_bytes(D, cs, n):
 class HotPath(object):
     """Pre-allocated buffers + direct C-ABI calls for one rank's share of the batch."""
 
-    def __init__(self, cfg, B, start, device, seed=12345):
+    def __init__(self, cfg, B, start, device, seed=12345, fused=True):
         _, D, cs, n, _, reward, strategy = cfg
         self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
         static, dynamic = synth.rand_instances(B, n, D, seed=seed, start=start)
@@ -81,6 +81,7 @@ class HotPath(object):
         self.lib = _lib.lib()
         self.ctx = _lib.ctx(device)
         self.hook = None                                     # optional per-kernel timing hook
+        self.fused = fused and strategy == "LB_GREEDY"
 
     def _k(self, name, fn, *args):
         stream = _lib.stream_of(self.device)
@@ -90,6 +91,8 @@ class HotPath(object):
             _lib.check(fn(*args, stream), self.ctx)
 
     def episode(self):
+        if self.fused:
+            return self.episode_fused()
         L, P, e = self.lib, _lib.ptr, self.env
         d = C.byref(e.desc)
         self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
@@ -104,6 +107,25 @@ class HotPath(object):
             self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(self.static),
                     self.static.shape[1], self.nR, P(ptr), None, P(self.feat))
         self._k("ratio", L.tap_env_ratio, self.ctx, d, P(e._state), P(self.reward), None, None)
+
+
+def _episode_fused(self):
+    """n launches per pass: tap_transition, first FRESH (no reset launch), last emits calc_ratio."""
+    L, P, e = self.lib, _lib.ptr, self.env
+    d = C.byref(e.desc)
+    dyn_in, cs_in, mask_in = self.dynamic0, self.cs0, self.mask0
+    for t in range(self.n):
+        ptr = self.tape[t]
+        o = t & 1
+        flags = (_lib.TAP_T_FRESH if t == 0 else 0) | (_lib.TAP_T_RATIO if t == self.n - 1 else 0)
+        self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.n, self.R, self.rows, 3,
+                P(dyn_in), P(self.static), self.static.shape[1], P(ptr), P(mask_in), P(cs_in),
+                P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat),
+                P(self.reward), flags)
+        dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
+
+
+HotPath.episode_fused = _episode_fused
 
 
 def time_passes(hp, steps, warmup, use_graph, world):
@@ -233,6 +255,7 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
     args = ap.parse_args()
@@ -249,7 +272,7 @@ def main():
     if args.batch:
         B = args.batch
         cfg = (name, D, cs, n, B, reward, strategy)
-    hp = HotPath(cfg, B, rank * B, dev)
+    hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused)
     use_graph = not args.no_graph
     dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
     hp.env.check()
@@ -260,12 +283,14 @@ def main():
     if rank == 0:
         kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)))
         env_b, mask_b = algorithmic_bytes(D, cs, n)
-        per_launch = {"env_step": env_b * B, "mask_step": mask_b * B}
-        dom = max(("env_step", "mask_step"), key=lambda k: kt[k]["total_us"])
+        per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B}
+        names = [k for k in ("transition", "mask_step", "env_step", "ratio", "reset") if k in kt]
+        dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
         ach = per_launch[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
+        npass = max(3, min(args.steps, 20))
         kernels = {}
-        for k in ("mask_step", "env_step", "ratio", "reset"):
-            kernels[k] = dict(avg_us=round(kt[k]["avg_us"], 3), launches_per_pass=kt[k]["launches"] // max(3, min(args.steps, 20)))
+        for k in names:
+            kernels[k] = dict(avg_us=round(kt[k]["avg_us"], 3), launches_per_pass=kt[k]["launches"] // npass)
             if k in per_launch:
                 kernels[k]["alg_bytes_per_launch"] = per_launch[k]
                 kernels[k]["alg_GBps"] = round(per_launch[k] / (kt[k]["avg_us"] * 1e-6) / 1e9, 2)
@@ -277,11 +302,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy,
-                       "pass": "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
+                       "pass": ("n x tap_transition (update_dynamic+update_mask+gather+add_new_block in one launch; "
+                                "first starts a fresh container, last emits calc_ratio)") if hp.fused else
+                               "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(args.config + ":" + dom),
-                         "alg_bytes_per_env_step": mask_b if dom == "mask_step" else env_b,
+                         "alg_bytes_per_env_step": per_launch[dom] // B,
                          "units_per_launch": B, "avg_launch_us": kt[dom]["avg_us"],
                          "event_pair_overhead_us": empty_us},
             "kernels": kernels,
@@ -291,12 +318,12 @@ def main():
         if args.sweep:
             for b in (8192, 32768, 131072, 524288, 2097152):
                 try:
-                    h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev)
+                    h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev, fused=hp.fused)
                     d2, _ = time_passes(h2, 10, 3, use_graph, 1)
                     k2, _ = kernel_event_times(h2, 3)
-                    print("sweep B=%d: %.3e env-steps/s; env_step %.1f us (%.0f GB/s alg), mask_step %.1f us (%.0f GB/s alg)" % (
-                        b, b * n * 10 / d2, k2["env_step"]["avg_us"], env_b * b / k2["env_step"]["avg_us"] / 1e3,
-                        k2["mask_step"]["avg_us"], mask_b * b / k2["mask_step"]["avg_us"] / 1e3), file=sys.stderr)
+                    print("sweep B=%d: %.3e env-steps/s; " % (b, b * n * 10 / d2) + "; ".join(
+                        "%s %.1f us (%.0f GB/s alg)" % (k, v["avg_us"], per_launch[k] / B * b / v["avg_us"] / 1e3)
+                        for k, v in k2.items() if k in per_launch), file=sys.stderr)
                     del h2
                 except Exception as ex:  # out of memory at the top end is fine
                     print("sweep B=%d failed: %s" % (b, ex), file=sys.stderr)

@@ -181,6 +181,24 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
                   const float *mask_in, const float *colsum_in, float *dyn_out, float *colsum_out,
                   float *current_out, float *mask_out, void *stream);
 
+/* ---- one whole lock-step in one launch --------------------------------------------------- */
+
+enum {
+    TAP_T_FRESH = 1, /* treat the state blob as freshly reset (Container.__init__, model.py:294) */
+    TAP_T_RATIO = 2  /* also emit Container.calc_ratio after the step (model.py:499-510) */
+};
+
+/* Everything DRL.forward does around its policy network for one decoding step (model.py:376-465):
+ * tap_mask_step + tap_env_step_gather fused, so the placement's latency hides under the HBM-bound
+ * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
+ * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
+ * LB_GREEDY only.  feature_out nullable; ratio_out (B,) f32 required with TAP_T_RATIO. */
+int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                   int update_rows, const float *dyn_in, const float *static_, int static_rows,
+                   const int64_t *ptr, const float *mask_in, const float *colsum_in,
+                   float *dyn_out, float *colsum_out, float *current_out, float *mask_out,
+                   float *feature_out, float *ratio_out, int flags, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ TAP_OK = 0
 TAP_E_INVALID, TAP_E_UNSUPPORTED, TAP_E_HIP, TAP_E_OVERFLOW, TAP_E_NODEVICE, TAP_E_STEPS = -1, -2, -3, -4, -5, -6
 TAP_LB_GREEDY, TAP_MACS = 0, 1
 TAP_DT_F32, TAP_DT_I32 = 0, 1
+TAP_T_FRESH, TAP_T_RATIO = 1, 2
 
 
 class TapError(RuntimeError):
@@ -60,6 +61,8 @@ _PROTOS = {
     "tap_dyn_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tap_update_dynamic": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_update_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tap_transition": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
+                            _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tap_mask_step": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 EXPORTS = tuple(_PROTOS)

@@ -127,33 +127,6 @@ extern "C" int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, v
 }
 
 // =============================================================================================
-// device: feature writer (tools.py:3716-3744), shared by step and get_heightmap
-// =============================================================================================
-
-// s = group's LDS slice with the CURRENT height-map (barrier'd); writes this lane's share
-template <int D, int G>
-__device__ __forceinline__ void tap_write_feature(int feature, int W, int L, const int *s, int cell,
-                                                  int hm, float *out /* env's row */)
-{
-    const int cells = W * L;
-    const bool incell = cell < cells;
-    if (feature == TAP_FEAT_DIFF) {
-        if (D == 2) {
-            if (cell < W - 1) out[cell] = (float)(s[cell + 1] - hm);               // :3739-3743
-        } else if (incell) {
-            const int x = cell / L, y = cell - x * L;
-            out[cell] = (float)(x > 0 ? hm - s[cell - L] : 0);                      // :3723-3725
-            out[cells + cell] = (float)(y > 0 ? hm - s[cell - 1] : 0);              // :3728-3730
-        }
-    } else if (feature == TAP_FEAT_ZERO) {
-        const int mn = group_min<G>(incell ? hm : INT_MAX);                         // :3719
-        if (incell) out[cell] = (float)(hm - mn);
-    } else if (incell) {
-        out[cell] = (float)hm;                                                      // :3717
-    }
-}
-
-// =============================================================================================
 // K1/K2: one lock-step placement for B containers
 // =============================================================================================
 
@@ -348,17 +321,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_env_ratio(tap_env_desc d, EnvView
         P = (double)c.x / (double)(c.y + c.x);                    // :3903
         S = (double)c.z / (double)c.w;                            // :3904
     }
-    double r;
-    switch (d.ratio_mode) {                                       // :3919-3964
-    case TAP_R_C: r = C / 3; break;
-    case TAP_R_CxS: r = (C * S) / 3; break;
-    case TAP_R_CP: r = (C + P) / 3; break;
-    case TAP_R_CPxS: r = ((C + P) * S) / 3; break;
-    case TAP_R_2CPS: r = ((2 * C + P) + S) / 3; break;
-    case TAP_R_CxPxS: r = ((C * P) * S) / 3; break;
-    case TAP_R_CP_HALF: r = (C + P) / 2; break;
-    default: r = ((C + P) + S) / 3; break;
-    }
+    const double r = tap_ratio_formula(d.ratio_mode, C, P, S);
     if (r32) r32[env] = (float)r;                                 // model.py:499,510 fp32 store
     if (r64) r64[env] = r;
     if (cps) { cps[(size_t)env * 3] = C; cps[(size_t)env * 3 + 1] = P; cps[(size_t)env * 3 + 2] = S; }
@@ -388,8 +351,9 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_env_export(tap_env_desc d, EnvVie
     const int cells = d.W * d.L, D = d.D, n = d.n_max;
     const size_t B = (size_t)d.B;
     if (hm) for (int i = 0; i < cells; ++i) hm[(size_t)env * cells + i] = v.hm[(size_t)env * cells + i];
-    if (pos) for (int t = 0; t < n * D; ++t) pos[(size_t)env * n * D + t] = v.pos[(size_t)t * B + env];
-    if (st) for (int t = 0; t < n; ++t) st[(size_t)env * n + t] = v.stable[(size_t)t * B + env];
+    const int done = v.cnt[(size_t)env * 4 + 3]; // steps taken; later rows may hold a previous episode
+    if (pos) for (int t = 0; t < n * D; ++t) pos[(size_t)env * n * D + t] = (t / D < done) ? v.pos[(size_t)t * B + env] : 0;
+    if (st) for (int t = 0; t < n; ++t) st[(size_t)env * n + t] = (t < done) ? v.stable[(size_t)t * B + env] : 0;
     if (cnt) for (int k = 0; k < 4; ++k) cnt[(size_t)env * 4 + k] = v.cnt[(size_t)env * 4 + k];
 }
 

@@ -8,6 +8,7 @@
 // updated incrementally (sum_new = sum_old - zeroed row), so the slab is never reduced again
 // after tap_dyn_colsum built the shadow once.
 #include "tap_common.h"
+#include "tap_masks.h"
 
 constexpr int WAVE = 64;
 constexpr int ENVS_PER_BLOCK = TAP_BLOCK / WAVE;
@@ -30,32 +31,6 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_colsum(int B, int n, int nR, 
     }
 }
 
-struct MaskArgs {
-    int B, n, R, nR, rows, update_rows, static_rows;
-    const float *dyn_in;
-    float *dyn_out;
-    const float *static_;
-    const int64_t *ptr;
-    const float *mask_in;
-    const float *cs_in;
-    float *cs_out;
-    float *cur_out;
-    float *mask_out;
-};
-
-// mask math for one column: pack.py:318-329
-__device__ __forceinline__ void mask_column(const MaskArgs &a, int env, int j, long real_m,
-                                            float move, float small, float large)
-{
-    float keep = a.mask_in ? a.mask_in[(size_t)env * a.nR + j] : 1.f;
-    if (a.ptr)
-        for (int r = 0; r < a.R; ++r)
-            if (j == real_m + (long)a.n * r) keep = 0.f;            // :320-321
-    if (a.mask_out) a.mask_out[(size_t)env * a.nR + j] = keep;    // chosen_mask
-    const float dm = small * large + move;                        // :327-328
-    if (a.cur_out) a.cur_out[(size_t)env * a.nR + j] = dm != 0.f ? 0.f : keep; // :329
-}
-
 // ---- fused step: copy-with-zeroed-rows + incremental column sums + both masks ----------------
 template <int VEC>
 __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
@@ -63,21 +38,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     const int env = blockIdx.x * ENVS_PER_BLOCK + threadIdx.x / WAVE;
     const int lane = threadIdx.x % WAVE;
     if (env >= a.B) return;
-    const int nR = a.nR, rows = a.rows;
-    const size_t slab = (size_t)rows * nR;
+    const int nR = a.nR;
+    const size_t slab = (size_t)a.rows * nR;
     const long p = a.ptr ? (long)a.ptr[env] : 0;
     // pack.py:339: block id read from row 0 of `static` as float -> long
     const long real = (a.ptr && a.static_) ? (long)a.static_[(size_t)env * a.static_rows * nR + p] : -1;
 
     if (a.dyn_out) {
-        // flat ranges [lo_i, hi_i) of the rows to clear (pack.py:372-374)
-        long lo[3], hi[3];
-        for (int i = 0; i < 3; ++i) {
-            const long r = real + (long)a.n * i;
-            const bool on = i < a.update_rows && real >= 0 && r < rows;
-            lo[i] = on ? r * nR : -1;
-            hi[i] = on ? (r + 1) * nR : -1;
-        }
+        const ClearRanges cr = clear_ranges(a, real);
         const float *src = a.dyn_in + (size_t)env * slab;
         float *dst = a.dyn_out + (size_t)env * slab;
         if (VEC == 4) {
@@ -87,36 +55,19 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
 #pragma unroll 4
             for (int q = lane; q < nchunk; q += WAVE) {
                 float4 v = s4[q];
-                const long f = (long)q * 4; // nR % 4 == 0: a chunk never straddles two rows
-                if ((f >= lo[0] && f < hi[0]) || (f >= lo[1] && f < hi[1]) || (f >= lo[2] && f < hi[2]))
-                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+                // nR % 4 == 0: a chunk never straddles two rows
+                if (in_cleared(cr, (long)q * 4)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                 d4[q] = v;
             }
         } else {
             for (long f = lane; f < (long)slab; f += WAVE) {
                 float v = src[f];
-                if ((f >= lo[0] && f < hi[0]) || (f >= lo[1] && f < hi[1]) || (f >= lo[2] && f < hi[2])) v = 0.f;
+                if (in_cleared(cr, f)) v = 0.f;
                 dst[f] = v;
             }
         }
     }
-
-    if (a.cs_out || a.cur_out || a.mask_out) {
-        long real_m = p;
-        while (real_m >= a.n) real_m -= a.n;                      // pack.py:314-316
-        for (int j = lane; j < nR; j += WAVE) {
-            float sum[3];
-            for (int s = 0; s < 3; ++s) {
-                float v = a.cs_in[((size_t)env * 3 + s) * nR + j];
-                const long r = real + (long)a.n * s;
-                if (a.dyn_out && s < a.update_rows && real >= 0 && r < rows)
-                    v -= a.dyn_in[(size_t)env * slab + (size_t)r * nR + j]; // the row being cleared
-                sum[s] = v;
-                if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + j] = v;
-            }
-            mask_column(a, env, j, real_m, sum[0], sum[1], sum[2]);
-        }
-    }
+    if (a.cs_out || a.cur_out || a.mask_out) mask_env(a, env, lane, real, p);
 }
 
 static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)

@@ -309,3 +309,53 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
     }
     return res;
 }
+
+// ---- feature writer (tools.py:3716-3744), shared by step, transition and get_heightmap ----------
+
+// s = group's LDS slice with the CURRENT height-map (barrier'd); writes this lane's share
+template <int D, int G>
+__device__ __forceinline__ void tap_write_feature(int feature, int W, int L, const int *s, int cell,
+                                                  int hm, float *out /* env's row */)
+{
+    const int cells = W * L;
+    const bool incell = cell < cells;
+    if (feature == TAP_FEAT_DIFF) {
+        if (D == 2) {
+            if (cell < W - 1) out[cell] = (float)(s[cell + 1] - hm);               // :3739-3743
+        } else if (incell) {
+            const int x = cell / L, y = cell - x * L;
+            out[cell] = (float)(x > 0 ? hm - s[cell - L] : 0);                      // :3723-3725
+            out[cells + cell] = (float)(y > 0 ? hm - s[cell - 1] : 0);              // :3728-3730
+        }
+    } else if (feature == TAP_FEAT_ZERO) {
+        const int mn = group_min<G>(incell ? hm : INT_MAX);                         // :3719
+        if (incell) out[cell] = (float)(hm - mn);
+    } else if (incell) {
+        out[cell] = (float)hm;                                                      // :3717
+    }
+}
+
+
+// Container.calc_ratio's formula table (tools.py:3919-3964)
+__device__ __forceinline__ double tap_ratio_formula(int mode, double C, double P, double S)
+{
+    switch (mode) {
+    case TAP_R_C: return C / 3;
+    case TAP_R_CxS: return (C * S) / 3;
+    case TAP_R_CP: return (C + P) / 3;
+    case TAP_R_CPxS: return ((C + P) * S) / 3;
+    case TAP_R_2CPS: return ((2 * C + P) + S) / 3;
+    case TAP_R_CxPxS: return ((C * P) * S) / 3;
+    case TAP_R_CP_HALF: return (C + P) / 2;
+    default: return ((C + P) + S) / 3;
+    }
+}
+
+// LDS hand-off between lanes of ONE wavefront (a lane group never spans waves): the LDS unit
+// executes a wave's DS instructions in order, so only the compiler must be kept from reordering.
+__device__ __forceinline__ void tap_wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}

@@ -163,6 +163,40 @@ class MaskStepper(object):
         return out, cur, new
 
 
+class EnvTransition(MaskStepper):
+    """One launch per decoding step: update_dynamic + update_mask + gather + add_new_block
+    (tap_transition), optionally starting from a fresh container and optionally emitting
+    calc_ratio.  LB_GREEDY only; MACS/MUL callers use MaskStepper + BatchedContainer."""
+
+    def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True):
+        super(EnvTransition, self).__init__(static, dynamic, input_type, allow_rot)
+        self.env = env
+        if env.batch_size != self.B or env.block_dim != self.block_dim:
+            raise ValueError("container batch / dimension does not match the instance tensors")
+
+    def step(self, ptr, fresh=False, want_ratio=False, want_feature=True, dyn_out=None):
+        """-> (new_dynamic, current_mask, mask, feature, ratio)."""
+        import ctypes as C
+        ptr = ptr.to(torch.int64).contiguous()
+        out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
+        cs = torch.empty_like(self.colsum)
+        cur = torch.empty_like(self.mask)
+        new = torch.empty_like(self.mask)
+        feat = self.env._new_feature() if want_feature else None
+        ratio = torch.empty(self.B, dtype=torch.float32, device=out.device) if want_ratio else None
+        flags = (_lib.TAP_T_FRESH if fresh else 0) | (_lib.TAP_T_RATIO if want_ratio else 0)
+        c = _lib.ctx(out.device)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib().tap_transition(
+                c, C.byref(self.env.desc), _lib.ptr(self.env._state), self.n, self.R, self.rows,
+                self.update_rows, _lib.ptr(self.dynamic), _lib.ptr(self.static), self.static.shape[1],
+                _lib.ptr(ptr), _lib.ptr(self.mask), _lib.ptr(self.colsum), _lib.ptr(out), _lib.ptr(cs),
+                _lib.ptr(cur), _lib.ptr(new), _lib.ptr(feat), _lib.ptr(ratio), flags,
+                _lib.stream_of(out.device)), c)
+        self.dynamic, self.colsum, self.current_mask, self.mask = out, cs, cur, new
+        return out, cur, new, feat, ratio
+
+
 def reward(static, tour_indices, reward_type, input_type, allow_rot, container_width, container_height,
            packing_strategy='LB_GREEDY'):
     """pack.reward (pack.py:378-473): pack every env's blocks in tour order from an empty

@@ -5,10 +5,13 @@ The reference interleaves its pointer network with a per-env Python loop and two
 copies per step (model.py:407-465).  Here a step is two kernel launches on the current stream
 (precedence update, placement) and nothing leaves the device until the caller asks.
 """
+import math
+
 import torch
 
+from . import _lib
 from .env import BatchedContainer
-from .pack import MaskStepper
+from .pack import EnvTransition, MaskStepper
 
 
 class TapePolicy(object):
@@ -33,39 +36,54 @@ class RandomFeasiblePolicy(object):
 
 def run_episode(static, dynamic, policy, container_width, container_height,
                 reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
-                input_type='bot', allow_rot=True, env=None, record=False, steps=None):
+                input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True):
     """One episode for a batch (model.py:254-515 minus the network).
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
-    returns ptr (B,) int64.  Returns a dict: tour_idx (B, steps), reward = -scores (B,) fp32
+    returns ptr (B,) int64.  With ``fused`` (LB_GREEDY) every step is ONE launch (tap_transition),
+    the first one starting from a fresh container and the last one emitting calc_ratio; otherwise
+    a step is two launches (tap_mask_step, tap_env_step_gather).  Returns a dict: tour_idx (B, steps), reward = -scores (B,) fp32
     (model.py:515), env, and with ``record`` the per-step features / masks.
     """
     if input_type in ('mul', 'mul-with'):
         raise NotImplementedError("two-container input types are not implemented in rollout")
-    masks = MaskStepper(static, dynamic, input_type, allow_rot)
-    B, n, D = masks.B, masks.n, masks.block_dim
+    block_dim = int(static.shape[1]) - 1
+    n = int(dynamic.shape[-1]) // (math.factorial(block_dim) if allow_rot else 1)
+    B, D = int(static.shape[0]), block_dim
     cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    dev = _lib.resolve_device(static.device)
     if env is None:
-        env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy,
-                               device=masks.static.device)
+        env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
+    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY
+    if fused:
+        masks = EnvTransition(static.to(dev), dynamic.to(dev), env, input_type, allow_rot)
     else:
+        masks = MaskStepper(static.to(dev), dynamic.to(dev), input_type, allow_rot)
         env.reset()
     static_part = masks.static[:, 1:, :]
-    decoder_static = torch.zeros(B, D, 1, device=masks.static.device)
-    decoder_dynamic = torch.zeros(env._feature_shape(), device=masks.static.device)
+    decoder_static = torch.zeros(B, D, 1, device=dev)
+    decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
+    nsteps = n if steps is None else steps
     tour, feats, curs, msks = [], [], [], []
-    for step in range(n if steps is None else steps):
+    ratio = None
+    for step in range(nsteps):
         ptr = policy(step=step, static=masks.static, dynamic=masks.dynamic,
                      current_mask=masks.current_mask, mask=masks.mask,
                      decoder_static=decoder_static, decoder_dynamic=decoder_dynamic)
         ptr = ptr.to(torch.int64)
-        masks.step(ptr)                                           # model.py:376-386
         decoder_static = torch.gather(static_part, 2, ptr.view(-1, 1, 1).expand(-1, D, 1))  # model.py:404-406
-        decoder_dynamic = env.add_new_blocks_gather(masks.static, ptr)                      # model.py:451-465
+        if fused:                                                 # model.py:376-386 + 451-465, one launch
+            _, _, _, decoder_dynamic, r = masks.step(ptr, fresh=(step == 0), want_ratio=(step == nsteps - 1))
+            ratio = r if r is not None else ratio
+        else:
+            masks.step(ptr)                                       # model.py:376-386
+            decoder_dynamic = env.add_new_blocks_gather(masks.static, ptr)                  # model.py:451-465
         tour.append(ptr.unsqueeze(1))
         if record:
             feats.append(decoder_dynamic); curs.append(masks.current_mask); msks.append(masks.mask)
-    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -env.calc_ratios(), 'env': env,
+    if ratio is None:
+        ratio = env.calc_ratios()                                 # model.py:499-510
+    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -ratio, 'env': env,
            'dynamic': masks.dynamic, 'mask': masks.mask}
     if record:
         out.update(features=feats, current_masks=curs, masks=msks)
