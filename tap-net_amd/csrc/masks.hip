@@ -32,39 +32,35 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_colsum(int B, int n, int nR, 
 }
 
 // ---- fused step: copy-with-zeroed-rows + incremental column sums + both masks ----------------
-template <int VEC>
+// FAST = stream_wave_fast (nR % 4 == 0, nR <= 64, aligned, full update); otherwise the generic
+// element-wise path, which also serves tap_update_mask (no copy) and tap_update_dynamic without a
+// shadow.
+template <bool FAST>
 __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
 {
-    const int env = blockIdx.x * ENVS_PER_BLOCK + threadIdx.x / WAVE;
+    extern __shared__ float mask_lds[];
+    const int wave = threadIdx.x / WAVE;
+    const int env = blockIdx.x * ENVS_PER_BLOCK + wave;
     const int lane = threadIdx.x % WAVE;
     if (env >= a.B) return;
+    if (FAST) {
+        const bool on[1] = {true};
+        stream_wave_fast<1, 6>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
+        return;
+    }
     const int nR = a.nR;
     const size_t slab = (size_t)a.rows * nR;
     const long p = a.ptr ? (long)a.ptr[env] : 0;
     // pack.py:339: block id read from row 0 of `static` as float -> long
     const long real = (a.ptr && a.static_) ? (long)a.static_[(size_t)env * a.static_rows * nR + p] : -1;
-
     if (a.dyn_out) {
         const ClearRanges cr = clear_ranges(a, real);
         const float *src = a.dyn_in + (size_t)env * slab;
         float *dst = a.dyn_out + (size_t)env * slab;
-        if (VEC == 4) {
-            const int nchunk = (int)(slab / 4);
-            const float4 *s4 = reinterpret_cast<const float4 *>(src);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
-#pragma unroll 4
-            for (int q = lane; q < nchunk; q += WAVE) {
-                float4 v = s4[q];
-                // nR % 4 == 0: a chunk never straddles two rows
-                if (in_cleared(cr, (long)q * 4)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                d4[q] = v;
-            }
-        } else {
-            for (long f = lane; f < (long)slab; f += WAVE) {
-                float v = src[f];
-                if (in_cleared(cr, f)) v = 0.f;
-                dst[f] = v;
-            }
+        for (long f = lane; f < (long)slab; f += WAVE) {
+            float v = src[f];
+            if (in_cleared(cr, (int)f)) v = 0.f;
+            dst[f] = v;
         }
     }
     if (a.cs_out || a.cur_out || a.mask_out) mask_env(a, env, lane, real, p);
@@ -74,10 +70,12 @@ static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)
 {
     const int grid = (a.B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
-    const bool vec = (a.nR % 4 == 0) && a.dyn_out &&
-                     ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
-    if (vec) hipLaunchKernelGGL(k_mask_step<4>, dim3(grid), dim3(TAP_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL(k_mask_step<1>, dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    if (mask_fast_path_ok(a)) {
+        const size_t lds = (size_t)ENVS_PER_BLOCK * 3 * a.nR * sizeof(float);
+        hipLaunchKernelGGL(k_mask_step<true>, dim3(grid), dim3(TAP_BLOCK), lds, st, a);
+    } else {
+        hipLaunchKernelGGL(k_mask_step<false>, dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    }
     TAP_LAUNCH_CHECK(ctx, "k_mask_step");
     return TAP_OK;
 }

@@ -34,7 +34,7 @@ __device__ __forceinline__ void mask_column(const MaskArgs &a, int env, int j, l
 
 // flat float ranges [lo_i, hi_i) of the rows update_dynamic clears for one env (pack.py:372-374)
 struct ClearRanges {
-    long lo[3], hi[3];
+    int lo[3], hi[3]; // a slab has < 2^31 floats
 };
 
 __device__ __forceinline__ ClearRanges clear_ranges(const MaskArgs &a, long real)
@@ -43,13 +43,13 @@ __device__ __forceinline__ ClearRanges clear_ranges(const MaskArgs &a, long real
     for (int i = 0; i < 3; ++i) {
         const long r = real + (long)a.n * i;
         const bool on = i < a.update_rows && real >= 0 && r < a.rows;
-        c.lo[i] = on ? r * a.nR : -1;
-        c.hi[i] = on ? (r + 1) * a.nR : -1;
+        c.lo[i] = on ? (int)(r * a.nR) : -1;
+        c.hi[i] = on ? (int)((r + 1) * a.nR) : -1;
     }
     return c;
 }
 
-__device__ __forceinline__ bool in_cleared(const ClearRanges &c, long f)
+__device__ __forceinline__ bool in_cleared(const ClearRanges &c, int f)
 {
     return (f >= c.lo[0] && f < c.hi[0]) || (f >= c.lo[1] && f < c.hi[1]) || (f >= c.lo[2] && f < c.hi[2]);
 }
@@ -62,15 +62,120 @@ __device__ __forceinline__ void mask_env(const MaskArgs &a, int env, int lane, l
     long real_m = p;
     while (real_m >= a.n) real_m -= a.n;                          // pack.py:314-316
     for (int j = lane; j < nR; j += 64) {
-        float sum[3];
-        for (int s = 0; s < 3; ++s) {
-            float v = a.cs_in[((size_t)env * 3 + s) * nR + j];
+        float sum[3], row[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {                             // issue all six loads first
+            sum[s] = a.cs_in[((size_t)env * 3 + s) * nR + j];
             const long r = real + (long)a.n * s;
-            if (a.dyn_out && s < a.update_rows && real >= 0 && r < a.rows)
-                v -= a.dyn_in[(size_t)env * slab + (size_t)r * nR + j]; // the row being cleared
-            sum[s] = v;
-            if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + j] = v;
+            row[s] = (a.dyn_out && s < a.update_rows && real >= 0 && r < a.rows)
+                         ? a.dyn_in[(size_t)env * slab + (size_t)r * nR + j] : 0.f; // the row being cleared
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            sum[s] -= row[s];
+            if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + j] = sum[s];
         }
         mask_column(a, env, j, real_m, sum[0], sum[1], sum[2]);
     }
+}
+
+// ---- fast path of one "stream wave" ----------------------------------------------------------
+// Copies NS consecutive env slabs (contiguous in memory) out of place with the chosen rows cleared
+// (pack.py:370-374), updates the column-sum shadow and writes both masks (pack.py:318-329), with a
+// SINGLE memory round trip before the stores:
+//   * every small input (ptr, row 0 of static, old column sums, old mask) is loaded up front, next
+//     to the first batch of slab loads; the block id `real = static[b,0,ptr]` (pack.py:339) is
+//     picked out of the row-0 registers with a wave shuffle instead of a dependent load;
+//   * slab loads are unconditional (clamped index) and issued U per lane before any store, so the
+//     compiler can count them (no vmcnt(0) stalls) and a wave has U KiB in flight;
+//   * the rows being cleared are captured into a wave-private LDS tile on their way through the
+//     registers, so "new sum = old sum - cleared row" needs no second read of the slab.
+// Requirements (checked by the caller): nR % 4 == 0, 16-byte aligned tensors, nR <= 64.
+// lds: NS * 3 * nR floats private to this wave.
+template <int NS, int U>
+__device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, int lane,
+                                                 const bool (&on)[NS], float *lds)
+{
+    const int nR = a.nR;
+    const size_t slab = (size_t)a.rows * nR;
+    const int nchunk = (int)(slab / 4);
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) if (on[k]) total = (k + 1) * nchunk; // on[] is a prefix
+    if (total == 0) return;
+    const bool col = lane < nR;
+    long p[NS];
+    float row0[NS], cs[NS][3], keep[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int env = senv0 + k;
+        const bool ok = on[k];
+        p[k] = ok ? (long)a.ptr[env] : 0;
+        row0[k] = (ok && col) ? a.static_[(size_t)env * a.static_rows * nR + lane] : 0.f;
+        keep[k] = (ok && col) ? (a.mask_in ? a.mask_in[(size_t)env * nR + lane] : 1.f) : 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) cs[k][s] = (ok && col) ? a.cs_in[((size_t)env * 3 + s) * nR + lane] : 0.f;
+    }
+    for (int i = lane; i < NS * 3 * nR; i += 64) lds[i] = 0.f;
+
+    const float4 *s4 = reinterpret_cast<const float4 *>(a.dyn_in + (size_t)senv0 * slab);
+    float4 *d4 = reinterpret_cast<float4 *>(a.dyn_out + (size_t)senv0 * slab);
+    ClearRanges cr[NS];
+    bool have_real = false;
+    for (int base = 0; base < total; base += 64 * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = s4[min(base + u * 64 + lane, total - 1)];
+        if (!have_real) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const long real = (long)__shfl(row0[k], (int)(p[k] & 63));    // pack.py:339
+                cr[k] = clear_ranges(a, on[k] ? real : -1);
+            }
+            have_real = true;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = base + u * 64 + lane;
+            if (q < total) {
+                const int k = (NS > 1 && q >= nchunk) ? 1 : 0;                // NS <= 2
+                const int f = (q - k * nchunk) * 4;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (f >= cr[k].lo[s] && f < cr[k].hi[s]) {
+                        *reinterpret_cast<float4 *>(lds + (k * 3 + s) * nR + (f - cr[k].lo[s])) = v[u];
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                d4[q] = v[u];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (!(on[k] && col)) continue;
+        const int env = senv0 + k;
+        long real_m = p[k];
+        while (real_m >= a.n) real_m -= a.n;                                  // pack.py:314-316
+        float sum[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            sum[s] = cs[k][s] - lds[(k * 3 + s) * nR + lane];
+            if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + lane] = sum[s];
+        }
+        float kp = keep[k];
+        for (int r = 0; r < a.R; ++r)
+            if (lane == real_m + (long)a.n * r) kp = 0.f;                     // pack.py:320-321
+        if (a.mask_out) a.mask_out[(size_t)env * nR + lane] = kp;
+        const float dm = sum[1] * sum[2] + sum[0];                            // pack.py:327-328
+        if (a.cur_out) a.cur_out[(size_t)env * nR + lane] = dm != 0.f ? 0.f : kp; // pack.py:329
+    }
+}
+
+inline bool mask_fast_path_ok(const MaskArgs &a)
+{
+    return a.dyn_out && a.ptr && a.static_ && a.cs_in && (a.nR % 4 == 0) && a.nR <= 64 && a.rows >= 1 &&
+           ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
 }

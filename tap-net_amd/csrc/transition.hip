@@ -6,11 +6,16 @@
 // Why fuse: at the BASELINE batch sizes the placement moves ~0.9 MB per launch and is pure latency
 // (two dependent loads, fp64 divides), while the precedence update streams ~40 MB and is HBM-bound.
 // In one launch the placement's latency hides under the stream and a kernel boundary per step
-// disappears.  A 256-thread workgroup owns EPB = 8 consecutive envs (4 when an env needs 64 lanes):
-// every wave streams EPB/4 of their dynamic slabs with 16-byte accesses, and the first EPB*G/64
-// waves also carry the lane-per-cell placement groups.  Env lanes issue their loads first, then the
-// wave streams, then the placement computes on data that has long arrived.  No s_barrier anywhere:
-// lane groups never span a wave, so LDS hand-offs only need compiler ordering.
+// disappears.  A workgroup owns EPB = 8 consecutive envs (4 when an env needs 64 lanes) and is made
+// of two kinds of waves: 4 stream waves, each copying EPB/4 dynamic slabs with 16-byte accesses
+// (the slabs' loads interleaved so all are in flight together) and then updating their column sums
+// and masks, and EPB*G/64 placement waves carrying the
+// lane-per-cell groups (at raised priority, so their short dependent chain issues promptly).  The
+// two kinds never exchange data, so there is no s_barrier: lane groups never span a wave and LDS
+// hand-offs only need compiler ordering.  (A first version that let the same waves stream and then
+// place showed no gain: every workgroup was in the same phase at the same time.)
+#include <cstdlib>
+
 #include "tap_common.h"
 #include "tap_masks.h"
 #include "tap_place.h"
@@ -22,23 +27,65 @@ struct TransArgs {
     float *ratio_out;
 };
 
-template <int D, int G, int VEC>
-__global__ void __launch_bounds__(TAP_BLOCK) k_transition(TransArgs a)
+template <int G, int SW> struct TransGeom {
+    static constexpr int EPB = (G == 64) ? 4 : 8;   // envs per workgroup
+    static constexpr int ENV_WAVES = EPB * G / 64;  // waves made of placement lane groups
+    static constexpr int STREAM_WAVES = (SW < EPB) ? SW : EPB; // waves that stream the dynamic slabs
+    static constexpr int SPW = EPB / STREAM_WAVES;  // slabs per stream wave
+    static constexpr int THREADS = 64 * (ENV_WAVES + STREAM_WAVES);
+};
+
+template <int D, int G, bool FAST, int SW>
+__global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TransArgs a)
 {
-    constexpr int EPB = (G == 64) ? 4 : 8;      // envs per workgroup
-    constexpr int SPW = EPB / 4;                // slabs per wave
-    constexpr int ENV_WAVES = EPB * G / 64;     // waves that carry placement lanes
-    __shared__ int s_old[TAP_BLOCK];
-    __shared__ int s_new[TAP_BLOCK];
+    using Geo = TransGeom<G, SW>;
+    constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
+    extern __shared__ float trans_lds[];
+    __shared__ int s_old[64 * ENV_WAVES];
+    __shared__ int s_new[64 * ENV_WAVES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
-    const int B = a.s.d.B, W = a.s.d.W, L = a.s.d.L, cells = W * L;
-    const bool fresh = a.flags & TAP_T_FRESH;
+    const int B = a.s.d.B;
 
-    // ---- placement lanes: issue the loads ------------------------------------------------------
-    const int grp = tid / G, cell = tid % G;
-    const int env = env_base + grp;
-    const bool ev = (wave < ENV_WAVES) && env < B, incell = cell < cells;
+    if (wave >= ENV_WAVES) {
+        // ---- stream waves: out-of-place copy of their slabs with the chosen rows cleared
+        //      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
+        const int sw = wave - ENV_WAVES;
+        const int senv0 = env_base + sw * SPW;
+        bool on[SPW];
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < B;
+        if (FAST) {
+            stream_wave_fast<SPW, 6>(a.m, senv0, lane, on, trans_lds + (size_t)sw * SPW * 3 * a.m.nR);
+        } else {
+            const size_t slab = (size_t)a.m.rows * a.m.nR;
+#pragma unroll
+            for (int k = 0; k < SPW; ++k) {
+                if (!on[k]) continue;
+                const int senv = senv0 + k;
+                const long p = (long)a.m.ptr[senv];
+                const long real = (long)a.m.static_[(size_t)senv * a.m.static_rows * a.m.nR + p]; // pack.py:339
+                const ClearRanges cr = clear_ranges(a.m, real);
+                const float *src = a.m.dyn_in + (size_t)senv * slab;
+                float *dst = a.m.dyn_out + (size_t)senv * slab;
+                for (long f = lane; f < (long)slab; f += 64) {
+                    float v = src[f];
+                    if (in_cleared(cr, (int)f)) v = 0.f;
+                    dst[f] = v;
+                }
+                mask_env(a.m, senv, lane, real, p);
+            }
+        }
+        return;
+    }
+
+    // ---- placement waves (tools.py:3663-3744): their latency chain runs beside the stream --------
+    __builtin_amdgcn_s_setprio(2);
+    const int W = a.s.d.W, L = a.s.d.L, cells = W * L;
+    const bool fresh = a.flags & TAP_T_FRESH;
+    const int cell = tid % G;
+    const int env = env_base + tid / G;
+    const bool ev = env < B, incell = cell < cells;
     int hm = 0, cv = 0, dims[3] = {1, 1, 1};
     if (ev) {
         if (!fresh) {
@@ -49,107 +96,82 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_transition(TransArgs a)
         for (int k = 0; k < D; ++k) // model.py:404-412
             dims[k] = (int)a.s.static_[((size_t)env * a.s.static_rows + 1 + k) * a.s.nR + p];
     }
-
-    // ---- every wave: stream its slabs (pack.py:370-374) -------------------------------------------
-    const size_t slab = (size_t)a.m.rows * a.m.nR;
-    long real[SPW], pp[SPW];
-#pragma unroll
-    for (int k = 0; k < SPW; ++k) {
-        const int senv = env_base + wave * SPW + k;
-        real[k] = -1; pp[k] = 0;
-        if (senv >= B) continue;
-        pp[k] = (long)a.m.ptr[senv];
-        real[k] = (long)a.m.static_[(size_t)senv * a.m.static_rows * a.m.nR + pp[k]]; // pack.py:339
-        const ClearRanges cr = clear_ranges(a.m, real[k]);
-        const float *src = a.m.dyn_in + (size_t)senv * slab;
-        float *dst = a.m.dyn_out + (size_t)senv * slab;
-        if (VEC == 4) {
-            const int nchunk = (int)(slab / 4);
-            const float4 *s4 = reinterpret_cast<const float4 *>(src);
-            float4 *d4 = reinterpret_cast<float4 *>(dst);
-#pragma unroll 8
-            for (int q = lane; q < nchunk; q += 64) {
-                float4 v = s4[q];
-                if (in_cleared(cr, (long)q * 4)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                d4[q] = v;
+    const int gl0 = lane - cell;
+    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
+    const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
+    int err = 0;
+    bool do_step = ev;
+    if (ev && cnt.count >= a.s.d.n_max) { err |= 2; do_step = false; }
+    if (ev && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
+    s_old[tid] = hm;
+    tap_wave_lds_sync();
+    const PlaceCfg cfg = {W, L, a.s.d.H, a.s.d.flags};
+    const int step = cnt.count;
+    const Placement pl = tap_place<D, G>(cfg, s_old + (tid - cell), cell, hm, cnt, err, bx, by, bz, do_step);
+    err = group_or<G>(err);
+    s_new[tid] = hm;
+    tap_wave_lds_sync();
+    const int gmax = (a.flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
+    if (ev) {
+        if (incell) a.s.v.hm[(size_t)env * cells + cell] = hm;
+        if (a.s.feature_out)
+            tap_write_feature<D, G>(a.s.d.feature, W, L, s_new + (tid - cell), cell, hm,
+                                    a.s.feature_out + (size_t)env * a.s.flen);
+        if (cell == 0) {
+            if (do_step || fresh)
+                reinterpret_cast<int4 *>(a.s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+            if (do_step) {
+                int32_t *q = a.s.v.pos + (size_t)step * D * B + env;
+                q[0] = pl.x;
+                if (D == 3) { q[B] = pl.y; q[2 * (size_t)B] = pl.z; } else q[B] = pl.z;
+                a.s.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
             }
-        } else {
-            for (long f = lane; f < (long)slab; f += 64) {
-                float v = src[f];
-                if (in_cleared(cr, f)) v = 0.f;
-                dst[f] = v;
+            if (fresh) a.s.v.err[env] = err;
+            else if (err) a.s.v.err[env] |= err;
+            if (a.flags & TAP_T_RATIO) { // tools.py:3887-3966 on the state just written
+                double C = 0.0, P = 0.0, S = 0.0;
+                if (cnt.count != 0) {
+                    C = (double)cnt.valid / (double)((long long)W * L * gmax);
+                    P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
+                    S = (double)cnt.nstable / (double)cnt.count;
+                }
+                a.ratio_out[env] = (float)tap_ratio_formula(a.s.d.ratio_mode, C, P, S);
             }
         }
+    } else if (a.s.d.feature == TAP_FEAT_ZERO) {
+        (void)group_min<G>(INT_MAX);
     }
+}
 
-    // ---- placement (tools.py:3663-3744) -----------------------------------------------------------
-    if (wave < ENV_WAVES) { // wave-uniform
-        const int gl0 = lane - cell;
-        Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
-        const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
-        int err = 0;
-        bool do_step = ev;
-        if (ev && cnt.count >= a.s.d.n_max) { err |= 2; do_step = false; }
-        if (ev && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
-        s_old[tid] = hm;
-        tap_wave_lds_sync();
-        const PlaceCfg cfg = {W, L, a.s.d.H, a.s.d.flags};
-        const int step = cnt.count;
-        const Placement pl = tap_place<D, G>(cfg, s_old + (tid - cell), cell, hm, cnt, err, bx, by, bz, do_step);
-        err = group_or<G>(err);
-        s_new[tid] = hm;
-        tap_wave_lds_sync();
-        const int gmax = (a.flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
-        if (ev) {
-            if (incell) a.s.v.hm[(size_t)env * cells + cell] = hm;
-            if (a.s.feature_out)
-                tap_write_feature<D, G>(a.s.d.feature, W, L, s_new + (tid - cell), cell, hm,
-                                        a.s.feature_out + (size_t)env * a.s.flen);
-            if (cell == 0) {
-                if (do_step || fresh)
-                    reinterpret_cast<int4 *>(a.s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
-                if (do_step) {
-                    int32_t *q = a.s.v.pos + (size_t)step * D * B + env;
-                    q[0] = pl.x;
-                    if (D == 3) { q[B] = pl.y; q[2 * (size_t)B] = pl.z; } else q[B] = pl.z;
-                    a.s.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
-                }
-                if (fresh) a.s.v.err[env] = err;
-                else if (err) a.s.v.err[env] |= err;
-                if (a.flags & TAP_T_RATIO) { // tools.py:3887-3966 on the state just written
-                    double C = 0.0, P = 0.0, S = 0.0;
-                    if (cnt.count != 0) {
-                        C = (double)cnt.valid / (double)((long long)W * L * gmax);
-                        P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
-                        S = (double)cnt.nstable / (double)cnt.count;
-                    }
-                    a.ratio_out[env] = (float)tap_ratio_formula(a.s.d.ratio_mode, C, P, S);
-                }
-            }
-        } else if (a.s.d.feature == TAP_FEAT_ZERO) {
-            (void)group_min<G>(INT_MAX);
-        }
+template <int D, int G, int SW>
+static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
+{
+    constexpr int EPB = TransGeom<G, SW>::EPB, THREADS = TransGeom<G, SW>::THREADS;
+    const int grid = (a.s.d.B + EPB - 1) / EPB;
+    if (grid == 0) return TAP_OK;
+    if (mask_fast_path_ok(a.m)) {
+        const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
+        hipLaunchKernelGGL((k_transition<D, G, true, SW>), dim3(grid), dim3(THREADS), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((k_transition<D, G, false, SW>), dim3(grid), dim3(THREADS), 0, st, a);
     }
+    TAP_LAUNCH_CHECK(ctx, "k_transition");
+    return TAP_OK;
+}
 
-    // ---- column sums + masks of the slabs this wave streamed (pack.py:318-329) ---------------------
-#pragma unroll
-    for (int k = 0; k < SPW; ++k) {
-        const int senv = env_base + wave * SPW + k;
-        if (senv < B) mask_env(a.m, senv, lane, real[k], pp[k]);
-    }
+// TAP_TR_VARIANT (tuning knob, read once): 0 = 4 stream waves x 2 slabs (default);
+// 2 = one stream wave per slab.
+static int transition_variant()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("TAP_TR_VARIANT"); v = e ? atoi(e) : 0; }
+    return v;
 }
 
 template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-    constexpr int EPB = (G == 64) ? 4 : 8;
-    const int grid = (a.s.d.B + EPB - 1) / EPB;
-    if (grid == 0) return TAP_OK;
-    const bool vec = (a.m.nR % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a.m.dyn_in) | reinterpret_cast<uintptr_t>(a.m.dyn_out)) % 16 == 0);
-    if (vec) hipLaunchKernelGGL((k_transition<D, G, 4>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
-    else hipLaunchKernelGGL((k_transition<D, G, 1>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
-    TAP_LAUNCH_CHECK(ctx, "k_transition");
-    return TAP_OK;
+    if (transition_variant() == 2) return launch_transition_v<D, G, 8>(ctx, a, st);
+    return launch_transition_v<D, G, 4>(ctx, a, st);
 }
 
 extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
