@@ -31,6 +31,9 @@ from tap_net_amd import dist as tdist       # noqa: E402
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 
+# nodes of one precedence window (rolling.py feeds the actor 10-node sub-graphs)
+WINDOW = {"c5": 10}
+
 CONFIGS = {
     # name: (workload string, D, container, n, per-GPU batch, reward, strategy)
     "c2": ("2D RAND nodes=10 container_width=5 LB_GREEDY batch=8192 on 1xMI355X (BASELINE configs[1])",
@@ -39,7 +42,8 @@ CONFIGS = {
            3, [5, 5, 50], 10, 4096, "C+P+S-lb-soft", "LB_GREEDY"),
     "c4": ("2D nodes=20 container_width=7 MACS batch=8192 on 1xMI355X (BASELINE configs[3], RAND-marginal blocks)",
            2, [7, 100], 20, 8192, "C+P+S-mcs-soft", "MACS"),
-    "c5": ("3D nodes=50 container_width=5x5 H=250 LB_GREEDY batch=8192 per GPU (BASELINE configs[4] shard)",
+    "c5": ("3D nodes=50 (5 consecutive 10-node precedence windows) container_width=5x5 H=250 LB_GREEDY "
+           "batch=8192 per GPU (BASELINE configs[4] shard)",
            3, [5, 5, 250], 50, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
 }
 
@@ -56,23 +60,31 @@ def algorithmic_bytes(D, cs, n):
 
 
 class HotPath(object):
-    """Pre-allocated buffers + direct C-ABI calls for one rank's share of the batch."""
+    """Pre-allocated buffers + direct C-ABI calls for one rank's share of the batch.
 
-    def __init__(self, cfg, B, start, device, seed=12345, fused=True):
+    An episode is `windows` consecutive precedence windows of `nw` nodes each over ONE long-lived
+    container per env (windows = 1 except for the rolling-sized config c5)."""
+
+    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None):
         _, D, cs, n, _, reward, strategy = cfg
         self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
-        static, dynamic = synth.rand_instances(B, n, D, seed=seed, start=start)
-        tape = synth.random_feasible_tape(static, dynamic, n, seed=seed + 1, start=start)
-        self.static = static.to(device)
-        self.dynamic0 = dynamic.to(device)
-        self.tape = tape.t().contiguous().to(device)          # (n, B): one contiguous ptr row per step
-        self.R = static.shape[2] // n
-        self.nR, self.rows = static.shape[2], dynamic.shape[1]
-        self.env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=device)
+        self.nw = window or n
+        assert n % self.nw == 0
+        self.windows = n // self.nw
         f32 = dict(dtype=torch.float32, device=device)
-        self.dyn = [torch.empty_like(self.dynamic0), torch.empty_like(self.dynamic0)]
-        self.cs0 = T.pack.dynamic_colsum(self.dynamic0, n).clone()
-        self.csb = [torch.empty_like(self.cs0), torch.empty_like(self.cs0)]
+        self.static, self.dynamic0, self.tape, self.cs0 = [], [], [], []
+        for w in range(self.windows):
+            static, dynamic = synth.rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start)
+            tape = synth.random_feasible_tape(static, dynamic, self.nw, seed=seed + 100 * w + 1, start=start)
+            self.static.append(static.to(device))
+            self.dynamic0.append(dynamic.to(device))
+            self.tape.append(tape.t().contiguous().to(device))  # (nw, B): one contiguous ptr row per step
+            self.cs0.append(T.pack.dynamic_colsum(self.dynamic0[-1], self.nw).clone())
+        self.R = self.static[0].shape[2] // self.nw
+        self.nR, self.rows = self.static[0].shape[2], self.dynamic0[0].shape[1]
+        self.env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=device)
+        self.dyn = [torch.empty_like(self.dynamic0[0]), torch.empty_like(self.dynamic0[0])]
+        self.csb = [torch.empty_like(self.cs0[0]), torch.empty_like(self.cs0[0])]
         self.mask0 = torch.ones(B, self.nR, **f32)
         self.maskb = [torch.empty(B, self.nR, **f32), torch.empty(B, self.nR, **f32)]
         self.cur = torch.empty(B, self.nR, **f32)
@@ -91,41 +103,34 @@ class HotPath(object):
             _lib.check(fn(*args, stream), self.ctx)
 
     def episode(self):
-        if self.fused:
-            return self.episode_fused()
+        """fused: n launches of tap_transition (first FRESH, last emits calc_ratio);
+        otherwise reset + n x (tap_mask_step, tap_env_step_gather) + tap_env_ratio."""
         L, P, e = self.lib, _lib.ptr, self.env
         d = C.byref(e.desc)
-        self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
-        dyn_in, cs_in, mask_in = self.dynamic0, self.cs0, self.mask0
-        for t in range(self.n):
-            ptr = self.tape[t]
-            o = t & 1
-            self._k("mask_step", L.tap_mask_step, self.ctx, self.B, self.n, self.R, self.rows, 3,
-                    P(dyn_in), P(self.static), self.static.shape[1], P(ptr), P(mask_in), P(cs_in),
-                    P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]))
-            dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
-            self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(self.static),
-                    self.static.shape[1], self.nR, P(ptr), None, P(self.feat))
-        self._k("ratio", L.tap_env_ratio, self.ctx, d, P(e._state), P(self.reward), None, None)
-
-
-def _episode_fused(self):
-    """n launches per pass: tap_transition, first FRESH (no reset launch), last emits calc_ratio."""
-    L, P, e = self.lib, _lib.ptr, self.env
-    d = C.byref(e.desc)
-    dyn_in, cs_in, mask_in = self.dynamic0, self.cs0, self.mask0
-    for t in range(self.n):
-        ptr = self.tape[t]
-        o = t & 1
-        flags = (_lib.TAP_T_FRESH if t == 0 else 0) | (_lib.TAP_T_RATIO if t == self.n - 1 else 0)
-        self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.n, self.R, self.rows, 3,
-                P(dyn_in), P(self.static), self.static.shape[1], P(ptr), P(mask_in), P(cs_in),
-                P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat),
-                P(self.reward), flags)
-        dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
-
-
-HotPath.episode_fused = _episode_fused
+        if not self.fused:
+            self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
+        step = 0
+        for w in range(self.windows):
+            st = self.static[w]
+            dyn_in, cs_in, mask_in = self.dynamic0[w], self.cs0[w], self.mask0
+            for t in range(self.nw):
+                ptr = self.tape[w][t]
+                o = t & 1
+                if self.fused:
+                    flags = (_lib.TAP_T_FRESH if step == 0 else 0) | (_lib.TAP_T_RATIO if step == self.n - 1 else 0)
+                    self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.nw, self.R, self.rows,
+                            3, P(dyn_in), P(st), st.shape[1], P(ptr), P(mask_in), P(cs_in), P(self.dyn[o]),
+                            P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
+                else:
+                    self._k("mask_step", L.tap_mask_step, self.ctx, self.B, self.nw, self.R, self.rows, 3,
+                            P(dyn_in), P(st), st.shape[1], P(ptr), P(mask_in), P(cs_in),
+                            P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]))
+                    self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st),
+                            st.shape[1], self.nR, P(ptr), None, P(self.feat))
+                dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
+                step += 1
+        if not self.fused:
+            self._k("ratio", L.tap_env_ratio, self.ctx, d, P(e._state), P(self.reward), None, None)
 
 
 def time_passes(hp, steps, warmup, use_graph, world):
@@ -171,7 +176,7 @@ def time_passes(hp, steps, warmup, use_graph, world):
     return tdist.max_over_ranks(dt, dev), graph
 
 
-def kernel_event_times(hp, steps):
+def kernel_event_times(hp, steps, graph=None):
     """Per-launch durations with HIP events on the launch stream (torch.cuda.Event on torch's
     current stream == the stream the kernels are enqueued on), over `steps` eager passes."""
     recs = {}
@@ -184,13 +189,29 @@ def kernel_event_times(hp, steps):
         b.record()
         recs.setdefault(name, []).append((a, b))
 
-    hp.hook = hook
+    pass_pairs = []
+    hp.hook = None if hp.fused else hook
     try:
         for _ in range(steps):
-            hp.episode()
+            if hp.fused:
+                # the pass is n back-to-back launches of ONE kernel: bracket the pass and divide, so the
+                # event overhead is amortised and the figure is comparable with rocprofv3's average
+                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+                a.record()
+                if graph is not None:
+                    graph.replay()
+                else:
+                    hp.episode()
+                b.record()
+                pass_pairs.append((a, b))
+            else:
+                hp.episode()
         torch.cuda.synchronize(hp.device)
     finally:
         hp.hook = None
+    if hp.fused:
+        us = np.array([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3 / hp.n
+        recs = None
     # cost of an empty event pair, to show how much of a short kernel's figure is event overhead
     pairs = []
     for _ in range(64):
@@ -199,6 +220,10 @@ def kernel_event_times(hp, steps):
     torch.cuda.synchronize(hp.device)
     empty_us = float(np.median([a.elapsed_time(b) for a, b in pairs]) * 1e3)
     out = {}
+    if recs is None:
+        out["transition"] = dict(launches=len(us) * hp.n, avg_us=float(us.mean()), med_us=float(np.median(us)),
+                                 total_us=float(us.sum() * hp.n))
+        return out, empty_us
     for name, evs in recs.items():
         us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
         out[name] = dict(launches=len(us), avg_us=float(us.mean()), med_us=float(np.median(us)),
@@ -206,26 +231,31 @@ def kernel_event_times(hp, steps):
     return out, empty_us
 
 
-def cpu_baseline(cfg, budget_s=12.0):
+def cpu_baseline(cfg, window=None, budget_s=12.0):
     """The oracle (C port of the reference algorithm) over the same pass, on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
     _, D, cs, n, B, reward, strategy = cfg
     B = min(B, 4096)
-    static, dynamic = synth.rand_instances(B, n, D, seed=12345)
-    tape = synth.random_feasible_tape(static, dynamic, n, seed=12346).numpy()
-    st, dyn0 = static.numpy(), dynamic.numpy()
-    R = st.shape[2] // n
-    blocks = np.stack([st[np.arange(B), 1:, tape[:, t]] for t in range(n)], axis=1).astype(np.int32)
+    nw = window or n
+    wins = []
+    for w in range(n // nw):
+        static, dynamic = synth.rand_instances(B, nw, D, seed=12345 + 100 * w)
+        tape = synth.random_feasible_tape(static, dynamic, nw, seed=12346 + 100 * w).numpy()
+        wins.append((static.numpy(), dynamic.numpy(), tape))
+    R = wins[0][0].shape[2] // nw
+    blocks = np.concatenate([np.stack([st[np.arange(B), 1:, tape[:, t]] for t in range(nw)], axis=1)
+                             for st, _, tape in wins], axis=1).astype(np.int32)
     desc = O.make_desc(cs, n, reward, "diff", strategy)
     O.lib()
     done, t0 = 0, time.perf_counter()
     while True:
-        dyn, mask = dyn0, np.ones((B, st.shape[2]), np.float32)
-        O.initial_mask(dyn, n)
-        for t in range(n):
-            dyn = O.update_dynamic(dyn, st, tape[:, t], n, 3)
-            _, mask = O.update_mask(mask, dyn, tape[:, t], n, R)
+        for st, dyn0, tape in wins:
+            dyn, mask = dyn0, np.ones((B, st.shape[2]), np.float32)
+            O.initial_mask(dyn, nw)
+            for t in range(nw):
+                dyn = O.update_dynamic(dyn, st, tape[:, t], nw, 3)
+                _, mask = O.update_mask(mask, dyn, tape[:, t], nw, R)
         r = O.run_episodes(desc, blocks, nthreads=1, want_heightmaps=False)
         assert r["nerr"] == 0
         done += B * n
@@ -272,7 +302,7 @@ def main():
     if args.batch:
         B = args.batch
         cfg = (name, D, cs, n, B, reward, strategy)
-    hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused)
+    hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config))
     use_graph = not args.no_graph
     dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
     hp.env.check()
@@ -281,8 +311,8 @@ def main():
 
     out = None
     if rank == 0:
-        kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)))
-        env_b, mask_b = algorithmic_bytes(D, cs, n)
+        kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)), graph if hp.fused else None)
+        env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
         per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B}
         names = [k for k in ("transition", "mask_step", "env_step", "ratio", "reset") if k in kt]
         dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
@@ -300,7 +330,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "i32 height-maps / f64 candidate scores / f32 masks",
             "data": "synthetic",
-            "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "container": cs,
+            "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy,
                        "pass": ("n x tap_transition (update_dynamic+update_mask+gather+add_new_block in one launch; "
                                 "first starts a fresh container, last emits calc_ratio)") if hp.fused else
@@ -314,11 +344,11 @@ def main():
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg)
+            out["cpu_baseline"] = cpu_baseline(cfg, WINDOW.get(args.config))
         if args.sweep:
             for b in (8192, 32768, 131072, 524288, 2097152):
                 try:
-                    h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev, fused=hp.fused)
+                    h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev, fused=hp.fused, window=hp.nw)
                     d2, _ = time_passes(h2, 10, 3, use_graph, 1)
                     k2, _ = kernel_event_times(h2, 3)
                     print("sweep B=%d: %.3e env-steps/s; " % (b, b * n * 10 / d2) + "; ".join(
