@@ -46,7 +46,8 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     (model.py:515), env, and with ``record`` the per-step features / masks.
     """
     if input_type in ('mul', 'mul-with'):
-        raise NotImplementedError("two-container input types are not implemented in rollout")
+        return _run_episode_mul(static, dynamic, policy, container_width, container_height, reward_type,
+                                heightmap_type, packing_strategy, input_type, allow_rot, record, steps)
     block_dim = int(static.shape[1]) - 1
     n = int(dynamic.shape[-1]) // (math.factorial(block_dim) if allow_rot else 1)
     B, D = int(static.shape[0]), block_dim
@@ -84,6 +85,48 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     if ratio is None:
         ratio = env.calc_ratios()                                 # model.py:499-510
     out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -ratio, 'env': env,
+           'dynamic': masks.dynamic, 'mask': masks.mask}
+    if record:
+        out.update(features=feats, current_masks=curs, masks=msks)
+    return out
+
+
+def _run_episode_mul(static, dynamic, policy, container_width, container_height, reward_type,
+                     heightmap_type, packing_strategy, input_type, allow_rot, record, steps):
+    """The two-container variant (input types 'mul' / 'mul-with', model.py:290-292, 396-447,
+    503-507): the last row of ``static`` holds each block's target container id; per step the chosen
+    block is placed in container a (id 0) or b (id 1) and the other one only reports its height-map
+    (the C ABI's ``active`` mask); decoder features are concatenated on dim 1 and the score is the
+    mean of the two ``calc_ratio`` values."""
+    D = int(static.shape[1]) - 2
+    n = int(dynamic.shape[-1]) // (math.factorial(D) if allow_rot else 1)
+    B = int(static.shape[0])
+    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    dev = _lib.resolve_device(static.device)
+    env_a = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
+    env_b = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
+    masks = MaskStepper(static.to(dev), dynamic.to(dev), input_type, allow_rot)
+    static_part = masks.static[:, 1:-1, :] if input_type == 'mul' else masks.static[:, 1:, :]   # model.py:389-394
+    ssize = static_part.shape[1]
+    decoder_static = torch.zeros(B, ssize, 1, device=dev)
+    decoder_dynamic = torch.cat((torch.zeros(env_a._feature_shape(), device=dev),
+                                 torch.zeros(env_b._feature_shape(), device=dev)), 1)
+    tour, feats, curs, msks = [], [], [], []
+    for step in range(n if steps is None else steps):
+        ptr = policy(step=step, static=masks.static, dynamic=masks.dynamic,
+                     current_mask=masks.current_mask, mask=masks.mask,
+                     decoder_static=decoder_static, decoder_dynamic=decoder_dynamic).to(torch.int64)
+        masks.step(ptr)
+        target = torch.gather(masks.static[:, -1, :], 1, ptr.view(-1, 1)).squeeze(1)           # model.py:396-401
+        decoder_static = torch.gather(static_part, 2, ptr.view(-1, 1, 1).expand(-1, ssize, 1))
+        fa = env_a.add_new_blocks_gather(masks.static, ptr, active=(target == 0))               # model.py:419-427
+        fb = env_b.add_new_blocks_gather(masks.static, ptr, active=(target == 1))
+        decoder_dynamic = torch.cat((fa, fb), 1)                                               # model.py:429-447
+        tour.append(ptr.unsqueeze(1))
+        if record:
+            feats.append(decoder_dynamic); curs.append(masks.current_mask); msks.append(masks.mask)
+    ratio = (env_a.calc_ratios() + env_b.calc_ratios()) / 2.0                                  # model.py:503-507
+    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -ratio, 'env': env_a, 'env_b': env_b,
            'dynamic': masks.dynamic, 'mask': masks.mask}
     if record:
         out.update(features=feats, current_masks=curs, masks=msks)
