@@ -152,6 +152,26 @@ int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const 
                        int static_rows, int nR, const int64_t *tour, float *reward_out,
                        int32_t *positions_out, uint8_t *stable_out, void *stream);
 
+/* ---- instance generation (generate.py:773-971) ---------------------------------------- */
+
+/* tools.calc_positions_lb_greedy (tools.py:2393-2449) for B explicit block lists: blocks (B, n, D)
+ * int32 in placement order, one launch.  This is what generate.generate_blocks calls with
+ * 'C+P+S-lb-hard' on the initial container (generate.py:908); an instance is accepted when every
+ * stable_out flag is 1 (generate.py:909-910).  reward_out (B,) f32 = -(C+P+S), positions_out
+ * (B, n, D) i32, stable_out (B, n) u8 -- each nullable. */
+int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const int32_t *blocks,
+                    float *reward_out, int32_t *positions_out, uint8_t *stable_out, void *stream);
+
+/* generate.calc_dependent (generate.py:575-771) + the rotation bookkeeping of
+ * generate.generate_blocks (generate.py:935-971) + pack.PACKDataset's layout (pack.py:101-195,
+ * input_type 'bot', allow_rot=True): from blocks and positions (B, n, D) i32 of fully packed
+ * initial containers to static_out (B, 1+D, n*R) and dynamic_out (B, 3n, n*R) f32.
+ * container_size = D host ints (the INITIAL container); arm_size as generate.py:623-641 (2D).
+ * n <= 64. */
+int tap_precedence(tap_ctx *ctx, int B, int D, int n, const int32_t *container_size, int arm_size,
+                   const int32_t *blocks, const int32_t *positions, float *static_out,
+                   float *dynamic_out, void *stream);
+
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) --------------------------- */
 /* dynamic is (B, rows, nR) f32 with rows = 3n ('bot', 'mul') or n ('simple', 'rot'); nR = n*R.
  * colsum is a (B, 3, nR) f32 shadow of the three per-section column sums of a dynamic tensor

@@ -129,6 +129,26 @@ int orc_calc_positions_lb_greedy(const orc_desc *d, int n, const int32_t *blocks
 int orc_reward(const orc_desc *d, int B, int n, int nR, int static_rows, const float *static_,
                const int64_t *tour, float *reward_out, int nthreads);
 
+/* ---- instance generation ---- */
+
+/* generate.calc_dependent (generate.py:575-771) on the env's voxel grid after n placements.
+ * Each output is an n*n row-major 0/1 matrix; M[a*n + b] = 1 reads "block a blocks block b"
+ * (move: a rests above b; left/right/forward/backward: a stands in b's side access).
+ * forward/backward are all-zero in 2D.  arm_size is used in 2D only (generate.py:623-641). */
+void orc_calc_dependent(const orc_env *e, int n, int arm_size, uint8_t *move, uint8_t *left,
+                        uint8_t *right, uint8_t *forward, uint8_t *backward);
+
+/* generate.generate_blocks for GIVEN block sizes (generate.py:893-971, container_width >= 0
+ * branch): pack `blocks` (n, D) into the initial container with 'C+P+S-lb-hard'
+ * (generate.py:908), derive the dependencies, and lay the result out as pack.PACKDataset does
+ * for input_type 'bot', allow_rot=True (pack.py:101-195): static_out (1+D, n*R) fp32,
+ * dynamic_out (3n, n*R) fp32, positions_out (n, D).  Returns 1 if the instance is accepted
+ * (every block placed and stable, generate.py:909-910), 0 if the reference would re-sample,
+ * < 0 on error. */
+int orc_instance_from_blocks(int D, const int32_t *init_size, int n, int arm_size,
+                             const int32_t *blocks, int32_t *positions_out, float *static_out,
+                             float *dynamic_out);
+
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) ---- */
 
 /* initial mask, model.py:297-307.  dynamic (B, rows, nR) fp32, rows = 3n ('bot') or n. */

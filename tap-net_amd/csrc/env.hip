@@ -409,6 +409,7 @@ struct EpisodeArgs {
     const float *static_;
     int static_rows, nR;
     const int64_t *tour;
+    const int32_t *blocks; // (B, n, D) explicit block lists when static_ is null (tap_pack_blocks)
     float *reward_out;
     int32_t *pos_out;
     uint8_t *stable_out;
@@ -427,10 +428,12 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
     Counters cnt = {0, 0, 0, 0};
     for (int t = 0; t < n; ++t) {
         int dims[3] = {1, 1, 1};
-        if (ev) { // pack.py:441-444 gather by tour, :454-455 rows 1..D, tools.py:2415 astype('int')
+        if (ev && a.static_) { // pack.py:441-444 gather by tour, :454-455 rows 1..D, tools.py:2415 astype('int')
             const long p = (long)a.tour[(size_t)env * n + t];
             for (int k = 0; k < D; ++k)
                 dims[k] = (int)a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
+        } else if (ev) {
+            for (int k = 0; k < D; ++k) dims[k] = a.blocks[((size_t)env * n + t) * D + k];
         }
         const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
         const bool ok = ev && bx >= 1 && by >= 1 && bz >= 1;
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
         const double P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
         const double S = (double)cnt.nstable / (double)n;
         // the reference raises on a height overflow; here the reward becomes NaN
-        a.reward_out[env] = err ? __int_as_float(0x7fc00000) : -(float)((C + P) + S);
+        if (a.reward_out) a.reward_out[env] = err ? __int_as_float(0x7fc00000) : -(float)((C + P) + S);
     }
 }
 
@@ -480,6 +483,18 @@ extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, in
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
     if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
         return tap_fail(ctx, TAP_E_INVALID, "bad episode arguments");
-    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, reward_out, positions_out, stable_out};
+    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, reward_out, positions_out, stable_out};
+    TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const int32_t *blocks,
+                               float *reward_out, int32_t *positions_out, uint8_t *stable_out,
+                               void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY only");
+    if (!blocks || B < 0 || n < 1) return tap_fail(ctx, TAP_E_INVALID, "bad pack_blocks arguments");
+    EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, reward_out, positions_out, stable_out};
     TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
 }

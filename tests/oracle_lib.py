@@ -70,6 +70,7 @@ def lib():
         L.orc_calc_positions_lb_greedy.argtypes = [C.POINTER(Desc), C.c_int] + [C.c_void_p] * 5
         L.orc_reward.argtypes = [C.POINTER(Desc), C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_instance_from_blocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L.orc_initial_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_update_dynamic.argtypes = [C.c_int] * 6 + [C.c_void_p] * 4
         L.orc_update_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
@@ -261,3 +262,16 @@ def update_mask(mask, dynamic, ptr, n, R):
 def is_stable_3d_mask(bx, by, mask):
     m = np.ascontiguousarray(mask, dtype=np.uint8).reshape(-1)
     return bool(lib().orc_is_stable_3d_mask(bx, by, _p(m)))
+
+
+def instance_from_blocks(blocks, init_size, arm_size=1):
+    """blocks (n, D) -> (accepted, positions (n,D), static (1+D, nR), dynamic (3n, nR))."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    n, D = blocks.shape
+    R = 2 if D == 2 else 6
+    cs = np.ascontiguousarray(init_size, dtype=np.int32)
+    pos = np.zeros((n, D), np.int32)
+    st = np.zeros((1 + D, n * R), np.float32)
+    dyn = np.zeros((3 * n, n * R), np.float32)
+    rc = lib().orc_instance_from_blocks(D, _p(cs), n, arm_size, _p(blocks), _p(pos), _p(st), _p(dyn))
+    return rc, pos, st, dyn

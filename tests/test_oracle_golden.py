@@ -152,3 +152,23 @@ def test_reward_tour():
         nerr, r = O.reward(ds["static"].astype(np.float32), rt["tour_%dd" % D].astype(np.int64),
                            "C+P+S-lb-soft", 5, 50)
         assert nerr == 0 and np.array_equal(r, rt["reward_%dd" % D])
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_instance_generation_from_reference_datasets(D):
+    """generate.generate_blocks + calc_dependent + PACKDataset layout: re-derive positions, static
+    and dynamic from the block sizes of instances the reference generated itself."""
+    ds = G.load("dataset_%dd.npz" % D)
+    n = 10
+    R = 2 if D == 2 else 6
+    N = ds["static"].shape[0]
+    blocks_txt = ds["txt_blocks"].reshape(N, R, D, n)              # R lines per sample, dimension-major
+    pos_txt = ds["txt_pos"].reshape(N, D, n)
+    init = [7, 50] if D == 2 else [7, 7, 50]
+    for b in range(N):
+        blocks = blocks_txt[b, 0].T                                 # rotation 0 = the sampled sizes
+        rc, pos, st, dyn = O.instance_from_blocks(blocks, init, arm_size=1)
+        assert rc == 1, b                                           # the reference accepted it
+        assert np.array_equal(pos, pos_txt[b].T), b
+        assert np.array_equal(st, ds["static"][b].astype(np.float32)), b
+        assert np.array_equal(dyn, ds["dynamic"][b].astype(np.float32)), b
