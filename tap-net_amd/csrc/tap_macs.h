@@ -1,0 +1,299 @@
+// tap_macs.h -- device code: one MACS / MUL 2D placement for one container, G lanes per container
+// (lane = container column).  tools.calc_one_position_mcs_2d (tools.py:2456-2749) re-stated on the
+// height-map plus the placement history; used by macs.hip (stand-alone step)
+// and transition.hip (fused step).
+//
+// The reference builds a list of "empty maximal spaces" (EMS), walks both bottom corners of every
+// EMS sequentially -- sliding the block until it settles, with a `visited` set shared by all walks --
+// scores every settled slot and takes the first maximum (optionally tie-broken by a usable-space
+// score).  What is parallel here:
+//   phase 1  EMS list: built by all lanes of the group redundantly in lock-step (identical LDS
+//            writes, every lane reads back only what it wrote, so no barrier); the duplicate check of
+//            block-top entries is strided over the lanes.
+//   phase 2  the walks: whether a block settles at (x, Z) -- supported, free, and stable when the
+//            reward is 'hard' -- depends on (x, Z) only, so a walk stops at the first position in its
+//            direction that is `good` and not yet taken by an earlier walk.  Per EMS every lane tests
+//            its own column once, ONE ballot gives the level's good-mask, and a walk is a
+//            find-first-set on good & ~taken[Z] & range (`taken`: per-level bitmask in LDS).  This
+//            phase is sequential over EMS but only integer bit-twiddling; it emits a slot list.
+//   phase 3  scoring: lanes take slots round-robin and evaluate C/P/S in fp64 (and, only for slots
+//            that tie at the maximum, the usable-space score); the reference's "first maximum, ties
+//            by usable space, then by order" is one lexicographic butterfly reduction.
+// Facts used: voxel (c,z) != 0 <=> z < hm[c]; level_free_space[z] == maximal runs of columns with
+// hm[c] <= z (so only z = 0 and z in {hm[c]} open new level-EMS); the usable-space score of a
+// candidate map hm' is base(hm') + (max_h - max(hm'))(W-1) with max_h common to all candidates, so
+// ties are ordered by base(hm') - max(hm')(W-1).
+#pragma once
+
+#include "tap_place.h"
+
+constexpr int MACS_EMS_CAP = 128;  // packed EMS entries per env
+constexpr int MACS_SLOT_CAP = 256; // two walks per EMS
+constexpr int MACS_MAX_H = 256;
+
+// LDS words per env group: hm | ems | slots | taken (uint16 per level) | history (x, z, bx, bz)
+__host__ __device__ constexpr int macs_group_words(int G, int H, int n_max)
+{
+    return G + MACS_EMS_CAP + MACS_SLOT_CAP + (H + 1) / 2 + 4 * n_max;
+}
+
+struct MacsLds {
+    int *hm, *ems, *slots, *hist;
+    unsigned short *taken;
+};
+
+__device__ __forceinline__ MacsLds macs_lds(int *base, int G, int H)
+{
+    MacsLds m;
+    m.hm = base;
+    m.ems = base + G;
+    m.slots = m.ems + MACS_EMS_CAP;
+    m.taken = reinterpret_cast<unsigned short *>(m.slots + MACS_SLOT_CAP);
+    m.hist = m.slots + MACS_SLOT_CAP + (H + 1) / 2;
+    return m;
+}
+
+template <int G> __device__ __forceinline__ int group_sum(int v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+
+// usable-space tie-break score of the candidate map (hm with columns [xs, xs+bx) raised to `top`):
+// sum_{h < m} longest free run (length - 1) at level h (tools.py:2667-2678), minus m (W - 1)
+template <int G>
+__device__ inline int macs_adj(const int (&hmr)[G], int W, int xs, int bx, int top, int m)
+{
+    int base = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) {
+        if (j >= W) break;
+        const int v = (j >= xs && j < xs + bx) ? top : hmr[j];
+        bool first = true;
+        int next = m, best_run = 0, run = -1;
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            if (k >= W) break;
+            const int hk = (k >= xs && k < xs + bx) ? top : hmr[k];
+            if (hk == v && k < j) first = false;
+            if (hk > v) next = min(next, hk);
+            if (hk <= v) { ++run; best_run = max(best_run, run); } else run = -1;
+        }
+        if (first && v < m) base += (next - v) * best_run;
+    }
+    return base - m * (W - 1);
+}
+
+// column bitmasks of the height-map held in registers (static indexing only, no LDS, no cross-lane)
+template <int G> __device__ __forceinline__ unsigned macs_mask_le(const int (&hmr)[G], unsigned wmask, int z)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) m |= (unsigned)(hmr[k] <= z) << k;
+    return m & wmask;
+}
+template <int G> __device__ __forceinline__ unsigned macs_mask_eq(const int (&hmr)[G], unsigned wmask, int z)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) m |= (unsigned)(hmr[k] == z) << k;
+    return m & wmask;
+}
+template <int G> __device__ __forceinline__ int macs_sum(const int (&hmr)[G], int xs, int bx)
+{
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) s += (k >= xs && k < xs + bx) ? hmr[k] : 0;
+    return s;
+}
+
+// One placement.  Preconditions: L.hm[cell] = hm, L.taken[0..H) = 0, L.hist[0..4*cnt.count) =
+// (x, z, bx, bz) of the earlier steps, all visible to the group (wave-level sync by the caller).
+// do_step is group-uniform.  On return hm/cnt are updated and res describes the placement.
+//
+// Every lane keeps the whole height-map in registers and derives per-level column bitmasks
+// (free: hm <= z, on: hm == z) from it, so runs, supports, footprint tests and stability are bit
+// operations; LDS only holds the EMS list, the slot list and the per-level `taken` masks.
+template <int G>
+__device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, int cell, int gl0,
+                                           int &hm, Counters &cnt, int &err, int bx, int bz,
+                                           bool do_step)
+{
+    const int W = c.W, H = c.H;
+    const bool incell = cell < W;
+    Placement res = {0, 0, 0, 0, 0};
+    if (!do_step) return res;
+    const int hard = c.flags & TAP_F_HARD;
+    const int vol = bx * bz, step = cnt.count;
+    const unsigned wmask = (1u << W) - 1u, gmask = (1u << G) - 1u;
+    int hmr[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) hmr[k] = L.hm[k];
+    int gmax = 0;
+#pragma unroll
+    for (int k = 0; k < G; ++k) gmax = max(gmax, hmr[k]);
+
+    // ---- phase 1: EMS list (identical on every lane of the group) ---------------------------------
+    int n_ems = 0;
+#define EMS_PUSH(x1, z, x2)                                                                  \
+    do {                                                                                     \
+        if (n_ems < MACS_EMS_CAP) L.ems[n_ems++] = ((x1) & 0xff) | (((x2) & 0xff) << 8) | ((z) << 16); \
+        else err |= 16;                                                                      \
+    } while (0)
+    // (a) per-level free runs (tools.py:2517-2529); only z = 0 and z in {hm[c]} differ from below
+    for (int z = 0;;) {
+        if (z + bz > H) break;                                                // :2519
+        unsigned m = macs_mask_le<G>(hmr, wmask, z);
+        const unsigned on = macs_mask_eq<G>(hmr, wmask, z);
+        while (m) {
+            const int x1 = __ffs((int)m) - 1;
+            const int len = __ffs((int)~(m >> x1)) - 1;                       // maximal run [x1, x1+len)
+            const unsigned run = ((1u << len) - 1u) << x1;
+            m &= ~run;
+            if (x1 + bx > W) break;                                           // :2525
+            if (z > 0 && !(on & run)) continue;                               // :2526-2528 same run below
+            EMS_PUSH(x1, z, x1 + len - 1);                                    // :2529
+        }
+        int nz = INT_MAX;                                                     // :2520 next level that differs
+#pragma unroll
+        for (int k = 0; k < G; ++k) nz = (hmr[k] > z) ? min(nz, hmr[k]) : nz;
+        if (nz == INT_MAX) break;
+        z = nz;
+    }
+    // (b) tops of the blocks placed so far (tools.py:2531-2555); failed steps sit at (0, 0)
+    for (int i = 0; i < step; ++i) {
+        const int x = L.hist[i * 4], z = L.hist[i * 4 + 1], xx = L.hist[i * 4 + 2], zz = L.hist[i * 4 + 3];
+        const int tz = z + zz;
+        if (!(tz < H)) continue;                                              // :2535
+        const unsigned fr = macs_mask_le<G>(hmr, wmask, tz);
+        const unsigned span = (xx >= 32 ? 0xffffffffu : ((1u << xx) - 1u)) << x; // slice clips at W (:2537)
+        if (((span & wmask) & ~fr) == 0) {
+            const int want = (x & 0xff) | (((x + xx - 1) & 0xff) << 8) | (tz << 16);
+            int dup = 0;                                                      // :2538
+            for (int k = cell; k < n_ems; k += G) dup |= L.ems[k] == want;
+            if (!group_or<G>(dup)) EMS_PUSH(x, tz, x + xx - 1);
+        } else {
+            if (x + xx - 1 >= W) { err |= 8; continue; }                      // reference: IndexError :2550
+            if (((fr >> x) & 1u) && x > 0 && ((fr >> (x - 1)) & 1u)) {        // :2543-2548 left part
+                const int len = __ffs((int)~(fr >> x)) - 1;                   // free columns from x rightwards
+                EMS_PUSH(x, tz, x + min(len, xx) - 1);
+            }
+            const int xe = x + xx - 1;
+            if (((fr >> xe) & 1u) && x + xx < W && ((fr >> (x + xx)) & 1u)) { // :2550-2555 right part
+                const unsigned low = fr << (31 - xe);                         // bit xe -> bit 31
+                const int len = __clz((int)~low);                             // free columns from xe leftwards
+                EMS_PUSH(xe - min(len, xx) + 1, tz, xe);
+            }
+        }
+    }
+
+    // ---- phase 2: both corner walks of every EMS (tools.py:2680-2700) -> slot list ------------------
+    const int X = W - bx + 1;
+    const unsigned fpm = (1u << bx) - 1u;
+    int n_slots = 0;
+    for (int e = 0; e < n_ems; ++e) {
+        const int pk = L.ems[e];
+        const int X1 = pk & 0xff, X2 = (pk >> 8) & 0xff, Z = pk >> 16;
+        // every lane tests its own column as the block's left edge at level Z (:2571-2588)
+        const unsigned fr = macs_mask_le<G>(hmr, wmask, Z), on = macs_mask_eq<G>(hmr, wmask, Z);
+        bool good = false;
+        if (incell && cell + bx <= W) {
+            const unsigned eq = (on >> cell) & fpm;
+            const bool free_ = ((fr >> cell) & fpm) == fpm;                   // :2576
+            const bool supported = Z == 0 || eq != 0;                         // :2574
+            const int stab = (Z == 0) ? 1 : (eq ? tap_stable2d(bx, eq) : 0);  // :2577-2585
+            good = supported && free_ && (stab || !hard);                     // :2580-2581
+        }
+        const unsigned gm = (unsigned)((__ballot(good) >> gl0) & gmask);
+        unsigned tk = L.taken[Z];
+        if (X1 < X) {                                                         // :2686 left corner, slide right
+            const unsigned m = gm & ~tk & ~((1u << X1) - 1u);
+            if (m) {
+                const int xs = __ffs((int)m) - 1;
+                tk |= 1u << xs;
+                L.slots[n_slots++] = xs | (Z << 8);
+            }
+        }
+        const int hi = X2 - bx + 1;                                           // :2694 right corner, slide left
+        if (hi >= 0) {
+            if (hi + bx > W) err |= 8;
+            else {
+                const unsigned m = gm & ~tk & ((2u << hi) - 1u);
+                if (m) {
+                    const int xs = 31 - __clz((int)m);
+                    tk |= 1u << xs;
+                    L.slots[n_slots++] = xs | (Z << 8);
+                }
+            }
+        }
+        L.taken[Z] = (unsigned short)tk; // every lane stores the same value and reads back its own
+    }
+
+    // ---- phase 3: score the slots (tools.py:2590-2604), lanes round-robin ---------------------------
+    const int valid2 = cnt.valid + vol;
+    const bool tiebreak = (c.flags & TAP_F_MCS_TIE) != 0, zero = (c.flags & TAP_F_MCS_ZERO) != 0;
+    // C/P/S of slot s -> ratio (0.0 when the reward string zeroes it, :2709-2710)
+    auto eval_slot = [&](int s, int &xs, int &Z, int &sum, int &stab) -> double {
+        const int sp = L.slots[s];
+        xs = sp & 0xff; Z = sp >> 8;
+        sum = macs_sum<G>(hmr, xs, bx);
+        const unsigned eq = (macs_mask_eq<G>(hmr, wmask, Z) >> xs) & fpm;     // a settled slot has max == Z
+        stab = (Z == 0) ? 1 : tap_stable2d(bx, eq);
+        if (zero) return 0.0;
+        int height = max(gmax, Z + bz);
+        if (Z + bx > height) height = Z + bz;                                 // :2594 (sic block_x)
+        const int emp = cnt.empty + bx * Z - sum;                             // :2598-2599
+        const double C = (double)valid2 / (double)((long long)height * W);
+        const double P = (c.flags & TAP_F_USE_P) ? (double)valid2 / (double)(emp + valid2) : 0.0;
+        const double S = (c.flags & TAP_F_USE_S) ? (double)(cnt.nstable + stab) / (double)(cnt.count + 1) : 0.0;
+        return (C + P) + S;
+    };
+    double my_r = -1.0;
+    int my_slot = INT_MAX; // order index of this lane's best slot
+    for (int s = cell; s < n_slots; s += G) {
+        int xs, Z, sum, stab;
+        const double r = eval_slot(s, xs, Z, sum, stab);
+        if (r > my_r) { my_r = r; my_slot = s; } // slots come in increasing order: first maximum kept
+    }
+    double rmax = my_r;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, G));
+    // winner (:2713-2736): the first slot reaching rmax, or -- with the 'mcs' tie-break -- the first
+    // one among them with the largest usable-space score
+    int win = INT_MAX;
+    if (n_slots > 0) {
+        if (!tiebreak) {
+            win = group_min<G>(my_r == rmax ? my_slot : INT_MAX);
+        } else {
+            int best_adj = INT_MIN, best_s = INT_MAX;
+            for (int s = cell; s < n_slots; s += G) {
+                int xs, Z, sum, stab;
+                if (eval_slot(s, xs, Z, sum, stab) != rmax) continue; // recomputing beats storing r
+                const int adj = macs_adj<G>(hmr, W, xs, bx, Z + bz, max(gmax, Z + bz));
+                if (adj > best_adj) { best_adj = adj; best_s = s; }
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) { // lexicographic (adj desc, order asc)
+                const int a2 = __shfl_xor(best_adj, o, G), s2 = __shfl_xor(best_s, o, G);
+                if (a2 > best_adj || (a2 == best_adj && s2 < best_s)) { best_adj = a2; best_s = s2; }
+            }
+            win = best_s;
+        }
+    }
+
+    // ---- commit (tools.py:2738-2747) -------------------------------------------------------------------
+    if (win != INT_MAX) {
+        int xs, Z, sum, stab;
+        (void)eval_slot(win, xs, Z, sum, stab);
+        res.placed = 1; res.x = xs; res.z = Z; res.stab = stab;
+        if (incell && cell >= xs && cell < xs + bx) hm = Z + bz;
+        cnt.valid += vol;
+        cnt.empty = cnt.empty + bx * Z - sum;
+        cnt.nstable += stab;
+        if (Z + bz > H) err |= 1;
+    }
+    cnt.count += 1;
+#undef EMS_PUSH
+    return res;
+}
