@@ -93,7 +93,7 @@ class HotPath(object):
         self.lib = _lib.lib()
         self.ctx = _lib.ctx(device)
         self.hook = None                                     # optional per-kernel timing hook
-        self.fused = fused and strategy == "LB_GREEDY"
+        self.fused = fused
 
     def _k(self, name, fn, *args):
         stream = _lib.stream_of(self.device)

@@ -212,7 +212,8 @@ enum {
  * tap_mask_step + tap_env_step_gather fused, so the placement's latency hides under the HBM-bound
  * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
  * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
- * LB_GREEDY only.  feature_out nullable; ratio_out (B,) f32 required with TAP_T_RATIO. */
+ * LB_GREEDY (2D/3D) and MACS/MUL (2D).  feature_out nullable; ratio_out (B,) f32 required with
+ * TAP_T_RATIO. */
 int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                    int update_rows, const float *dyn_in, const float *static_, int static_rows,
                    const int64_t *ptr, const float *mask_in, const float *colsum_in,

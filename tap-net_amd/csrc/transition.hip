@@ -17,6 +17,7 @@
 #include <cstdlib>
 
 #include "tap_common.h"
+#include "tap_macs.h"
 #include "tap_masks.h"
 #include "tap_place.h"
 
@@ -26,6 +27,37 @@ struct TransArgs {
     int flags;
     float *ratio_out;
 };
+
+// ---- a stream wave: out-of-place copy of SPW consecutive slabs with the chosen rows cleared
+//      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
+template <int SPW, bool FAST>
+__device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
+{
+    bool on[SPW];
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
+    if (FAST) {
+        stream_wave_fast<SPW, 6>(m, senv0, lane, on, lds);
+        return;
+    }
+    const size_t slab = (size_t)m.rows * m.nR;
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+        if (!on[k]) continue;
+        const int senv = senv0 + k;
+        const long p = (long)m.ptr[senv];
+        const long real = (long)m.static_[(size_t)senv * m.static_rows * m.nR + p]; // pack.py:339
+        const ClearRanges cr = clear_ranges(m, real);
+        const float *src = m.dyn_in + (size_t)senv * slab;
+        float *dst = m.dyn_out + (size_t)senv * slab;
+        for (long f = lane; f < (long)slab; f += 64) {
+            float v = src[f];
+            if (in_cleared(cr, (int)f)) v = 0.f;
+            dst[f] = v;
+        }
+        mask_env(m, senv, lane, real, p);
+    }
+}
 
 template <int G, int SW> struct TransGeom {
     static constexpr int EPB = (G == 64) ? 4 : 8;   // envs per workgroup
@@ -48,34 +80,8 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     const int B = a.s.d.B;
 
     if (wave >= ENV_WAVES) {
-        // ---- stream waves: out-of-place copy of their slabs with the chosen rows cleared
-        //      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
-        const int sw = wave - ENV_WAVES;
-        const int senv0 = env_base + sw * SPW;
-        bool on[SPW];
-#pragma unroll
-        for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < B;
-        if (FAST) {
-            stream_wave_fast<SPW, 6>(a.m, senv0, lane, on, trans_lds + (size_t)sw * SPW * 3 * a.m.nR);
-        } else {
-            const size_t slab = (size_t)a.m.rows * a.m.nR;
-#pragma unroll
-            for (int k = 0; k < SPW; ++k) {
-                if (!on[k]) continue;
-                const int senv = senv0 + k;
-                const long p = (long)a.m.ptr[senv];
-                const long real = (long)a.m.static_[(size_t)senv * a.m.static_rows * a.m.nR + p]; // pack.py:339
-                const ClearRanges cr = clear_ranges(a.m, real);
-                const float *src = a.m.dyn_in + (size_t)senv * slab;
-                float *dst = a.m.dyn_out + (size_t)senv * slab;
-                for (long f = lane; f < (long)slab; f += 64) {
-                    float v = src[f];
-                    if (in_cleared(cr, (int)f)) v = 0.f;
-                    dst[f] = v;
-                }
-                mask_env(a.m, senv, lane, real, p);
-            }
-        }
+        trans_stream_wave<SPW, FAST>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+                                     trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
         return;
     }
 
@@ -143,6 +149,106 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     }
 }
 
+// ---- the same fusion for MACS / MUL 2D (tap_macs.h): G = 8/16 lanes per env ---------------------
+template <int G, bool FAST>
+__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(TransArgs a)
+{
+    using Geo = TransGeom<G, 4>;
+    constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
+    extern __shared__ float trans_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int env_base = blockIdx.x * EPB;
+    const int B = a.s.d.B, W = a.s.d.W, H = a.s.d.H;
+    if (wave >= ENV_WAVES) {
+        trans_stream_wave<SPW, FAST>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+                                     trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(2);
+    int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
+    const bool fresh = a.flags & TAP_T_FRESH;
+    const int cell = tid % G, gl0 = lane - cell;
+    const int env = env_base + tid / G;
+    const bool ev = env < B, incell = cell < W;
+    const MacsLds L = macs_lds(macs_base + (tid / G) * macs_group_words(G, H, a.s.d.n_max), G, H);
+    int hm = 0, cv = 0, bx = 1, bz = 1;
+    if (ev) {
+        if (!fresh) {
+            if (incell) hm = a.s.v.hm[(size_t)env * W + cell];
+            if (cell < 4) cv = a.s.v.cnt[(size_t)env * 4 + cell];
+        }
+        const long p = (long)a.s.ptr[env];
+        bx = (int)a.s.static_[((size_t)env * a.s.static_rows + 1) * a.s.nR + p];
+        bz = (int)a.s.static_[((size_t)env * a.s.static_rows + 2) * a.s.nR + p];
+    }
+    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
+    int err = 0;
+    bool do_step = ev;
+    if (ev && cnt.count >= a.s.d.n_max) { err |= 2; do_step = false; }
+    if (ev && (bx < 1 || bz < 1)) { err |= 4; do_step = false; }
+    L.hm[cell] = hm;
+    for (int i = cell; i < H; i += G) L.taken[i] = 0;
+    if (ev)
+        for (int k = cell; k < cnt.count * 4 && k < a.s.d.n_max * 4; k += G) {
+            const int i = k >> 2, f = k & 3;
+            L.hist[k] = (f < 2 ? a.s.v.pos : a.s.v.blk)[(size_t)(i * 2 + (f & 1)) * B + env];
+        }
+    tap_wave_lds_sync();
+    const int step = cnt.count;
+    const PlaceCfg cfg = {W, 1, H, a.s.d.flags};
+    const Placement pl = tap_macs_place<G>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
+    err = group_or<G>(err);
+    tap_wave_lds_sync();
+    L.hm[cell] = hm;
+    tap_wave_lds_sync();
+    const int gmax = (a.flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
+    if (ev) {
+        if (incell) a.s.v.hm[(size_t)env * W + cell] = hm;
+        if (a.s.feature_out)
+            tap_write_feature<2, G>(a.s.d.feature, W, 1, L.hm, cell, hm, a.s.feature_out + (size_t)env * a.s.flen);
+        if (cell == 0) {
+            if (do_step || fresh)
+                reinterpret_cast<int4 *>(a.s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+            if (do_step) {
+                a.s.v.pos[(size_t)(step * 2) * B + env] = pl.x;
+                a.s.v.pos[(size_t)(step * 2 + 1) * B + env] = pl.z;
+                a.s.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
+                a.s.v.blk[(size_t)(step * 2) * B + env] = bx;
+                a.s.v.blk[(size_t)(step * 2 + 1) * B + env] = bz;
+            }
+            if (fresh) a.s.v.err[env] = err;
+            else if (err) a.s.v.err[env] |= err;
+            if (a.flags & TAP_T_RATIO) {
+                double C = 0.0, P = 0.0, S = 0.0;
+                if (cnt.count != 0) {
+                    C = (double)cnt.valid / (double)((long long)W * gmax);
+                    P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
+                    S = (double)cnt.nstable / (double)cnt.count;
+                }
+                a.ratio_out[env] = (float)tap_ratio_formula(a.s.d.ratio_mode, C, P, S);
+            }
+        }
+    } else if (a.s.d.feature == TAP_FEAT_ZERO) {
+        (void)group_min<G>(INT_MAX);
+    }
+}
+
+int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d); // macs.hip
+
+template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
+{
+    constexpr int EPB = TransGeom<G, 4>::EPB, THREADS = TransGeom<G, 4>::THREADS;
+    const int grid = (a.s.d.B + EPB - 1) / EPB;
+    if (grid == 0) return TAP_OK;
+    const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
+                       (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max) * sizeof(int);
+    if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
+    if (mask_fast_path_ok(a.m)) hipLaunchKernelGGL((k_transition_macs<G, true>), dim3(grid), dim3(THREADS), lds, st, a);
+    else hipLaunchKernelGGL((k_transition_macs<G, false>), dim3(grid), dim3(THREADS), lds, st, a);
+    TAP_LAUNCH_CHECK(ctx, "k_transition_macs");
+    return TAP_OK;
+}
+
 template <int D, int G, int SW>
 static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
@@ -183,8 +289,7 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
-    if (d->strategy != TAP_LB_GREEDY)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "tap_transition implements LB_GREEDY; step MACS/MUL with tap_mask_step + tap_env_step_gather");
+    if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
     if (!state || !dyn_in || !static_ || !ptr || !mask_in || !colsum_in || !dyn_out || !colsum_out ||
         !current_out || !mask_out || n < 1 || R < 1 || rows < 1 || static_rows < 1 + d->D ||
         update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
@@ -200,6 +305,9 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     a.flags = flags;
     a.ratio_out = ratio_out;
     const int Gs = tap_group_size(d);
+    if (d->strategy == TAP_MACS)
+        return d->W <= 8 ? launch_transition_macs<8>(ctx, a, (hipStream_t)stream)
+                         : launch_transition_macs<16>(ctx, a, (hipStream_t)stream);
     if (d->D == 2) {
         if (Gs == 8) return launch_transition<2, 8>(ctx, a, (hipStream_t)stream);
         if (Gs == 16) return launch_transition<2, 16>(ctx, a, (hipStream_t)stream);

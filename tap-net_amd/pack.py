@@ -166,7 +166,7 @@ class MaskStepper(object):
 class EnvTransition(MaskStepper):
     """One launch per decoding step: update_dynamic + update_mask + gather + add_new_block
     (tap_transition), optionally starting from a fresh container and optionally emitting
-    calc_ratio.  LB_GREEDY only; MACS/MUL callers use MaskStepper + BatchedContainer."""
+    calc_ratio."""
 
     def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True):
         super(EnvTransition, self).__init__(static, dynamic, input_type, allow_rot)

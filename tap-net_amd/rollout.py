@@ -55,7 +55,6 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     dev = _lib.resolve_device(static.device)
     if env is None:
         env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
-    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY
     if fused:
         masks = EnvTransition(static.to(dev), dynamic.to(dev), env, input_type, allow_rot)
     else:
