@@ -172,6 +172,27 @@ int tap_precedence(tap_ctx *ctx, int B, int D, int n, const int32_t *container_s
                    const int32_t *blocks, const int32_t *positions, float *static_out,
                    float *dynamic_out, void *stream);
 
+/* ---- rolling precedence windows (generate.py:1589-1839, rolling.py:589-637) ------------- */
+
+/* generate.InitialContainer.__init__: the five dependency graphs of B fully packed initial
+ * containers with N <= 64 blocks each, as 64-bit column masks: rel_out (B, 5, N) uint64 with bit a
+ * of rel[b][k][j] = "block a blocks block j" (k = move, left, right, forward, backward);
+ * state_out (B, 2) uint64 = (entered, window), both cleared. */
+int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container_size, int arm_size,
+                     const int32_t *blocks, const int32_t *positions, uint64_t *rel_out,
+                     uint64_t *state_out, void *stream);
+
+/* One step of rolling.validate's loop: InitialContainer.remove_block for the column picked in the
+ * previous window (remove_ptr (B,) int64, NULL on the first call), then convert_to_input():
+ * top the window up to `child` nodes and emit static_out (B, 1+D, child*R), dynamic_out
+ * (B, 3*child, child*R) f32.  Optional by-products: colsum_out (B, 3, child*R) (the column sums
+ * update_mask needs), current_mask_out (B, child*R) (model.py:297-307), nodes_out (B, child) i32
+ * (sorted global block ids = static's columns), err_out (B,) i32 (1 = window could not be filled). */
+int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
+                       const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
+                       float *static_out, float *dynamic_out, float *colsum_out,
+                       float *current_mask_out, int32_t *nodes_out, int32_t *err_out, void *stream);
+
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) --------------------------- */
 /* dynamic is (B, rows, nR) f32 with rows = 3n ('bot', 'mul') or n ('simple', 'rot'); nR = n*R.
  * colsum is a (B, 3, nR) f32 shadow of the three per-section column sums of a dynamic tensor

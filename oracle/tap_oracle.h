@@ -149,6 +149,21 @@ int orc_instance_from_blocks(int D, const int32_t *init_size, int n, int arm_siz
                              const int32_t *blocks, int32_t *positions_out, float *static_out,
                              float *dynamic_out);
 
+/* ---- rolling windows: generate.InitialContainer (generate.py:1589-1839) ---- */
+
+typedef struct orc_rolling orc_rolling;
+/* InitialContainer.__init__: paint the initial container from blocks (N, D; rotation 0) and
+ * positions (N, D), derive the five dependency graphs (calc_dependent, arm_size 1). */
+orc_rolling *orc_rolling_new(int D, const int32_t *init_size, int N, int child,
+                             const int32_t *blocks, const int32_t *positions);
+void orc_rolling_free(orc_rolling *r);
+/* InitialContainer.convert_to_input (generate.py:1778-1822) incl. sub_deps_graph (:1674-1776):
+ * static_out (1+D, child*R), dynamic_out (3*child, child*R) fp32, nodes_out (child) = sorted
+ * sub_graph_nodes.  Returns is_last_graph() (1 / 0), < 0 when the window could not be filled. */
+int orc_rolling_window(orc_rolling *r, float *static_out, float *dynamic_out, int32_t *nodes_out);
+/* InitialContainer.remove_block(sub_graph_nodes[local_index]) (generate.py:1824-1835) */
+void orc_rolling_remove(orc_rolling *r, int local_index);
+
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) ---- */
 
 /* initial mask, model.py:297-307.  dynamic (B, rows, nR) fp32, rows = 3n ('bot') or n. */

@@ -5,14 +5,15 @@ update_mask / reward, PACKDataset) backed by hand-written HIP kernels behind the
 include/tapenv.h.  The directory name is not a Python identifier; import it as ``tap_net_amd``
 (the alias module at the repository root) or via importlib.
 """
-from . import _lib, build, dist, env, generate, pack, rollout, synth   # noqa: F401
+from . import _lib, build, dist, env, generate, pack, rolling, rollout, synth   # noqa: F401
 from ._lib import TapError, TapOverflowError                   # noqa: F401
 from .env import BatchedContainer, Container                   # noqa: F401
 from .generate import generate_instances                       # noqa: F401
 from .pack import (EnvTransition, MaskStepper, PACKDataset, initial_mask, reward,   # noqa: F401
                    update_dynamic, update_mask)
+from .rolling import RollingWindows, run_rolling_episode            # noqa: F401
 from .rollout import RandomFeasiblePolicy, TapePolicy, run_episode   # noqa: F401
 
 __all__ = ["BatchedContainer", "Container", "MaskStepper", "EnvTransition", "PACKDataset", "initial_mask", "reward",
            "update_dynamic", "update_mask", "run_episode", "TapePolicy", "RandomFeasiblePolicy",
-           "generate_instances", "TapError", "TapOverflowError"]
+           "generate_instances", "RollingWindows", "run_rolling_episode", "TapError", "TapOverflowError"]

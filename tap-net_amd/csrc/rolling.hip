@@ -1,0 +1,317 @@
+// rolling.hip -- rolling precedence windows: generate.InitialContainer
+// (generate.py:1589-1839) as rolling.validate drives it (rolling.py:589-637), for B instances in
+// lock-step.  gfx950 only.
+//
+// The reference keeps five networkx digraphs over the N blocks of an instance and, per decoding
+// step, (1) drops the block the policy picked from the current window, (2) tops the window up to
+// `child` nodes with in-degree-0 nodes of what is left of the movement graph, layer by layer in
+// node order, (3) cuts the five induced sub-graphs, adding a self-loop to a side graph wherever a
+// blocker is still outside the window, and (4) lays them out as the network's static / dynamic
+// input.  With N <= 64 every graph is one 64-bit column mask per node ("who blocks me"), the state
+// is two masks (entered, window), and one wavefront (lane = node) handles one instance:
+// layers are ballots, "lowest k free nodes" is a rank test, sub-matrix entries are bit tests.
+//
+// One reference quirk is reproduced on purpose: the sub-graph matrices are indexed in the
+// iteration order of a CPython set of the window's node ids (networkx FilterAtlas walks
+// show_nodes' set when the sub-graph is less than half of the graph), while the static columns use
+// the sorted order (generate.py:1758-1761 vs 1774, 1793).  pyset_* below re-states
+// Objects/setobject.c for small ints (hash(n) == n): 9 linear probes, perturb shift 5, growth x4
+// once fill*5 >= mask*3.
+#include "tap_common.h"
+#include "tap_place.h"
+
+struct RollArgs {
+    int B, D, N, child, W, L, H, arm;
+    const int32_t *blocks;    // (B, N, D) rotation 0
+    const int32_t *positions; // (B, N, D)  (init only)
+    unsigned long long *rel;  // (B, 5, N)  move, left, right, forward, backward column masks
+    unsigned long long *state; // (B, 2)    entered, window
+    const int64_t *remove_ptr; // (B,) column picked in the previous window, or null
+    float *static_out;        // (B, 1+D, child*R)
+    float *dynamic_out;       // (B, 3*child, child*R)
+    float *colsum_out;        // (B, 3, child*R) nullable
+    float *cur_mask_out;      // (B, child*R) nullable
+    int32_t *nodes_out;       // (B, child) nullable
+    int32_t *err_out;         // (B,) nullable: 1 = window could not be filled
+};
+
+__device__ __forceinline__ bool rng_meet(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
+
+// ---- relations: the same box predicates as k_precedence (generate.hip), one lane per node --------
+template <int D>
+__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_init(RollArgs a)
+{
+    __shared__ int s_blk[TAP_BLOCK / 64][64 * 3];
+    __shared__ int s_pos[TAP_BLOCK / 64][64 * 3];
+    const int w = threadIdx.x >> 6, b = threadIdx.x & 63;
+    const int inst = blockIdx.x * (TAP_BLOCK / 64) + w;
+    const int n = a.N;
+    if (inst < a.B)
+        for (int k = b; k < n * D; k += 64) {
+            s_blk[w][k] = a.blocks[(size_t)inst * n * D + k];
+            s_pos[w][k] = a.positions[(size_t)inst * n * D + k];
+        }
+    tap_wave_lds_sync();
+    if (inst >= a.B) return;
+    if (b == 0) { a.state[(size_t)inst * 2] = 0; a.state[(size_t)inst * 2 + 1] = 0; }
+    if (b >= n) return;
+    const int *blk = s_blk[w], *pos = s_pos[w];
+#define BX(i) blk[(i) * D]
+#define BY(i) (D == 3 ? blk[(i) * D + 1] : 1)
+#define BZ(i) blk[(i) * D + D - 1]
+#define PX(i) pos[(i) * D]
+#define PY(i) (D == 3 ? pos[(i) * D + 1] : 0)
+#define PZ(i) pos[(i) * D + D - 1]
+    const int x = PX(b), y = PY(b), z = PZ(b), bx = BX(b), by = BY(b), bz = BZ(b);
+    const int top = z + bz, z_mid = z + (bz - 1) / 2;
+    u64 move = 0, left = 0, right = 0, fwd = 0, bwd = 0;
+    if (D == 2) {                                                     // generate.py:575-647
+        for (int o = 0; o < n; ++o) {
+            if (o == b) continue;
+            const int ox = PX(o), oz = PZ(o), obx = BX(o), otop = oz + BZ(o);
+            if (rng_meet(ox, ox + obx, x, x + bx) && oz > z) move |= 1ull << o;
+            if (x >= a.arm && rng_meet(ox, ox + obx, x - a.arm, x) && otop > z_mid) left |= 1ull << o;
+            if (x + bx <= a.W - a.arm && rng_meet(ox, ox + obx, x + bx, x + bx + a.arm) && otop > z_mid) right |= 1ull << o;
+        }
+        if (x < a.arm) left |= 1ull << b;
+        if (x + bx > a.W - a.arm) right |= 1ull << b;
+    } else {                                                          // generate.py:649-752
+        for (int i = 0; i < bx; ++i)
+            for (int j = 0; j < by; ++j) {
+                const int cx = x + i, cy = y + j;
+                int best = -1, bestz = INT_MAX;
+                for (int o = 0; o < n; ++o) {
+                    if (o == b) continue;
+                    const int ox = PX(o), oy = PY(o), oz = PZ(o);
+                    if (cx >= ox && cx < ox + BX(o) && cy >= oy && cy < oy + BY(o) && oz >= top && oz < bestz) { bestz = oz; best = o; }
+                }
+                if (best >= 0) move |= 1ull << best;
+            }
+        const int ymid = y + (by - 1) / 2, xmid = x + (bx - 1) / 2;
+        for (int o = 0; o < n; ++o) {
+            if (o == b) continue;
+            const int ox = PX(o), oy = PY(o), otop = PZ(o) + BZ(o);
+            if (otop <= z_mid) continue;
+            const bool in_y = ymid >= oy && ymid < oy + BY(o), in_x = xmid >= ox && xmid < ox + BX(o);
+            if (x > 0 && in_y && x - 1 >= ox && x - 1 < ox + BX(o)) left |= 1ull << o;
+            if (x + bx < a.W && in_y && x + bx >= ox && x + bx < ox + BX(o)) right |= 1ull << o;
+            if (y > 0 && in_x && y - 1 >= oy && y - 1 < oy + BY(o)) fwd |= 1ull << o;
+            if (y + by < a.L && in_x && y + by >= oy && y + by < oy + BY(o)) bwd |= 1ull << o;
+        }
+        if (x == 0) left |= 1ull << b;
+        if (x + bx == a.W) right |= 1ull << b;
+        if (y == 0) fwd |= 1ull << b;
+        if (y + by == a.L) bwd |= 1ull << b;
+    }
+    u64 *r = a.rel + (size_t)inst * 5 * n;
+    r[b] = move; r[n + b] = left; r[2 * n + b] = right; r[3 * n + b] = fwd; r[4 * n + b] = bwd;
+#undef BX
+#undef BY
+#undef BZ
+#undef PX
+#undef PY
+#undef PZ
+}
+
+// ---- CPython set emulation (see file header) ------------------------------------------------------
+__device__ inline int pyset_probe(const int *table, int mask, int key)
+{
+    unsigned long long perturb = (unsigned long long)key;
+    int i = key & mask;
+    for (;;) {
+        int probes = (i + 9 <= mask) ? 9 : 0, j = i;
+        do {
+            if (table[j] < 0) return j;
+            ++j;
+        } while (probes--);
+        perturb >>= 5;
+        i = (int)((i * 5ull + 1ull + perturb) & (unsigned long long)mask);
+    }
+}
+
+constexpr int PYSET_CAP = 256;
+
+// keys[0..n) in list order -> order[0..n) in set iteration order; tbl/tmp: PYSET_CAP ints each
+__device__ inline void pyset_order(const int *keys, int n, int *order, int *tbl, int *tmp)
+{
+    int size = 8, fill = 0;
+    for (int i = 0; i < size; ++i) tbl[i] = -1;
+    for (int k = 0; k < n; ++k) {
+        tbl[pyset_probe(tbl, size - 1, keys[k])] = keys[k];
+        ++fill;
+        if (fill * 5 >= (size - 1) * 3) {                  // set_table_resize(used * 4)
+            int newsize = 8;
+            while (newsize <= fill * 4) newsize <<= 1;
+            const int oldsize = size;
+            for (int i = 0; i < oldsize; ++i) tmp[i] = tbl[i];
+            size = newsize;
+            for (int i = 0; i < size; ++i) tbl[i] = -1;
+            for (int i = 0; i < oldsize; ++i)
+                if (tmp[i] >= 0) tbl[pyset_probe(tbl, size - 1, tmp[i])] = tmp[i];
+        }
+    }
+    int m = 0;
+    for (int i = 0; i < size; ++i) if (tbl[i] >= 0) order[m++] = tbl[i];
+}
+
+// ---- one window step: remove, top up, cut sub-graphs, emit tensors ----------------------------------
+template <int D>
+__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
+{
+    __shared__ int s_lst[TAP_BLOCK / 64][64];   // sub_graph_nodes in list order
+    __shared__ int s_ord[TAP_BLOCK / 64][64];   // sub-graph node order (matrix index -> node)
+    __shared__ int s_pos[TAP_BLOCK / 64][64];   // node -> matrix index
+    __shared__ int s_tbl[TAP_BLOCK / 64][2 * PYSET_CAP];
+    const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
+    const int inst = blockIdx.x * (TAP_BLOCK / 64) + w;
+    if (inst >= a.B) return;
+    const int N = a.N, child = a.child;
+    constexpr int R = D == 2 ? 2 : 6;
+    const int nRc = child * R;
+    const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
+    const u64 bit = 1ull << v, below = bit - 1ull;
+    const bool isnode = v < N;
+    u64 rel[5] = {0, 0, 0, 0, 0};
+    if (isnode) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) rel[k] = a.rel[((size_t)inst * 5 + k) * N + v];
+    }
+    u64 entered = a.state[(size_t)inst * 2], window = a.state[(size_t)inst * 2 + 1];
+
+    // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
+    if (a.remove_ptr) {
+        long slot = (long)a.remove_ptr[inst];
+        while (slot >= child) slot -= child;
+        const bool hit = (window & bit) && __popcll(window & below) == slot;
+        window &= ~__ballot(hit);
+    }
+    // (2) top the window up: in-degree-0 nodes of gm_copy, layer by layer, ascending ids
+    //     (generate.py:1724-1750); list order = old window (sorted by the previous call) + appended
+    int count = __popcll(window);
+    if (window & bit) s_lst[w][__popcll(window & below)] = v;
+    u64 added = 0;
+    while (count < child) {
+        const u64 gmc = all & ~(entered | added);                    // nodes still in gm_copy
+        const bool free_ = isnode && (gmc & bit) && (__popcll(gmc) == 1 || (rel[0] & gmc) == 0);
+        const u64 fm = __ballot(free_);
+        if (fm == 0) break;
+        const int need = child - count;
+        const bool take = free_ && __popcll(fm & below) < need;
+        if (take) s_lst[w][count + __popcll(fm & below)] = v;
+        const u64 tm = __ballot(take);
+        added |= tm;
+        count += __popcll(tm);
+    }
+    entered |= added;   // after_nodes_list.remove (:1745) and, the window being full, decompose() (:1712-1721)
+    window |= added;
+    const int short_window = count != child;
+    tap_wave_lds_sync();
+
+    // (3) node order of the induced sub-graphs (:1684-1688, 1758-1761)
+    if (2 * child < N) {
+        if (v == 0 && !short_window) pyset_order(s_lst[w], child, s_ord[w], s_tbl[w], s_tbl[w] + PYSET_CAP);
+    } else if (window & bit) {
+        s_ord[w][__popcll(window & below)] = v;
+    }
+    tap_wave_lds_sync();
+    if (v < child && !short_window) s_pos[w][s_ord[w][v]] = v;
+    tap_wave_lds_sync();
+
+    if (v == 0) {
+        a.state[(size_t)inst * 2] = entered;
+        a.state[(size_t)inst * 2 + 1] = window;
+        if (a.err_out) a.err_out[inst] = short_window;
+    }
+    if (short_window || !(window & bit)) return;
+
+    // (4) tensors (generate.py:1778-1822): this lane owns window node v
+    const int slot = __popcll(window & below);      // sorted position  -> static column
+    const int midx = s_pos[w][v];                   // sub-graph index   -> dynamic row / column
+    const u64 after = all & ~entered;               // after_nodes_list
+    // :1690-1705 a blocker that has not entered any window yet => the side counts as self-blocked
+    u64 side[5];
+    side[0] = rel[0] & window;
+#pragma unroll
+    for (int k = 1; k < 5; ++k) side[k] = (rel[k] & window) | ((rel[k] & after) ? bit : 0ull);
+    const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+    const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
+    float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
+    const int32_t *blk = a.blocks + ((size_t)inst * N + v) * D;
+    if (a.nodes_out) a.nodes_out[(size_t)inst * child + slot] = v;
+    for (int r = 0; r < R; ++r) {
+        const int *p = D == 2 ? perm2[r] : perm3[r];
+        const int scol = r * child + slot, dcol = r * child + midx;
+        st[scol] = (float)slot;                                                   // :1795-1801
+        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + scol] = (float)blk[p[k]];
+        u64 small = 0, large = 0;                                                 // :1808-1821
+        if (p[D - 1] == 0) { small = side[1]; large = side[2]; }
+        else if (D == 3 && p[D - 1] == 1) { small = side[3]; large = side[4]; }
+        for (int i = 0; i < child; ++i) {
+            const int node = s_ord[w][i];
+            dy[(size_t)i * nRc + dcol] = (float)((side[0] >> node) & 1);
+            dy[(size_t)(child + i) * nRc + dcol] = (float)((small >> node) & 1);
+            dy[(size_t)(2 * child + i) * nRc + dcol] = (float)((large >> node) & 1);
+        }
+        const float ms = (float)__popcll(side[0]), ss = (float)__popcll(small), ls = (float)__popcll(large);
+        if (a.colsum_out) {
+            float *cs = a.colsum_out + (size_t)inst * 3 * nRc;
+            cs[dcol] = ms; cs[nRc + dcol] = ss; cs[2 * nRc + dcol] = ls;
+        }
+        if (a.cur_mask_out)                                                       // model.py:297-307
+            a.cur_mask_out[(size_t)inst * nRc + dcol] = (ss * ls + ms != 0.f) ? 0.f : 1.f;
+    }
+}
+
+static int roll_check(tap_ctx *ctx, int B, int D, int N, int child)
+{
+    if ((D != 2 && D != 3) || B < 0 || N < 1 || N > 64 || child < 1 || child > N || child > 64)
+        return tap_fail(ctx, TAP_E_INVALID, "bad rolling arguments (total blocks <= 64, window <= total)");
+    if (2 * child < N && child > 76)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "window too large for the set-order table");
+    return TAP_OK;
+}
+
+extern "C" int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container_size,
+                                int arm_size, const int32_t *blocks, const int32_t *positions,
+                                uint64_t *rel_out, uint64_t *state_out, void *stream)
+{
+    int rc = roll_check(ctx, B, D, N, 1);
+    if (rc) return rc;
+    if (!container_size || !blocks || !positions || !rel_out || !state_out || arm_size < 1)
+        return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    RollArgs a = {};
+    a.B = B; a.D = D; a.N = N; a.W = container_size[0]; a.L = D == 3 ? container_size[1] : 1;
+    a.H = container_size[D - 1]; a.arm = arm_size; a.blocks = blocks; a.positions = positions;
+    a.rel = reinterpret_cast<unsigned long long *>(rel_out);
+    a.state = reinterpret_cast<unsigned long long *>(state_out);
+    const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
+    if (grid == 0) return TAP_OK;
+    if (D == 2) hipLaunchKernelGGL(k_rolling_init<2>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_rolling_init<3>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    TAP_LAUNCH_CHECK(ctx, "k_rolling_init");
+    return TAP_OK;
+}
+
+extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
+                                  const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
+                                  float *static_out, float *dynamic_out, float *colsum_out,
+                                  float *current_mask_out, int32_t *nodes_out, int32_t *err_out,
+                                  void *stream)
+{
+    int rc = roll_check(ctx, B, D, N, child);
+    if (rc) return rc;
+    if (!blocks || !rel || !state || !static_out || !dynamic_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    RollArgs a = {};
+    a.B = B; a.D = D; a.N = N; a.child = child; a.blocks = blocks;
+    a.rel = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(rel));
+    a.state = reinterpret_cast<unsigned long long *>(state);
+    a.remove_ptr = remove_ptr; a.static_out = static_out; a.dynamic_out = dynamic_out;
+    a.colsum_out = colsum_out; a.cur_mask_out = current_mask_out; a.nodes_out = nodes_out; a.err_out = err_out;
+    const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
+    if (grid == 0) return TAP_OK;
+    if (D == 2) hipLaunchKernelGGL(k_rolling_window<2>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_rolling_window<3>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    TAP_LAUNCH_CHECK(ctx, "k_rolling_window");
+    return TAP_OK;
+}

@@ -1,0 +1,123 @@
+"""Rolling precedence windows -- the batched counterpart of ``generate.InitialContainer``
+(generate.py:1589-1839) and of the outer loop of ``rolling.validate`` (rolling.py:589-637), which
+packs instances far larger than the policy's 10-node input by re-cutting a 10-node sub-graph of the
+precedence DAG after every placement (batch size 1, networkx, in the reference).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .env import BatchedContainer
+from .pack import EnvTransition
+
+
+class RollingWindows(object):
+    """B instances of N <= 64 packed blocks each; ``next(ptr)`` drops the block picked in the
+    previous window and returns the next window's network input."""
+
+    def __init__(self, blocks, positions, initial_container_size, child_graph_size=10, arm_size=1):
+        self.blocks = blocks.to(torch.int32).contiguous()
+        self.device = _lib.resolve_device(self.blocks.device)
+        positions = positions.to(device=self.device, dtype=torch.int32).contiguous()
+        self.B, self.N, self.D = self.blocks.shape
+        self.child = int(child_graph_size)
+        self.R = 2 if self.D == 2 else 6
+        self.rel = torch.empty(self.B, 5, self.N, dtype=torch.int64, device=self.device)
+        self.state = torch.empty(self.B, 2, dtype=torch.int64, device=self.device)
+        self.steps_done = 0
+        cs = (C.c_int32 * self.D)(*[int(v) for v in initial_container_size])
+        self._ctx = _lib.ctx(self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().tap_rolling_init(self._ctx, self.B, self.D, self.N, cs, int(arm_size),
+                                                   _lib.ptr(self.blocks), _lib.ptr(positions), _lib.ptr(self.rel),
+                                                   _lib.ptr(self.state), _lib.stream_of(self.device)), self._ctx)
+
+    @property
+    def windows_total(self):
+        """Number of convert_to_input() calls of one instance: N - child single-step windows plus the last one."""
+        return self.N - self.child + 1
+
+    def is_last_graph(self):
+        """InitialContainer.is_last_graph (generate.py:1838-1839) for the window returned last; the
+        instances run in lock-step, so this is a host-side count, not a device read."""
+        return self.steps_done >= self.windows_total
+
+    def next(self, remove_ptr=None, want_masks=True):
+        """convert_to_input() after remove_block(sub_graph_nodes[ptr % child]).
+        -> dict(static, dynamic, nodes, colsum, current_mask)."""
+        if (remove_ptr is None) != (self.steps_done == 0):
+            raise ValueError("pass the previous window's pick to every call but the first")
+        f32 = dict(dtype=torch.float32, device=self.device)
+        nRc = self.child * self.R
+        static = torch.empty(self.B, 1 + self.D, nRc, **f32)
+        dynamic = torch.empty(self.B, 3 * self.child, nRc, **f32)
+        nodes = torch.empty(self.B, self.child, dtype=torch.int32, device=self.device)
+        colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks else None
+        cur = torch.empty(self.B, nRc, **f32) if want_masks else None
+        err = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        ptr = None if remove_ptr is None else remove_ptr.to(device=self.device, dtype=torch.int64).contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().tap_rolling_window(
+                self._ctx, self.B, self.D, self.N, self.child, _lib.ptr(self.blocks), _lib.ptr(self.rel),
+                _lib.ptr(self.state), _lib.ptr(ptr), _lib.ptr(static), _lib.ptr(dynamic), _lib.ptr(colsum),
+                _lib.ptr(cur), _lib.ptr(nodes), _lib.ptr(err), _lib.stream_of(self.device)), self._ctx)
+        self.steps_done += 1
+        self._err = err
+        return dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, current_mask=cur)
+
+    def check(self):
+        if int(self._err.sum().item()):
+            raise _lib.TapError(_lib.TAP_E_INVALID, "a precedence window could not be filled")
+
+
+def run_rolling_episode(blocks, positions, initial_container_size, policy, container_width, container_height,
+                        child_graph_size=10, reward_type='C+P+S-lb-soft', heightmap_type='diff',
+                        packing_strategy='LB_GREEDY', record=False):
+    """rolling.validate's loop for a batch (rolling.py:589-637 around DRL.forward(one_step),
+    rolling.py:294-460): N - child windows of ONE decoding step each, then a full episode on the
+    last window; one long-lived target container per instance.
+
+    ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
+    -> ptr (B,) int64 as in rollout.run_episode.  Returns dict(tour (B, N) of window-local picks,
+    nodes (B, N) global block ids in packing order, reward, env)."""
+    from . import pack as tpack
+    rw = RollingWindows(blocks, positions, initial_container_size, child_graph_size)
+    B, N, D, child = rw.B, rw.N, rw.D, rw.child
+    dev = rw.device
+    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    env = BatchedContainer(B, cs, N, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
+    decoder_static = torch.zeros(B, D, 1, device=dev)
+    decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
+    ar = torch.arange(B, device=dev)
+    tour, picked, feats = [], [], []
+    ptr, ratio, step = None, None, 0
+    for _ in range(N - child):                                   # one_step windows
+        win = rw.next(ptr)
+        ones = torch.ones_like(win['current_mask'])
+        ptr = policy(step=step, static=win['static'], dynamic=win['dynamic'], current_mask=win['current_mask'],
+                     mask=ones, decoder_static=decoder_static, decoder_dynamic=decoder_dynamic).to(torch.int64)
+        decoder_static = torch.gather(win['static'][:, 1:, :], 2, ptr.view(-1, 1, 1).expand(-1, D, 1))
+        decoder_dynamic = env.add_new_blocks_gather(win['static'], ptr)
+        tour.append(ptr.unsqueeze(1)); picked.append(win['nodes'][ar, ptr % child].unsqueeze(1))
+        if record:
+            feats.append(decoder_dynamic)
+        step += 1
+    win = rw.next(ptr)                                           # last graph: a whole episode on it
+    assert rw.is_last_graph()
+    tpack._shadow_put(win['dynamic'], win['colsum'])
+    trans = EnvTransition(win['static'], win['dynamic'], env)
+    for t in range(child):
+        ptr = policy(step=step, static=trans.static, dynamic=trans.dynamic, current_mask=trans.current_mask,
+                     mask=trans.mask, decoder_static=decoder_static, decoder_dynamic=decoder_dynamic).to(torch.int64)
+        decoder_static = torch.gather(trans.static[:, 1:, :], 2, ptr.view(-1, 1, 1).expand(-1, D, 1))
+        _, _, _, decoder_dynamic, r = trans.step(ptr, fresh=False, want_ratio=(t == child - 1))
+        ratio = r if r is not None else ratio
+        tour.append(ptr.unsqueeze(1)); picked.append(win['nodes'][ar, ptr % child].unsqueeze(1))
+        if record:
+            feats.append(decoder_dynamic)
+        step += 1
+    out = dict(tour_idx=torch.cat(tour, 1), nodes=torch.cat(picked, 1), reward=-ratio, env=env, windows=rw)
+    if record:
+        out['features'] = feats
+    return out

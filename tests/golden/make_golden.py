@@ -15,9 +15,11 @@ Fixtures:
   episode_2d.npz, episode_3d.npz     reference DRL.forward (pretrained actor, greedy) traces
   reward_tour.npz                    pack.reward on those tours
   kat.npz                            hand-checkable known answers
+  rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
 """
 import argparse
 import itertools
+import math
 import os
 import sys
 import tempfile
@@ -317,6 +319,45 @@ def make_kat(tools):
     save("kat.npz", **out)
 
 
+def make_rolling(tools, generate):
+    """generate.InitialContainer (generate.py:1589-1839) driven like rolling.validate
+    (rolling.py:589-637): windows of 10 nodes over 50-/24-block instances, random feasible picks."""
+    out = {}
+    cases = []
+    rng = np.random.RandomState(77)
+    for D, N, child, init, count in ((2, 50, 10, [7, 250], 6), (3, 50, 10, [7, 7, 250], 4),
+                                     (2, 24, 6, [6, 120], 6), (3, 20, 5, [5, 5, 100], 4)):
+        R = math.factorial(D)
+        for c in range(count):
+            np.random.seed(1000 * D + 10 * N + c)
+            rot_blocks, positions, _, _, _ = generate.generate_blocks(N, list(init), 1, [1, 5])
+            blocks_all = np.asarray(rot_blocks).reshape(R, D, N).transpose(0, 2, 1).reshape(R * N, D)  # rolling.py:484-486
+            pos = np.asarray(positions).reshape(D, N).T                                               # rolling.py:491-492
+            ic = generate.InitialContainer(blocks_all, pos, N, list(init), True, child, 'bot')
+            statics, dynamics, nodes, ptrs = [], [], [], []
+            while True:
+                static, dynamic = ic.convert_to_input()
+                statics.append(static.astype(np.int16)); dynamics.append(dynamic.astype(np.int8))
+                nodes.append(np.asarray(ic.sub_graph_nodes, dtype=np.int16))
+                if ic.is_last_graph():
+                    break
+                move = dynamic[:child].sum(0); small = dynamic[child:2 * child].sum(0); large = dynamic[2 * child:].sum(0)
+                ok = np.flatnonzero((small * large + move) == 0)
+                ptr = int(rng.choice(ok))
+                ptrs.append(ptr)
+                ic.remove_block(ic.sub_graph_nodes[ptr % child])
+            tag = "r%d" % len(cases)
+            cases.append(repr(dict(D=D, N=N, child=child, init=list(init))))
+            out[tag + "_blocks"] = blocks_all[:N].astype(np.int8)
+            out[tag + "_pos"] = pos.astype(np.int16)
+            out[tag + "_static"] = np.asarray(statics)
+            out[tag + "_dynamic"] = np.asarray(dynamics)
+            out[tag + "_nodes"] = np.asarray(nodes)
+            out[tag + "_ptr"] = np.asarray(ptrs, dtype=np.int16)
+    out["cases"] = np.asarray(cases)
+    save("rolling.npz", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
@@ -324,7 +365,7 @@ def main():
     mods = ref_loader.load()
     if mods is None:
         sys.exit("reference checkout not found at %s" % ref_loader.REFERENCE_DIR)
-    tools, pack, _ = mods
+    tools, pack, generate = mods
     import torch
     torch.manual_seed(0)
     want = lambda k: args.only is None or k in args.only  # noqa: E731
@@ -333,6 +374,7 @@ def main():
     if want("macs2d"): make_macs2d(tools)
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
+    if want("rolling"): make_rolling(tools, generate)
     if want("data"):
         with tempfile.TemporaryDirectory() as tmp:
             statics, dynamics, tours = {}, {}, {}

@@ -71,6 +71,11 @@ def lib():
         L.orc_reward.argtypes = [C.POINTER(Desc), C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_instance_from_blocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.orc_rolling_new.restype = C.c_void_p
+        L.orc_rolling_new.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_rolling_free.argtypes = [C.c_void_p]
+        L.orc_rolling_window.argtypes = [C.c_void_p] * 4
+        L.orc_rolling_remove.argtypes = [C.c_void_p, C.c_int]
         L.orc_initial_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_update_dynamic.argtypes = [C.c_int] * 6 + [C.c_void_p] * 4
         L.orc_update_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
@@ -275,3 +280,30 @@ def instance_from_blocks(blocks, init_size, arm_size=1):
     dyn = np.zeros((3 * n, n * R), np.float32)
     rc = lib().orc_instance_from_blocks(D, _p(cs), n, arm_size, _p(blocks), _p(pos), _p(st), _p(dyn))
     return rc, pos, st, dyn
+
+
+class Rolling:
+    """generate.InitialContainer backed by the oracle."""
+
+    def __init__(self, blocks, positions, init_size, child):
+        blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+        positions = np.ascontiguousarray(positions, dtype=np.int32)
+        self.N, self.D = blocks.shape
+        self.child, self.R = child, (2 if self.D == 2 else 6)
+        cs = np.ascontiguousarray(init_size, dtype=np.int32)
+        self._h = lib().orc_rolling_new(self.D, _p(cs), self.N, child, _p(blocks), _p(positions))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_rolling_free(self._h)
+            self._h = None
+
+    def convert_to_input(self):
+        st = np.zeros((1 + self.D, self.child * self.R), np.float32)
+        dy = np.zeros((3 * self.child, self.child * self.R), np.float32)
+        nodes = np.zeros(self.child, np.int32)
+        rc = lib().orc_rolling_window(self._h, _p(st), _p(dy), _p(nodes))
+        return rc, st, dy, nodes
+
+    def remove(self, local_index):
+        lib().orc_rolling_remove(self._h, int(local_index))

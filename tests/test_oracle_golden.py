@@ -172,3 +172,22 @@ def test_instance_generation_from_reference_datasets(D):
         assert np.array_equal(pos, pos_txt[b].T), b
         assert np.array_equal(st, ds["static"][b].astype(np.float32)), b
         assert np.array_equal(dyn, ds["dynamic"][b].astype(np.float32)), b
+
+
+def test_rolling_windows():
+    """generate.InitialContainer window traces (the outer loop of rolling.py)."""
+    import ast
+    z = G.load("rolling.npz")
+    for i, m in enumerate(z["cases"]):
+        meta = ast.literal_eval(str(m))
+        tag = "r%d_" % i
+        ro = O.Rolling(z[tag + "blocks"], z[tag + "pos"], meta["init"], meta["child"])
+        T = z[tag + "static"].shape[0]
+        for t in range(T):
+            rc, st, dy, nodes = ro.convert_to_input()
+            assert rc == (1 if t == T - 1 else 0), (i, t, rc)
+            assert np.array_equal(nodes, z[tag + "nodes"][t]), (i, t)
+            assert np.array_equal(st, z[tag + "static"][t].astype(np.float32)), (i, t)
+            assert np.array_equal(dy, z[tag + "dynamic"][t].astype(np.float32)), (i, t)
+            if t < T - 1:
+                ro.remove(int(z[tag + "ptr"][t]) % meta["child"])
