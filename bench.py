@@ -33,6 +33,9 @@ HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARC
 
 # nodes of one precedence window (rolling.py feeds the actor 10-node sub-graphs)
 WINDOW = {"c5": 10}
+# configs whose pass is rolling.validate's loop: N - 10 one-step windows re-cut from the precedence DAG
+# after every placement (tap_rolling_window + tap_env_step_gather), then a full episode on the last one
+ROLLING = {"c5"}
 
 CONFIGS = {
     # name: (workload string, D, container, n, per-GPU batch, reward, strategy)
@@ -133,6 +136,66 @@ class HotPath(object):
             self._k("ratio", L.tap_env_ratio, self.ctx, d, P(e._state), P(self.reward), None, None)
 
 
+class RollingHotPath(HotPath):
+    """c5: true rolling windows over device-generated 50-block instances (initial container
+    7x7x250 as scripts/rolling.sh); actions replayed from a tape recorded with a random feasible
+    policy."""
+
+    def __init__(self, cfg, B, start, device, seed=12345, window=10):
+        _, D, cs, n, _, reward, strategy = cfg
+        self.D, self.cs, self.n, self.B, self.device, self.nw = D, cs, n, B, device, window
+        self.fused, self.hook, self.rolling = True, None, True
+        self.lib, self.ctx = _lib.lib(), _lib.ctx(device)
+        init = [7, 250] if D == 2 else [7, 7, 250]
+        _, _, blocks, positions = T.generate.generate_instances(B, n, D, init[0], init[-1], 1, (1, 5),
+                                                                seed=seed + start, device=device, return_aux=True)
+        g = torch.Generator(device=device)
+        g.manual_seed(seed + 1 + start)
+        rec = T.run_rolling_episode(blocks, positions, init,
+                                    lambda current_mask, **_: torch.multinomial(current_mask, 1, generator=g).squeeze(1),
+                                    cs[0], cs[-1], child_graph_size=window, reward_type=reward)
+        rec["env"].check()
+        self.tape = rec["tour_idx"].t().contiguous()             # (n, B)
+        self.rw = rec["windows"]                                 # holds blocks + relation masks
+        self.env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=device)
+        self.R = 2 if D == 2 else 6
+        self.nR, self.rows = window * self.R, 3 * window
+        f32 = dict(dtype=torch.float32, device=device)
+        self.static = torch.empty(B, 1 + D, self.nR, **f32)
+        self.dyn = [torch.empty(B, self.rows, self.nR, **f32) for _ in range(3)]
+        self.csb = [torch.empty(B, 3, self.nR, **f32) for _ in range(3)]
+        self.mask0 = torch.ones(B, self.nR, **f32)
+        self.maskb = [torch.empty(B, self.nR, **f32), torch.empty(B, self.nR, **f32)]
+        self.cur = torch.empty(B, self.nR, **f32)
+        self.feat = torch.empty(self.env._feature_shape(), **f32)
+        self.reward = torch.empty(B, **f32)
+        self.state = torch.zeros(B, 2, dtype=torch.int64, device=device)
+        self.want = rec["reward"].clone()
+
+    def episode(self):
+        L, P, e, rw = self.lib, _lib.ptr, self.env, self.rw
+        d = C.byref(e.desc)
+        self.state.zero_()
+        self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
+        n1 = self.n - self.nw
+        for t in range(n1 + 1):                                   # one window per placement (+ the last graph)
+            prev = P(self.tape[t - 1]) if t > 0 else None
+            self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
+                    P(rw.blocks), P(rw.rel), P(self.state), prev, P(self.static), P(self.dyn[2]), P(self.csb[2]),
+                    P(self.cur), None, None)
+            if t < n1:
+                self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(self.static),
+                        self.static.shape[1], self.nR, P(self.tape[t]), None, P(self.feat))
+        dyn_in, cs_in, mask_in = self.dyn[2], self.csb[2], self.mask0
+        for t in range(self.nw):                                  # the last graph: a whole episode
+            o = t & 1
+            flags = _lib.TAP_T_RATIO if t == self.nw - 1 else 0
+            self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.nw, self.R, self.rows, 3,
+                    P(dyn_in), P(self.static), self.static.shape[1], P(self.tape[n1 + t]), P(mask_in), P(cs_in),
+                    P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
+            dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
+
+
 def time_passes(hp, steps, warmup, use_graph, world):
     dev = hp.device
     handles = []
@@ -190,10 +253,11 @@ def kernel_event_times(hp, steps, graph=None):
         recs.setdefault(name, []).append((a, b))
 
     pass_pairs = []
-    hp.hook = None if hp.fused else hook
+    pure = hp.fused and not getattr(hp, 'rolling', False)
+    hp.hook = None if pure else hook
     try:
         for _ in range(steps):
-            if hp.fused:
+            if pure:
                 # the pass is n back-to-back launches of ONE kernel: bracket the pass and divide, so the
                 # event overhead is amortised and the figure is comparable with rocprofv3's average
                 a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
@@ -209,7 +273,7 @@ def kernel_event_times(hp, steps, graph=None):
         torch.cuda.synchronize(hp.device)
     finally:
         hp.hook = None
-    if hp.fused:
+    if pure:
         us = np.array([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3 / hp.n
         recs = None
     # cost of an empty event pair, to show how much of a short kernel's figure is event overhead
@@ -267,6 +331,50 @@ def cpu_baseline(cfg, window=None, budget_s=12.0):
                        "oracle/libtap_oracle.so single thread" % (done // (B * n), B, n, el))
 
 
+def cpu_baseline_rolling(cfg, window, budget_s=12.0):
+    """The oracle over rolling.validate's loop (windows re-cut after every placement), one host core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    _, D, cs, n, B, reward, strategy = cfg
+    init = [7, 250] if D == 2 else [7, 7, 250]
+    rng = np.random.RandomState(1)
+    blocks = synth.rand_blocks(64, n, D, seed=777)
+    inst = []
+    for b in range(64):                      # instances = blocks the oracle's generator restatement accepts
+        rc, pos, _, _ = O.instance_from_blocks(blocks[b], init, 1)
+        if rc == 1:
+            inst.append((blocks[b], pos))
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for bl, pos in inst:
+            ro = O.Rolling(bl, pos, init, window)
+            e = O.Env(cs, n, reward, "diff", strategy)
+            for t in range(n - window + 1):
+                rc, st, dy, nodes = ro.convert_to_input()
+                cur = O.initial_mask(dy[None], window)[0]
+                if t == n - window:
+                    break
+                p = int(rng.choice(np.flatnonzero(cur)))
+                e.add_new_block(st[1:, p])
+                ro.remove(p % window)
+            mask = np.ones((1, st.shape[1]), np.float32)
+            dyn = dy[None]
+            for t in range(window):
+                p = np.array([rng.choice(np.flatnonzero(cur))], dtype=np.int64)
+                e.add_new_block(st[1:, int(p[0])])
+                dyn = O.update_dynamic(dyn, st[None], p, window, 3)
+                c2, mask = O.update_mask(mask, dyn, p, window, st.shape[1] // window)
+                cur = c2[0]
+            e.calc_ratio()
+            done += n
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            break
+    return dict(value=done / el, unit="env-steps/s", cores=1, kind="port",
+                sample="%d rolling episodes of %d placements (window %d) over %d oracle-generated instances, %.1f s, "
+                       "oracle/libtap_oracle.so single thread driven per step from Python" % (done // n, n, window, len(inst), el))
+
+
 def load_traffic(name):
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(p):
@@ -288,6 +396,8 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
+    ap.add_argument("--approx-windows", action="store_true",
+                    help="c5: consecutive independent 10-node windows instead of true rolling windows")
     args = ap.parse_args()
 
     rank, world, local = tdist.init_from_env()
@@ -302,7 +412,11 @@ def main():
     if args.batch:
         B = args.batch
         cfg = (name, D, cs, n, B, reward, strategy)
-    hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config))
+    rolling = args.config in ROLLING and not args.approx_windows
+    if rolling:
+        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config])
+    else:
+        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config))
     use_graph = not args.no_graph
     dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
     hp.env.check()
@@ -311,10 +425,13 @@ def main():
 
     out = None
     if rank == 0:
-        kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)), graph if hp.fused else None)
+        kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)), graph if (hp.fused and not rolling) else None)
         env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
-        per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B}
-        names = [k for k in ("transition", "mask_step", "env_step", "ratio", "reset") if k in kt]
+        R_ = 2 if D == 2 else 6
+        win_b = (1 + D) * hp.nw * R_ * 4 + 3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 4 + 32   # static + dynamic + mask + state
+        per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B,
+                      "rolling_window": win_b * B}
+        names = [k for k in ("transition", "rolling_window", "mask_step", "env_step", "ratio", "reset") if k in kt]
         dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
         ach = per_launch[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
         npass = max(3, min(args.steps, 20))
@@ -332,7 +449,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy,
-                       "pass": ("n x tap_transition (update_dynamic+update_mask+gather+add_new_block in one launch; "
+                       "pass": ("rolling.validate's loop: (n - window) x (tap_rolling_window + tap_env_step_gather), then "
+                                "window x tap_transition on the last graph") if rolling else
+                               ("n x tap_transition (update_dynamic+update_mask+gather+add_new_block in one launch; "
                                 "first starts a fresh container, last emits calc_ratio)") if hp.fused else
                                "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
                        "launch": "hipGraph replay" if use_graph else "eager"},
@@ -344,7 +463,7 @@ def main():
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, WINDOW.get(args.config))
+            out["cpu_baseline"] = cpu_baseline_rolling(cfg, WINDOW[args.config]) if rolling else cpu_baseline(cfg, WINDOW.get(args.config))
         if args.sweep:
             for b in (8192, 32768, 131072, 524288, 2097152):
                 try:

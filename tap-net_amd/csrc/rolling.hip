@@ -162,6 +162,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
     __shared__ int s_ord[TAP_BLOCK / 64][64];   // sub-graph node order (matrix index -> node)
     __shared__ int s_pos[TAP_BLOCK / 64][64];   // node -> matrix index
     __shared__ int s_tbl[TAP_BLOCK / 64][2 * PYSET_CAP];
+    __shared__ int s_srt[TAP_BLOCK / 64][64];   // sorted position -> node
+    __shared__ u64 s_side[TAP_BLOCK / 64][5][64]; // column masks by sub-graph index
     const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
     const int inst = blockIdx.x * (TAP_BLOCK / 64) + w;
     if (inst >= a.B) return;
@@ -222,44 +224,59 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
         a.state[(size_t)inst * 2 + 1] = window;
         if (a.err_out) a.err_out[inst] = short_window;
     }
-    if (short_window || !(window & bit)) return;
+    if (short_window) return;
 
-    // (4) tensors (generate.py:1778-1822): this lane owns window node v
-    const int slot = __popcll(window & below);      // sorted position  -> static column
-    const int midx = s_pos[w][v];                   // sub-graph index   -> dynamic row / column
+    // (4) tensors (generate.py:1778-1822).  Window-node lanes publish their five column masks (with
+    //     the :1690-1705 rule: a blocker that has not entered any window yet => the side counts as
+    //     self-blocked) by sub-graph index; then ALL 64 lanes write the tensors element-wise with
+    //     consecutive addresses, so every store instruction covers 256 contiguous bytes.
     const u64 after = all & ~entered;               // after_nodes_list
-    // :1690-1705 a blocker that has not entered any window yet => the side counts as self-blocked
-    u64 side[5];
-    side[0] = rel[0] & window;
+    if (window & bit) {
+        const int midx = s_pos[w][v];
+        s_side[w][0][midx] = rel[0] & window;
 #pragma unroll
-    for (int k = 1; k < 5; ++k) side[k] = (rel[k] & window) | ((rel[k] & after) ? bit : 0ull);
+        for (int k = 1; k < 5; ++k) s_side[w][k][midx] = (rel[k] & window) | ((rel[k] & after) ? bit : 0ull);
+        s_srt[w][__popcll(window & below)] = v;     // sorted position -> node (static's column order)
+        if (a.nodes_out) a.nodes_out[(size_t)inst * child + __popcll(window & below)] = v;
+    }
+    tap_wave_lds_sync();
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
     float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
-    const int32_t *blk = a.blocks + ((size_t)inst * N + v) * D;
-    if (a.nodes_out) a.nodes_out[(size_t)inst * child + slot] = v;
-    for (int r = 0; r < R; ++r) {
+    // which side pair guards rotation r (:1808-1821): the axis that becomes vertical
+    auto side_of = [&](int r, int sec) -> int {
         const int *p = D == 2 ? perm2[r] : perm3[r];
-        const int scol = r * child + slot, dcol = r * child + midx;
-        st[scol] = (float)slot;                                                   // :1795-1801
-        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + scol] = (float)blk[p[k]];
-        u64 small = 0, large = 0;                                                 // :1808-1821
-        if (p[D - 1] == 0) { small = side[1]; large = side[2]; }
-        else if (D == 3 && p[D - 1] == 1) { small = side[3]; large = side[4]; }
-        for (int i = 0; i < child; ++i) {
-            const int node = s_ord[w][i];
-            dy[(size_t)i * nRc + dcol] = (float)((side[0] >> node) & 1);
-            dy[(size_t)(child + i) * nRc + dcol] = (float)((small >> node) & 1);
-            dy[(size_t)(2 * child + i) * nRc + dcol] = (float)((large >> node) & 1);
-        }
-        const float ms = (float)__popcll(side[0]), ss = (float)__popcll(small), ls = (float)__popcll(large);
-        if (a.colsum_out) {
-            float *cs = a.colsum_out + (size_t)inst * 3 * nRc;
-            cs[dcol] = ms; cs[nRc + dcol] = ss; cs[2 * nRc + dcol] = ls;
+        if (sec == 0) return 0;
+        if (p[D - 1] == 0) return sec;              // left / right
+        if (D == 3 && p[D - 1] == 1) return 2 + sec; // forward / backward
+        return -1;                                   // up / down: empty
+    };
+    // lane = column (r, cm); rows are walked in order, so each store instruction writes one row
+    // segment of up to 64 consecutive floats and nothing is divided per element
+    for (int col = v; col < nRc; col += 64) {
+        const int r = col / child, cm = col - r * child;
+        const int *p = D == 2 ? perm2[r] : perm3[r];
+        const int32_t *blk = a.blocks + ((size_t)inst * N + s_srt[w][cm]) * D;  // static: cm = sorted slot
+        st[col] = (float)cm;                                                      // :1795-1801
+        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)blk[p[k]];
+        u64 m[3];
+        float sum[3];
+#pragma unroll
+        for (int sec = 0; sec < 3; ++sec) {
+            const int k = side_of(r, sec);
+            m[sec] = k < 0 ? 0ull : s_side[w][k][cm];                             // dynamic: cm = sub-graph index
+            sum[sec] = (float)__popcll(m[sec]);
+            if (a.colsum_out) a.colsum_out[((size_t)inst * 3 + sec) * nRc + col] = sum[sec];
         }
         if (a.cur_mask_out)                                                       // model.py:297-307
-            a.cur_mask_out[(size_t)inst * nRc + dcol] = (ss * ls + ms != 0.f) ? 0.f : 1.f;
+            a.cur_mask_out[(size_t)inst * nRc + col] = (sum[1] * sum[2] + sum[0] != 0.f) ? 0.f : 1.f;
+        for (int rm = 0; rm < child; ++rm) {
+            const int node = s_ord[w][rm];
+#pragma unroll
+            for (int sec = 0; sec < 3; ++sec)
+                dy[(size_t)(sec * child + rm) * nRc + col] = (float)((m[sec] >> node) & 1ull);
+        }
     }
 }
 
