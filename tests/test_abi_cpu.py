@@ -100,3 +100,24 @@ def test_packdataset_layout(tmp_path):
         s, dy, ds_, dd = ds[3]
         assert s.shape == (1 + D, 10 * (2 if D == 2 else 6)) and dy.shape[0] == 30
         assert len(ds) == N
+
+
+def test_dataset_files_round_trip(tmp_path):
+    """f4: tensors -> the reference's six text files -> back.  The files must equal, value for value,
+    the ones the reference wrote for the same instances (kept in the golden fixture)."""
+    import golden_util as G
+    from tap_net_amd import datafiles
+    for D, N in ((2, 256), (3, 64)):
+        z = G.load("dataset_%dd.npz" % D)
+        n = 10
+        pos = z["txt_pos"].reshape(N, D, n).transpose(0, 2, 1)
+        d = str(tmp_path / ("w%d" % D)) + "/"
+        datafiles.write_dataset(d, z["static"], z["dynamic"], pos, container_ids=z["txt_container"])
+        for k in ("blocks", "pos", "container", "dep_move", "dep_small", "dep_large"):
+            got = np.loadtxt(d + k + ".txt").astype(np.int8)
+            assert np.array_equal(got, z["txt_" + k]), (D, k)
+        ds = T.PACKDataset(d, n, N, 1, "bot", "diff", True, 5)
+        assert np.array_equal(ds.static.numpy(), z["static"].astype(np.float32))
+        assert np.array_equal(ds.dynamic.numpy(), z["dynamic"].astype(np.float32))
+        raw = datafiles.read_raw(d, n, D)
+        assert raw["blocks"].shape == (N, 2 if D == 2 else 6, D, n)
