@@ -141,10 +141,10 @@ class RollingHotPath(HotPath):
     7x7x250 as scripts/rolling.sh); actions replayed from a tape recorded with a random feasible
     policy."""
 
-    def __init__(self, cfg, B, start, device, seed=12345, window=10):
+    def __init__(self, cfg, B, start, device, seed=12345, window=10, fused_rolling=False):
         _, D, cs, n, _, reward, strategy = cfg
         self.D, self.cs, self.n, self.B, self.device, self.nw = D, cs, n, B, device, window
-        self.fused, self.hook, self.rolling = True, None, True
+        self.fused, self.hook, self.rolling, self.fused_rolling = True, None, True, fused_rolling
         self.lib, self.ctx = _lib.lib(), _lib.ctx(device)
         init = [7, 250] if D == 2 else [7, 7, 250]
         _, _, blocks, positions = T.generate.generate_instances(B, n, D, init[0], init[-1], 1, (1, 5),
@@ -162,6 +162,7 @@ class RollingHotPath(HotPath):
         self.nR, self.rows = window * self.R, 3 * window
         f32 = dict(dtype=torch.float32, device=device)
         self.static = torch.empty(B, 1 + D, self.nR, **f32)
+        self.static2 = torch.empty(B, 1 + D, self.nR, **f32)
         self.dyn = [torch.empty(B, self.rows, self.nR, **f32) for _ in range(3)]
         self.csb = [torch.empty(B, 3, self.nR, **f32) for _ in range(3)]
         self.mask0 = torch.ones(B, self.nR, **f32)
@@ -178,20 +179,28 @@ class RollingHotPath(HotPath):
         self.state.zero_()
         self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
         n1 = self.n - self.nw
-        for t in range(n1 + 1):                                   # one window per placement (+ the last graph)
-            prev = P(self.tape[t - 1]) if t > 0 else None
-            self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
-                    P(rw.blocks), P(rw.rel), P(self.state), prev, P(self.static), P(self.dyn[2]), P(self.csb[2]),
-                    P(self.cur), None, None)
-            if t < n1:
-                self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(self.static),
+        st = [self.static, self.static2]
+        self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
+                P(rw.blocks), P(rw.rel), P(self.state), None, P(st[0]), P(self.dyn[2]), P(self.csb[2]),
+                P(self.cur), None, None)
+        for t in range(n1):
+            if self.fused_rolling:                                # placement t + window t+1: one launch
+                self._k("rolling_step", L.tap_rolling_step, self.ctx, d, P(e._state), self.n, self.nw, P(rw.blocks),
+                        P(rw.rel), P(self.state), P(self.tape[t]), P(st[t & 1]), P(st[(t + 1) & 1]), P(self.dyn[2]),
+                        P(self.csb[2]), P(self.cur), None, None, P(self.feat))
+            else:                                                 # measured 4 % faster at B = 8192 (occupancy)
+                self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st[t & 1]),
                         self.static.shape[1], self.nR, P(self.tape[t]), None, P(self.feat))
+                self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
+                        P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
+                        P(self.csb[2]), P(self.cur), None, None)
+        self.static_last = st[n1 & 1]
         dyn_in, cs_in, mask_in = self.dyn[2], self.csb[2], self.mask0
         for t in range(self.nw):                                  # the last graph: a whole episode
             o = t & 1
             flags = _lib.TAP_T_RATIO if t == self.nw - 1 else 0
             self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.nw, self.R, self.rows, 3,
-                    P(dyn_in), P(self.static), self.static.shape[1], P(self.tape[n1 + t]), P(mask_in), P(cs_in),
+                    P(dyn_in), P(self.static_last), self.static.shape[1], P(self.tape[n1 + t]), P(mask_in), P(cs_in),
                     P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
             dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
 
@@ -396,6 +405,7 @@ def main():
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
+    ap.add_argument("--fused-rolling", action="store_true", help="c5: tap_rolling_step instead of env_step + rolling_window")
     ap.add_argument("--approx-windows", action="store_true",
                     help="c5: consecutive independent 10-node windows instead of true rolling windows")
     args = ap.parse_args()
@@ -414,7 +424,7 @@ def main():
         cfg = (name, D, cs, n, B, reward, strategy)
     rolling = args.config in ROLLING and not args.approx_windows
     if rolling:
-        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config])
+        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=args.fused_rolling)
     else:
         hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config))
     use_graph = not args.no_graph
@@ -430,8 +440,8 @@ def main():
         R_ = 2 if D == 2 else 6
         win_b = (1 + D) * hp.nw * R_ * 4 + 3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 4 + 32   # static + dynamic + mask + state
         per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B,
-                      "rolling_window": win_b * B}
-        names = [k for k in ("transition", "rolling_window", "mask_step", "env_step", "ratio", "reset") if k in kt]
+                      "rolling_window": win_b * B, "rolling_step": (win_b + env_b) * B}
+        names = [k for k in ("transition", "rolling_step", "rolling_window", "mask_step", "env_step", "ratio", "reset") if k in kt]
         dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
         ach = per_launch[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
         npass = max(3, min(args.steps, 20))
@@ -449,8 +459,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy,
-                       "pass": ("rolling.validate's loop: (n - window) x (tap_rolling_window + tap_env_step_gather), then "
-                                "window x tap_transition on the last graph") if rolling else
+                       "pass": ("rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window) "
+                                "[or tap_rolling_step with --fused-rolling], then window x tap_transition on the last graph") if rolling else
                                ("n x tap_transition (update_dynamic+update_mask+gather+add_new_block in one launch; "
                                 "first starts a fresh container, last emits calc_ratio)") if hp.fused else
                                "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",

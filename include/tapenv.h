@@ -193,6 +193,16 @@ int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32
                        float *static_out, float *dynamic_out, float *colsum_out,
                        float *current_mask_out, int32_t *nodes_out, int32_t *err_out, void *stream);
 
+/* One decoding step of rolling.validate in one launch: add_new_block for the column `ptr` picked
+ * in the CURRENT window (block gathered from static_cur, the tensor tap_rolling_window / _step
+ * wrote last) fused with remove_block + convert_to_input() for the NEXT window (written to
+ * static_next, which must be a different buffer).  feature_out as in tap_env_step.  LB_GREEDY. */
+int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
+                     const int32_t *blocks, const uint64_t *rel, uint64_t *state, const int64_t *ptr,
+                     const float *static_cur, float *static_next, float *dynamic_out,
+                     float *colsum_out, float *current_mask_out, int32_t *nodes_out,
+                     int32_t *err_out, float *feature_out, void *stream);
+
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) --------------------------- */
 /* dynamic is (B, rows, nR) f32 with rows = 3n ('bot', 'mul') or n ('simple', 'rot'); nR = n*R.
  * colsum is a (B, 3, nR) f32 shadow of the three per-section column sums of a dynamic tensor

@@ -19,6 +19,7 @@
 // once fill*5 >= mask*3.
 #include "tap_common.h"
 #include "tap_place.h"
+#include "tap_waves.h"
 
 struct RollArgs {
     int B, D, N, child, W, L, H, arm;
@@ -155,17 +156,19 @@ __device__ inline void pyset_order(const int *keys, int n, int *order, int *tbl,
 }
 
 // ---- one window step: remove, top up, cut sub-graphs, emit tensors ----------------------------------
+struct RollLds {          // one wavefront's scratch
+    int lst[64];          // sub_graph_nodes in list order
+    int ord[64];          // sub-graph node order (matrix index -> node)
+    int pos[64];          // node -> matrix index
+    int srt[64];          // sorted position -> node
+    int tbl[2 * PYSET_CAP];
+    u64 side[5][64];      // column masks by sub-graph index
+};
+
+// one wavefront = one instance, lane v = node v; every lane of the wave must call this
 template <int D>
-__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
+__device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
 {
-    __shared__ int s_lst[TAP_BLOCK / 64][64];   // sub_graph_nodes in list order
-    __shared__ int s_ord[TAP_BLOCK / 64][64];   // sub-graph node order (matrix index -> node)
-    __shared__ int s_pos[TAP_BLOCK / 64][64];   // node -> matrix index
-    __shared__ int s_tbl[TAP_BLOCK / 64][2 * PYSET_CAP];
-    __shared__ int s_srt[TAP_BLOCK / 64][64];   // sorted position -> node
-    __shared__ u64 s_side[TAP_BLOCK / 64][5][64]; // column masks by sub-graph index
-    const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
-    const int inst = blockIdx.x * (TAP_BLOCK / 64) + w;
     if (inst >= a.B) return;
     const int N = a.N, child = a.child;
     constexpr int R = D == 2 ? 2 : 6;
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
     // (2) top the window up: in-degree-0 nodes of gm_copy, layer by layer, ascending ids
     //     (generate.py:1724-1750); list order = old window (sorted by the previous call) + appended
     int count = __popcll(window);
-    if (window & bit) s_lst[w][__popcll(window & below)] = v;
+    if (window & bit) S.lst[__popcll(window & below)] = v;
     u64 added = 0;
     while (count < child) {
         const u64 gmc = all & ~(entered | added);                    // nodes still in gm_copy
@@ -199,7 +202,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
         if (fm == 0) break;
         const int need = child - count;
         const bool take = free_ && __popcll(fm & below) < need;
-        if (take) s_lst[w][count + __popcll(fm & below)] = v;
+        if (take) S.lst[count + __popcll(fm & below)] = v;
         const u64 tm = __ballot(take);
         added |= tm;
         count += __popcll(tm);
@@ -211,12 +214,12 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
 
     // (3) node order of the induced sub-graphs (:1684-1688, 1758-1761)
     if (2 * child < N) {
-        if (v == 0 && !short_window) pyset_order(s_lst[w], child, s_ord[w], s_tbl[w], s_tbl[w] + PYSET_CAP);
+        if (v == 0 && !short_window) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
     } else if (window & bit) {
-        s_ord[w][__popcll(window & below)] = v;
+        S.ord[__popcll(window & below)] = v;
     }
     tap_wave_lds_sync();
-    if (v < child && !short_window) s_pos[w][s_ord[w][v]] = v;
+    if (v < child && !short_window) S.pos[S.ord[v]] = v;
     tap_wave_lds_sync();
 
     if (v == 0) {
@@ -232,11 +235,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
     //     consecutive addresses, so every store instruction covers 256 contiguous bytes.
     const u64 after = all & ~entered;               // after_nodes_list
     if (window & bit) {
-        const int midx = s_pos[w][v];
-        s_side[w][0][midx] = rel[0] & window;
+        const int midx = S.pos[v];
+        S.side[0][midx] = rel[0] & window;
 #pragma unroll
-        for (int k = 1; k < 5; ++k) s_side[w][k][midx] = (rel[k] & window) | ((rel[k] & after) ? bit : 0ull);
-        s_srt[w][__popcll(window & below)] = v;     // sorted position -> node (static's column order)
+        for (int k = 1; k < 5; ++k) S.side[k][midx] = (rel[k] & window) | ((rel[k] & after) ? bit : 0ull);
+        S.srt[__popcll(window & below)] = v;     // sorted position -> node (static's column order)
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + __popcll(window & below)] = v;
     }
     tap_wave_lds_sync();
@@ -257,7 +260,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
     for (int col = v; col < nRc; col += 64) {
         const int r = col / child, cm = col - r * child;
         const int *p = D == 2 ? perm2[r] : perm3[r];
-        const int32_t *blk = a.blocks + ((size_t)inst * N + s_srt[w][cm]) * D;  // static: cm = sorted slot
+        const int32_t *blk = a.blocks + ((size_t)inst * N + S.srt[cm]) * D;  // static: cm = sorted slot
         st[col] = (float)cm;                                                      // :1795-1801
         for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)blk[p[k]];
         u64 m[3];
@@ -265,19 +268,58 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
 #pragma unroll
         for (int sec = 0; sec < 3; ++sec) {
             const int k = side_of(r, sec);
-            m[sec] = k < 0 ? 0ull : s_side[w][k][cm];                             // dynamic: cm = sub-graph index
+            m[sec] = k < 0 ? 0ull : S.side[k][cm];                             // dynamic: cm = sub-graph index
             sum[sec] = (float)__popcll(m[sec]);
             if (a.colsum_out) a.colsum_out[((size_t)inst * 3 + sec) * nRc + col] = sum[sec];
         }
         if (a.cur_mask_out)                                                       // model.py:297-307
             a.cur_mask_out[(size_t)inst * nRc + col] = (sum[1] * sum[2] + sum[0] != 0.f) ? 0.f : 1.f;
         for (int rm = 0; rm < child; ++rm) {
-            const int node = s_ord[w][rm];
+            const int node = S.ord[rm];
 #pragma unroll
             for (int sec = 0; sec < 3; ++sec)
                 dy[(size_t)(sec * child + rm) * nRc + col] = (float)((m[sec] >> node) & 1ull);
         }
     }
+}
+
+
+template <int D>
+__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
+{
+    __shared__ RollLds S[TAP_BLOCK / 64];
+    const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
+    rolling_window_wave<D>(a, blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
+}
+
+// ---- fused rolling step: add_new_block for the column picked in the CURRENT window (gathered from
+//      its static tensor) and the NEXT window, in one launch.  Both depend only on that pick, so the
+//      placement waves (lane-per-cell groups, tap_waves.h) and the window waves (one per instance)
+//      of a workgroup run side by side, as in tap_transition.
+struct RollStepArgs {
+    RollArgs r;
+    StepArgs s;
+};
+
+template <int D, int G>
+__global__ void __launch_bounds__((64 * (4 + 4 * G / 64 + (4 * G % 64 ? 1 : 0)))) k_rolling_step(RollStepArgs a)
+{
+    constexpr int EPB = 4;                                  // instances per workgroup
+    constexpr int ENV_WAVES = (EPB * G + 63) / 64;
+    __shared__ RollLds S[EPB];
+    __shared__ int s_old[64 * ENV_WAVES];
+    __shared__ int s_new[64 * ENV_WAVES];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int base = blockIdx.x * EPB;
+    if (wave < ENV_WAVES) {
+        __builtin_amdgcn_s_setprio(2);
+        const int cell = tid % G, grp = tid / G;
+        // groups beyond EPB (when EPB*G is not a multiple of 64) idle on an out-of-range env
+        const int env = grp < EPB ? base + grp : a.s.d.B;
+        tap_lb_place_wave<D, G>(a.s, 0, nullptr, env, cell, lane, s_old + (tid - cell), s_new + (tid - cell));
+        return;
+    }
+    rolling_window_wave<D>(a.r, base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
 }
 
 static int roll_check(tap_ctx *ctx, int B, int D, int N, int child)
@@ -331,4 +373,53 @@ extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, 
     else hipLaunchKernelGGL(k_rolling_window<3>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
     TAP_LAUNCH_CHECK(ctx, "k_rolling_window");
     return TAP_OK;
+}
+
+template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollStepArgs &a, hipStream_t st)
+{
+    constexpr int EPB = 4, ENV_WAVES = (EPB * G + 63) / 64, THREADS = 64 * (ENV_WAVES + EPB);
+    const int grid = (a.r.B + EPB - 1) / EPB;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL((k_rolling_step<D, G>), dim3(grid), dim3(THREADS), 0, st, a);
+    TAP_LAUNCH_CHECK(ctx, "k_rolling_step");
+    return TAP_OK;
+}
+
+extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
+                                const int32_t *blocks, const uint64_t *rel, uint64_t *state,
+                                const int64_t *ptr, const float *static_cur, float *static_next,
+                                float *dynamic_out, float *colsum_out, float *current_mask_out,
+                                int32_t *nodes_out, int32_t *err_out, float *feature_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: LB_GREEDY only");
+    rc = roll_check(ctx, d->B, d->D, N, child);
+    if (rc) return rc;
+    if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||
+        static_cur == static_next)
+        return tap_fail(ctx, TAP_E_INVALID, "bad rolling_step arguments (static_cur and static_next must differ)");
+    RollStepArgs a = {};
+    const int R = d->D == 2 ? 2 : 6;
+    a.r.B = d->B; a.r.D = d->D; a.r.N = N; a.r.child = child; a.r.blocks = blocks;
+    a.r.rel = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(rel));
+    a.r.state = reinterpret_cast<unsigned long long *>(state);
+    a.r.remove_ptr = ptr; a.r.static_out = static_next; a.r.dynamic_out = dynamic_out;
+    a.r.colsum_out = colsum_out; a.r.cur_mask_out = current_mask_out; a.r.nodes_out = nodes_out; a.r.err_out = err_out;
+    a.s.d = *d;
+    tap_env_layout(d, env_state, &a.s.v);
+    a.s.static_ = static_cur; a.s.static_rows = 1 + d->D; a.s.nR = child * R; a.s.ptr = ptr;
+    a.s.feature_out = feature_out; a.s.flen = tap_env_feature_len(d);
+    const int Gs = tap_group_size(d);
+    hipStream_t st = (hipStream_t)stream;
+    if (d->D == 2) {
+        if (Gs == 8) return launch_rolling_step<2, 8>(ctx, a, st);
+        if (Gs == 16) return launch_rolling_step<2, 16>(ctx, a, st);
+        if (Gs == 32) return launch_rolling_step<2, 32>(ctx, a, st);
+        return launch_rolling_step<2, 64>(ctx, a, st);
+    }
+    if (Gs == 8) return launch_rolling_step<3, 8>(ctx, a, st);
+    if (Gs == 16) return launch_rolling_step<3, 16>(ctx, a, st);
+    if (Gs == 32) return launch_rolling_step<3, 32>(ctx, a, st);
+    return launch_rolling_step<3, 64>(ctx, a, st);
 }

@@ -1,0 +1,75 @@
+// tap_waves.h -- the "placement wave" shared by the fused kernels (transition.hip, rolling.hip):
+// the lanes of one wavefront carry 64/G lane-per-cell groups, each stepping one container with
+// tools.Container.add_new_block (LB_GREEDY) on a block gathered from `static` (model.py:404-465),
+// optionally from a fresh container and optionally emitting calc_ratio (model.py:499-510).
+#pragma once
+
+#include "tap_common.h"
+#include "tap_place.h"
+
+// env: this group's container; cell / lane: lane index inside the group / the wave;
+// g_old, g_new: the group's two G-int LDS slices.  Every lane of the wave must call this.
+template <int D, int G>
+__device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, float *ratio_out,
+                                                  int env, int cell, int lane, int *g_old, int *g_new)
+{
+    const int W = s.d.W, L = s.d.L, cells = W * L;
+    const bool fresh = flags & TAP_T_FRESH;
+    const int B = s.d.B;
+    const bool ev = env < B, incell = cell < cells;
+    int hm = 0, cv = 0, dims[3] = {1, 1, 1};
+    if (ev) {
+        if (!fresh) {
+            if (incell) hm = s.v.hm[(size_t)env * cells + cell];
+            if (cell < 4) cv = s.v.cnt[(size_t)env * 4 + cell];
+        }
+        const long p = (long)s.ptr[env];
+        for (int k = 0; k < D; ++k) // model.py:404-412
+            dims[k] = (int)s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
+    }
+    const int gl0 = lane - cell;
+    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
+    const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
+    int err = 0;
+    bool do_step = ev;
+    if (ev && cnt.count >= s.d.n_max) { err |= 2; do_step = false; }
+    if (ev && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
+    g_old[cell] = hm;
+    tap_wave_lds_sync();
+    const PlaceCfg cfg = {W, L, s.d.H, s.d.flags};
+    const int step = cnt.count;
+    const Placement pl = tap_place<D, G>(cfg, g_old, cell, hm, cnt, err, bx, by, bz, do_step);
+    err = group_or<G>(err);
+    g_new[cell] = hm;
+    tap_wave_lds_sync();
+    const int gmax = (flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
+    if (ev) {
+        if (incell) s.v.hm[(size_t)env * cells + cell] = hm;
+        if (s.feature_out)
+            tap_write_feature<D, G>(s.d.feature, W, L, g_new, cell, hm,
+                                    s.feature_out + (size_t)env * s.flen);
+        if (cell == 0) {
+            if (do_step || fresh)
+                reinterpret_cast<int4 *>(s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+            if (do_step) {
+                int32_t *q = s.v.pos + (size_t)step * D * B + env;
+                q[0] = pl.x;
+                if (D == 3) { q[B] = pl.y; q[2 * (size_t)B] = pl.z; } else q[B] = pl.z;
+                s.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
+            }
+            if (fresh) s.v.err[env] = err;
+            else if (err) s.v.err[env] |= err;
+            if (flags & TAP_T_RATIO) { // tools.py:3887-3966 on the state just written
+                double C = 0.0, P = 0.0, S = 0.0;
+                if (cnt.count != 0) {
+                    C = (double)cnt.valid / (double)((long long)W * L * gmax);
+                    P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
+                    S = (double)cnt.nstable / (double)cnt.count;
+                }
+                ratio_out[env] = (float)tap_ratio_formula(s.d.ratio_mode, C, P, S);
+            }
+        }
+    } else if (s.d.feature == TAP_FEAT_ZERO) {
+        (void)group_min<G>(INT_MAX);
+    }
+}

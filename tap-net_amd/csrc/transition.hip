@@ -20,6 +20,7 @@
 #include "tap_macs.h"
 #include "tap_masks.h"
 #include "tap_place.h"
+#include "tap_waves.h"
 
 struct TransArgs {
     StepArgs s;   // placement (always the gather form: s.static_, s.ptr)
@@ -77,7 +78,6 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     __shared__ int s_new[64 * ENV_WAVES];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
-    const int B = a.s.d.B;
 
     if (wave >= ENV_WAVES) {
         trans_stream_wave<SPW, FAST>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
@@ -87,66 +87,9 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
 
     // ---- placement waves (tools.py:3663-3744): their latency chain runs beside the stream --------
     __builtin_amdgcn_s_setprio(2);
-    const int W = a.s.d.W, L = a.s.d.L, cells = W * L;
-    const bool fresh = a.flags & TAP_T_FRESH;
     const int cell = tid % G;
-    const int env = env_base + tid / G;
-    const bool ev = env < B, incell = cell < cells;
-    int hm = 0, cv = 0, dims[3] = {1, 1, 1};
-    if (ev) {
-        if (!fresh) {
-            if (incell) hm = a.s.v.hm[(size_t)env * cells + cell];
-            if (cell < 4) cv = a.s.v.cnt[(size_t)env * 4 + cell];
-        }
-        const long p = (long)a.s.ptr[env];
-        for (int k = 0; k < D; ++k) // model.py:404-412
-            dims[k] = (int)a.s.static_[((size_t)env * a.s.static_rows + 1 + k) * a.s.nR + p];
-    }
-    const int gl0 = lane - cell;
-    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
-    const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
-    int err = 0;
-    bool do_step = ev;
-    if (ev && cnt.count >= a.s.d.n_max) { err |= 2; do_step = false; }
-    if (ev && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
-    s_old[tid] = hm;
-    tap_wave_lds_sync();
-    const PlaceCfg cfg = {W, L, a.s.d.H, a.s.d.flags};
-    const int step = cnt.count;
-    const Placement pl = tap_place<D, G>(cfg, s_old + (tid - cell), cell, hm, cnt, err, bx, by, bz, do_step);
-    err = group_or<G>(err);
-    s_new[tid] = hm;
-    tap_wave_lds_sync();
-    const int gmax = (a.flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
-    if (ev) {
-        if (incell) a.s.v.hm[(size_t)env * cells + cell] = hm;
-        if (a.s.feature_out)
-            tap_write_feature<D, G>(a.s.d.feature, W, L, s_new + (tid - cell), cell, hm,
-                                    a.s.feature_out + (size_t)env * a.s.flen);
-        if (cell == 0) {
-            if (do_step || fresh)
-                reinterpret_cast<int4 *>(a.s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
-            if (do_step) {
-                int32_t *q = a.s.v.pos + (size_t)step * D * B + env;
-                q[0] = pl.x;
-                if (D == 3) { q[B] = pl.y; q[2 * (size_t)B] = pl.z; } else q[B] = pl.z;
-                a.s.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
-            }
-            if (fresh) a.s.v.err[env] = err;
-            else if (err) a.s.v.err[env] |= err;
-            if (a.flags & TAP_T_RATIO) { // tools.py:3887-3966 on the state just written
-                double C = 0.0, P = 0.0, S = 0.0;
-                if (cnt.count != 0) {
-                    C = (double)cnt.valid / (double)((long long)W * L * gmax);
-                    P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
-                    S = (double)cnt.nstable / (double)cnt.count;
-                }
-                a.ratio_out[env] = (float)tap_ratio_formula(a.s.d.ratio_mode, C, P, S);
-            }
-        }
-    } else if (a.s.d.feature == TAP_FEAT_ZERO) {
-        (void)group_min<G>(INT_MAX);
-    }
+    tap_lb_place_wave<D, G>(a.s, a.flags, a.ratio_out, env_base + tid / G, cell, lane,
+                            s_old + (tid - cell), s_new + (tid - cell));
 }
 
 // ---- the same fusion for MACS / MUL 2D (tap_macs.h): G = 8/16 lanes per env ---------------------

@@ -66,6 +66,31 @@ class RollingWindows(object):
         self._err = err
         return dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, current_mask=cur)
 
+    def step(self, ptr, env, static_cur, want_masks=True, want_feature=True):
+        """One decoding step in ONE launch (tap_rolling_step): place the block picked in the current
+        window (column ``ptr`` of ``static_cur``) into ``env`` and build the next window.
+        -> (feature, next-window dict)."""
+        f32 = dict(dtype=torch.float32, device=self.device)
+        nRc = self.child * self.R
+        static = torch.empty(self.B, 1 + self.D, nRc, **f32)
+        dynamic = torch.empty(self.B, 3 * self.child, nRc, **f32)
+        nodes = torch.empty(self.B, self.child, dtype=torch.int32, device=self.device)
+        colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks else None
+        cur = torch.empty(self.B, nRc, **f32) if want_masks else None
+        err = torch.zeros(self.B, dtype=torch.int32, device=self.device)
+        feat = env._new_feature() if want_feature else None
+        ptr = ptr.to(device=self.device, dtype=torch.int64).contiguous()
+        static_cur = static_cur.contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().tap_rolling_step(
+                self._ctx, C.byref(env.desc), _lib.ptr(env._state), self.N, self.child, _lib.ptr(self.blocks),
+                _lib.ptr(self.rel), _lib.ptr(self.state), _lib.ptr(ptr), _lib.ptr(static_cur), _lib.ptr(static),
+                _lib.ptr(dynamic), _lib.ptr(colsum), _lib.ptr(cur), _lib.ptr(nodes), _lib.ptr(err), _lib.ptr(feat),
+                _lib.stream_of(self.device)), self._ctx)
+        self.steps_done += 1
+        self._err = err
+        return feat, dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, current_mask=cur)
+
     def check(self):
         if int(self._err.sum().item()):
             raise _lib.TapError(_lib.TAP_E_INVALID, "a precedence window could not be filled")
@@ -73,7 +98,7 @@ class RollingWindows(object):
 
 def run_rolling_episode(blocks, positions, initial_container_size, policy, container_width, container_height,
                         child_graph_size=10, reward_type='C+P+S-lb-soft', heightmap_type='diff',
-                        packing_strategy='LB_GREEDY', record=False):
+                        packing_strategy='LB_GREEDY', record=False, fused=True):
     """rolling.validate's loop for a batch (rolling.py:589-637 around DRL.forward(one_step),
     rolling.py:294-460): N - child windows of ONE decoding step each, then a full episode on the
     last window; one long-lived target container per instance.
@@ -91,20 +116,24 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
     decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
     ar = torch.arange(B, device=dev)
     tour, picked, feats = [], [], []
+    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY
     ptr, ratio, step = None, None, 0
+    win = rw.next(None)
     for _ in range(N - child):                                   # one_step windows
-        win = rw.next(ptr)
         ones = torch.ones_like(win['current_mask'])
         ptr = policy(step=step, static=win['static'], dynamic=win['dynamic'], current_mask=win['current_mask'],
                      mask=ones, decoder_static=decoder_static, decoder_dynamic=decoder_dynamic).to(torch.int64)
         decoder_static = torch.gather(win['static'][:, 1:, :], 2, ptr.view(-1, 1, 1).expand(-1, D, 1))
-        decoder_dynamic = env.add_new_blocks_gather(win['static'], ptr)
         tour.append(ptr.unsqueeze(1)); picked.append(win['nodes'][ar, ptr % child].unsqueeze(1))
+        if fused:                                                # placement + next window: one launch
+            decoder_dynamic, win = rw.step(ptr, env, win['static'])
+        else:
+            decoder_dynamic = env.add_new_blocks_gather(win['static'], ptr)
+            win = rw.next(ptr)
         if record:
             feats.append(decoder_dynamic)
         step += 1
-    win = rw.next(ptr)                                           # last graph: a whole episode on it
-    assert rw.is_last_graph()
+    assert rw.is_last_graph()                                    # `win` is the last graph: a whole episode on it
     tpack._shadow_put(win['dynamic'], win['colsum'])
     trans = EnvTransition(win['static'], win['dynamic'], env)
     for t in range(child):
