@@ -2,6 +2,7 @@
 // feature, ratio, export, check, and the whole-episode reward kernel.  gfx950 only.
 #include "tap_common.h"
 #include "tap_place.h"
+#include "tap_waves.h"
 
 // =============================================================================================
 // context / descriptor (host)
@@ -133,66 +134,13 @@ extern "C" int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, v
 template <int D, int G>
 __global__ void __launch_bounds__(TAP_BLOCK) k_env_step(StepArgs a)
 {
+    // every wave is a placement wave (tap_waves.h); lane groups never span a wave, so there is no
+    // workgroup barrier
     __shared__ int s_old[TAP_BLOCK];
     __shared__ int s_new[TAP_BLOCK];
-    const int tid = threadIdx.x, grp = tid / G, cell = tid % G;
-    const int env = blockIdx.x * (TAP_BLOCK / G) + grp;
-    const int B = a.d.B, W = a.d.W, L = a.d.L, cells = W * L;
-    const bool ev = env < B, incell = cell < cells;
-    const int gl0 = (tid & 63) - cell; // first lane of this group inside the wave
-
-    int hm = (ev && incell) ? a.v.hm[(size_t)env * cells + cell] : 0;
-    const int cv = (ev && cell < 4) ? a.v.cnt[(size_t)env * 4 + cell] : 0;
-    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
-
-    int dims[3] = {1, 1, 1};
-    bool act = ev;
-    if (ev) {
-        if (a.static_) { // gather of model.py:404-412
-            const long p = (long)a.ptr[env];
-            for (int k = 0; k < D; ++k)
-                dims[k] = (int)a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
-        } else if (a.blocks_dtype == TAP_DT_F32) {
-            for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)a.blocks)[(size_t)env * D + k];
-        } else {
-            for (int k = 0; k < D; ++k) dims[k] = ((const int32_t *)a.blocks)[(size_t)env * D + k];
-        }
-        if (a.active) act = a.active[env] != 0;
-    }
-    const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
-
-    int err = 0;
-    bool do_step = act;
-    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }       // tools.py:3677 IndexError
-    if (act && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
-
-    s_old[tid] = hm;
-    __syncthreads();
-    const PlaceCfg cfg = {W, L, a.d.H, a.d.flags};
-    const int step = cnt.count;
-    const Placement pl = tap_place<D, G>(cfg, s_old + grp * G, cell, hm, cnt, err, bx, by, bz, do_step);
-    err = group_or<G>(err);
-
-    s_new[tid] = hm;
-    __syncthreads();
-    if (ev) {
-        if (incell) a.v.hm[(size_t)env * cells + cell] = hm;
-        if (a.feature_out)
-            tap_write_feature<D, G>(a.d.feature, W, L, s_new + grp * G, cell, hm,
-                                    a.feature_out + (size_t)env * a.flen);
-        if (cell == 0) {
-            if (do_step) {
-                reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
-                int32_t *pp = a.v.pos + (size_t)step * D * B + env;
-                pp[0] = pl.x;
-                if (D == 3) { pp[B] = pl.y; pp[2 * (size_t)B] = pl.z; } else pp[B] = pl.z;
-                a.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
-            }
-            if (err) a.v.err[env] |= err;
-        }
-    } else if (a.d.feature == TAP_FEAT_ZERO) {
-        (void)group_min<G>(INT_MAX); // keep the cross-lane op convergent for tail groups
-    }
+    const int tid = threadIdx.x, cell = tid % G;
+    tap_lb_place_wave<D, G>(a, 0, nullptr, blockIdx.x * (TAP_BLOCK / G) + tid / G, cell, tid & 63,
+                            s_old + (tid - cell), s_new + (tid - cell));
 }
 
 template <int D, int G> static int launch_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)

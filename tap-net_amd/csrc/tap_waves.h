@@ -1,6 +1,7 @@
 // tap_waves.h -- the "placement wave" shared by the fused kernels (transition.hip, rolling.hip):
 // the lanes of one wavefront carry 64/G lane-per-cell groups, each stepping one container with
-// tools.Container.add_new_block (LB_GREEDY) on a block gathered from `static` (model.py:404-465),
+// tools.Container.add_new_block (LB_GREEDY) on a block given directly or gathered from `static`
+// (model.py:404-465),
 // optionally from a fresh container and optionally emitting calc_ratio (model.py:499-510).
 #pragma once
 
@@ -23,17 +24,25 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
             if (incell) hm = s.v.hm[(size_t)env * cells + cell];
             if (cell < 4) cv = s.v.cnt[(size_t)env * 4 + cell];
         }
-        const long p = (long)s.ptr[env];
-        for (int k = 0; k < D; ++k) // model.py:404-412
-            dims[k] = (int)s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
+        if (s.static_) { // gather of model.py:404-412
+            const long p = (long)s.ptr[env];
+            for (int k = 0; k < D; ++k)
+                dims[k] = (int)s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
+        } else if (s.blocks_dtype == TAP_DT_F32) { // block.astype(int), tools.py:3689
+            for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)s.blocks)[(size_t)env * D + k];
+        } else {
+            for (int k = 0; k < D; ++k) dims[k] = ((const int32_t *)s.blocks)[(size_t)env * D + k];
+        }
     }
+    // `active` = 0: the 'mul' input types' idle container -- untouched, only reports its feature
+    const bool act = ev && (!s.active || s.active[env] != 0);
     const int gl0 = lane - cell;
     Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
     const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
     int err = 0;
-    bool do_step = ev;
-    if (ev && cnt.count >= s.d.n_max) { err |= 2; do_step = false; }
-    if (ev && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
+    bool do_step = act;
+    if (act && cnt.count >= s.d.n_max) { err |= 2; do_step = false; }  // tools.py:3677 IndexError
+    if (act && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
     g_old[cell] = hm;
     tap_wave_lds_sync();
     const PlaceCfg cfg = {W, L, s.d.H, s.d.flags};
