@@ -3,7 +3,8 @@
 
 One "step" = one full pass of the hot path over one batch of synthetic instances:
     reset -> n x [ update_dynamic + update_mask (one launch) ; add_new_block (one launch) ]
-          -> calc_ratio (one launch) [-> all-gather of the (B,) reward vector when N > 1]
+          -> calc_ratio (one launch) [-> when N > 1, the (B,) reward vectors of 8 consecutive passes
+             are all-gathered with one RCCL call]
 i.e. what DRL.forward does around its policy network for one batch (model.py:294-515), with the
 actions replayed from a pre-computed feasible tape.  value = env-steps/s = (placements in all
 envs on all ranks) / wall time, inputs resident in HBM before the timed region.
@@ -205,19 +206,40 @@ class RollingHotPath(HotPath):
             dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
 
 
+GATHER_EVERY = 8   # passes whose (B,) reward vectors share one RCCL all-gather (fewer, larger collectives)
+
+
 def time_passes(hp, steps, warmup, use_graph, world):
     dev = hp.device
     handles = []
+    acc = torch.empty(GATHER_EVERY, hp.B, dtype=torch.float32, device=dev) if world > 1 else None
+    state = {"i": 0}
+
+    def flush(count):
+        import torch.distributed as dist
+        buf = acc[:count].clone()                              # the only exchange of the whole job
+        out = [torch.empty_like(buf) for _ in range(world)]
+        handles.append((dist.all_gather(out, buf, async_op=True), out))
 
     def one_pass(g):
         if g is not None:
             g.replay()
         else:
             hp.episode()
-        if world > 1:                                           # the only exchange: the reward vector
-            import torch.distributed as dist
-            out = [torch.empty_like(hp.reward) for _ in range(world)]
-            handles.append((dist.all_gather(out, hp.reward, async_op=True), out))
+        if world > 1:
+            acc[state["i"]].copy_(hp.reward)
+            state["i"] += 1
+            if state["i"] == GATHER_EVERY:
+                flush(GATHER_EVERY)
+                state["i"] = 0
+
+    def drain():
+        if world > 1 and state["i"]:
+            flush(state["i"])
+            state["i"] = 0
+        for h, _ in handles:
+            h.wait()
+        handles.clear()
 
     graph = None
     if use_graph:
@@ -232,16 +254,13 @@ def time_passes(hp, steps, warmup, use_graph, world):
             hp.episode()
     for _ in range(warmup):
         one_pass(graph)
-    for h, _ in handles:
-        h.wait()
-    handles.clear()
+    drain()
     tdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
         one_pass(graph)
-    for h, _ in handles:
-        h.wait()
+    drain()
     torch.cuda.synchronize(dev)
     tdist.barrier()
     dt = time.perf_counter() - t0
@@ -415,6 +434,7 @@ def main():
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libtapenv has no CPU path")
+    local = local % torch.cuda.device_count()   # > 1 rank per GPU only happens in the gloo self-test
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cfg = CONFIGS[args.config]
