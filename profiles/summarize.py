@@ -46,7 +46,8 @@ with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.csv" % (tag, cfg)), 
         w.writerow([k, m.get("calls_FETCH_SIZE", 0), "%.3f" % fs, "%.3f" % ws, int((2 * fs + ws) * 1024)])
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-short = {"k_mask_step": "mask_step", "k_env_step": "env_step", "k_transition": "transition"}
+short = {"k_mask_step": "mask_step", "k_env_step": "env_step", "k_transition": "transition",
+         "k_rolling_window": "rolling_window", "k_rolling_step": "rolling_step", "k_macs2d_step": "macs_step"}
 for k, m in means.items():
     for pat, name in short.items():
         if pat in k:
