@@ -1,0 +1,61 @@
+"""Live comparison of the host-side mirror (PACKDataset, file format) with the imported reference.
+Build container only; skipped wherever /root/reference is absent."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import ref_loader
+import tap_net_amd as T
+from tap_net_amd import datafiles
+
+pytestmark = [pytest.mark.reference,
+              pytest.mark.skipif(not ref_loader.available(), reason="reference checkout not present")]
+
+
+@pytest.fixture(scope="module")
+def dirs(tmp_path_factory):
+    out = {}
+    for D, N in ((2, 256), (3, 64)):
+        z = G.load("dataset_%dd.npz" % D)
+        pos = z["txt_pos"].reshape(N, D, 10).transpose(0, 2, 1)
+        d = str(tmp_path_factory.mktemp("ds%d" % D)) + "/"
+        datafiles.write_dataset(d, z["static"], z["dynamic"], pos, container_ids=z["txt_container"])
+        # a second, different directory (samples reversed) to exercise mix_data_file
+        d2 = str(tmp_path_factory.mktemp("mix%d" % D)) + "/"
+        datafiles.write_dataset(d2, z["static"][::-1], z["dynamic"][::-1], pos[::-1], container_ids=z["txt_container"][::-1])
+        out[D] = (d, d2, N)
+    return out
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("input_type,allow_rot", [("bot", True), ("bot", False), ("simple", False), ("rot", True),
+                                                  ("bot-rot", True), ("mul", True), ("mul-with", True), ("rot-old", True)])
+def test_packdataset_matches_reference(dirs, D, input_type, allow_rot):
+    pack = ref_loader.load()[1]
+    d, d2, N = dirs[D]
+    for hm_type in ("diff", "full"):
+        for mix in (None, d2):
+            try:
+                ref = pack.PACKDataset(d, 10, N, 7, input_type, hm_type, allow_rot, 5, mix_data_file=mix, unit=1)
+            except Exception as e:      # e.g. 'bot' without rotations: the reference cannot build it either
+                with pytest.raises(type(e)):
+                    T.PACKDataset(d, 10, N, 7, input_type, hm_type, allow_rot, 5, mix_data_file=mix, unit=1)
+                continue
+            mine = T.PACKDataset(d, 10, N, 7, input_type, hm_type, allow_rot, 5, mix_data_file=mix, unit=1)
+            assert torch.equal(ref.static, mine.static), (input_type, allow_rot, hm_type, mix is not None)
+            assert torch.equal(ref.dynamic, mine.dynamic)
+            assert ref.decoder_static.shape == mine.decoder_static.shape
+            assert ref.decoder_dynamic.shape == mine.decoder_dynamic.shape
+            assert len(ref) == len(mine)
+            for a, b in zip(ref[5], mine[5]):
+                assert torch.equal(a, b)
+
+
+def test_no_precedence_and_unit(dirs):
+    pack = ref_loader.load()[1]
+    d, _, N = dirs[2]
+    ref = pack.PACKDataset(d, 10, N, 3, "bot", "diff", True, 5, unit=0.5, no_precedence=True)
+    mine = T.PACKDataset(d, 10, N, 3, "bot", "diff", True, 5, unit=0.5, no_precedence=True)
+    assert torch.equal(ref.static, mine.static) and torch.equal(ref.dynamic, mine.dynamic)
+    assert ref.decoder_dynamic.shape == mine.decoder_dynamic.shape
