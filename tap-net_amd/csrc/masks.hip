@@ -32,10 +32,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_colsum(int B, int n, int nR, 
 }
 
 // ---- fused step: copy-with-zeroed-rows + incremental column sums + both masks ----------------
-// FAST = stream_wave_fast (nR % 4 == 0, nR <= 64, aligned, full update); otherwise the generic
+// NC > 0 = stream_wave_fast with NC columns per lane (nR % 4 == 0, nR <= 256, aligned, shadow
+// given); NC == 0 = the generic
 // element-wise path, which also serves tap_update_mask (no copy) and tap_update_dynamic without a
 // shadow.
-template <bool FAST>
+template <int NC>
 __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
 {
     extern __shared__ float mask_lds[];
@@ -43,9 +44,9 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     const int env = blockIdx.x * ENVS_PER_BLOCK + wave;
     const int lane = threadIdx.x % WAVE;
     if (env >= a.B) return;
-    if (FAST) {
+    if (NC > 0) {
         const bool on[1] = {true};
-        stream_wave_fast<1, 6>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
+        stream_wave_fast<1, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         return;
     }
     const int nR = a.nR;
@@ -70,11 +71,12 @@ static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)
 {
     const int grid = (a.B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
-    if (mask_fast_path_ok(a)) {
-        const size_t lds = (size_t)ENVS_PER_BLOCK * 3 * a.nR * sizeof(float);
-        hipLaunchKernelGGL(k_mask_step<true>, dim3(grid), dim3(TAP_BLOCK), lds, st, a);
-    } else {
-        hipLaunchKernelGGL(k_mask_step<false>, dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    const size_t lds = (size_t)ENVS_PER_BLOCK * 3 * a.nR * sizeof(float);
+    switch (mask_fast_path_cols(a)) {
+    case 1: hipLaunchKernelGGL(k_mask_step<1>, dim3(grid), dim3(TAP_BLOCK), lds, st, a); break;
+    case 2: hipLaunchKernelGGL(k_mask_step<2>, dim3(grid), dim3(TAP_BLOCK), lds, st, a); break;
+    case 4: hipLaunchKernelGGL(k_mask_step<4>, dim3(grid), dim3(TAP_BLOCK), lds, st, a); break;
+    default: hipLaunchKernelGGL(k_mask_step<0>, dim3(grid), dim3(TAP_BLOCK), 0, st, a); break;
     }
     TAP_LAUNCH_CHECK(ctx, "k_mask_step");
     return TAP_OK;

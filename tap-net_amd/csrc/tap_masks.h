@@ -90,9 +90,9 @@ __device__ __forceinline__ void mask_env(const MaskArgs &a, int env, int lane, l
 //     compiler can count them (no vmcnt(0) stalls) and a wave has U KiB in flight;
 //   * the rows being cleared are captured into a wave-private LDS tile on their way through the
 //     registers, so "new sum = old sum - cleared row" needs no second read of the slab.
-// Requirements (checked by the caller): nR % 4 == 0, 16-byte aligned tensors, nR <= 64.
-// lds: NS * 3 * nR floats private to this wave.
-template <int NS, int U>
+// Requirements (checked by the caller): nR % 4 == 0, 16-byte aligned tensors, nR <= 64 * NC.
+// lds: NS * 3 * nR floats private to this wave.  NC = columns per lane (1, 2 or 4).
+template <int NS, int U, int NC>
 __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, int lane,
                                                  const bool (&on)[NS], float *lds)
 {
@@ -103,18 +103,21 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
 #pragma unroll
     for (int k = 0; k < NS; ++k) if (on[k]) total = (k + 1) * nchunk; // on[] is a prefix
     if (total == 0) return;
-    const bool col = lane < nR;
     long p[NS];
-    float row0[NS], cs[NS][3], keep[NS];
+    float row0[NS][NC], cs[NS][NC][3], keep[NS][NC];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int env = senv0 + k;
-        const bool ok = on[k];
-        p[k] = ok ? (long)a.ptr[env] : 0;
-        row0[k] = (ok && col) ? a.static_[(size_t)env * a.static_rows * nR + lane] : 0.f;
-        keep[k] = (ok && col) ? (a.mask_in ? a.mask_in[(size_t)env * nR + lane] : 1.f) : 0.f;
+        p[k] = on[k] ? (long)a.ptr[env] : 0;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) cs[k][s] = (ok && col) ? a.cs_in[((size_t)env * 3 + s) * nR + lane] : 0.f;
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            const bool ok = on[k] && j < nR;
+            row0[k][c] = ok ? a.static_[(size_t)env * a.static_rows * nR + j] : 0.f;
+            keep[k][c] = ok ? (a.mask_in ? a.mask_in[(size_t)env * nR + j] : 1.f) : 0.f;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) cs[k][c][s] = ok ? a.cs_in[((size_t)env * 3 + s) * nR + j] : 0.f;
+        }
     }
     for (int i = lane; i < NS * 3 * nR; i += 64) lds[i] = 0.f;
 
@@ -129,8 +132,13 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
         if (!have_real) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                const long real = (long)__shfl(row0[k], (int)(p[k] & 63));    // pack.py:339
-                cr[k] = clear_ranges(a, on[k] ? real : -1);
+                float r0 = 0.f;                                               // pack.py:339 via shuffle
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const float t = __shfl(row0[k][c], (int)(p[k] & 63));
+                    if ((p[k] >> 6) == c) r0 = t;
+                }
+                cr[k] = clear_ranges(a, on[k] ? (long)r0 : -1);
             }
             have_real = true;
         }
@@ -155,27 +163,34 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        if (!(on[k] && col)) continue;
+        if (!on[k]) continue;
         const int env = senv0 + k;
         long real_m = p[k];
         while (real_m >= a.n) real_m -= a.n;                                  // pack.py:314-316
-        float sum[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            sum[s] = cs[k][s] - lds[(k * 3 + s) * nR + lane];
-            if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + lane] = sum[s];
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            if (j >= nR) continue;
+            float sum[3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                sum[s] = cs[k][c][s] - lds[(k * 3 + s) * nR + j];
+                if (a.cs_out) a.cs_out[((size_t)env * 3 + s) * nR + j] = sum[s];
+            }
+            float kp = keep[k][c];
+            for (int r = 0; r < a.R; ++r)
+                if (j == real_m + (long)a.n * r) kp = 0.f;                    // pack.py:320-321
+            if (a.mask_out) a.mask_out[(size_t)env * nR + j] = kp;
+            const float dm = sum[1] * sum[2] + sum[0];                        // pack.py:327-328
+            if (a.cur_out) a.cur_out[(size_t)env * nR + j] = dm != 0.f ? 0.f : kp; // pack.py:329
         }
-        float kp = keep[k];
-        for (int r = 0; r < a.R; ++r)
-            if (lane == real_m + (long)a.n * r) kp = 0.f;                     // pack.py:320-321
-        if (a.mask_out) a.mask_out[(size_t)env * nR + lane] = kp;
-        const float dm = sum[1] * sum[2] + sum[0];                            // pack.py:327-328
-        if (a.cur_out) a.cur_out[(size_t)env * nR + lane] = dm != 0.f ? 0.f : kp; // pack.py:329
     }
 }
 
-inline bool mask_fast_path_ok(const MaskArgs &a)
+// columns per lane the fast path needs: 1, 2 or 4; 0 = use the generic element-wise path
+inline int mask_fast_path_cols(const MaskArgs &a)
 {
-    return a.dyn_out && a.ptr && a.static_ && a.cs_in && (a.nR % 4 == 0) && a.nR <= 64 && a.rows >= 1 &&
-           ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
+    const bool ok = a.dyn_out && a.ptr && a.static_ && a.cs_in && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 &&
+                    ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
+    return !ok ? 0 : a.nR <= 64 ? 1 : a.nR <= 128 ? 2 : 4;
 }

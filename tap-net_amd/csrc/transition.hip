@@ -31,14 +31,14 @@ struct TransArgs {
 
 // ---- a stream wave: out-of-place copy of SPW consecutive slabs with the chosen rows cleared
 //      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
-template <int SPW, bool FAST>
+template <int SPW, int NC>
 __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
 {
     bool on[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
-    if (FAST) {
-        stream_wave_fast<SPW, 6>(m, senv0, lane, on, lds);
+    if (NC > 0) {
+        stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         return;
     }
     const size_t slab = (size_t)m.rows * m.nR;
@@ -68,7 +68,7 @@ template <int G, int SW> struct TransGeom {
     static constexpr int THREADS = 64 * (ENV_WAVES + STREAM_WAVES);
 };
 
-template <int D, int G, bool FAST, int SW>
+template <int D, int G, int NC, int SW>
 __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TransArgs a)
 {
     using Geo = TransGeom<G, SW>;
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     const int env_base = blockIdx.x * EPB;
 
     if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, FAST>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+        trans_stream_wave<SPW, NC>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
         return;
     }
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
 }
 
 // ---- the same fusion for MACS / MUL 2D (tap_macs.h): G = 8/16 lanes per env ---------------------
-template <int G, bool FAST>
+template <int G, int NC>
 __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(TransArgs a)
 {
     using Geo = TransGeom<G, 4>;
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
     const int env_base = blockIdx.x * EPB;
     const int B = a.s.d.B, W = a.s.d.W, H = a.s.d.H;
     if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, FAST>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+        trans_stream_wave<SPW, NC>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
         return;
     }
@@ -186,8 +186,12 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
                        (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max) * sizeof(int);
     if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
-    if (mask_fast_path_ok(a.m)) hipLaunchKernelGGL((k_transition_macs<G, true>), dim3(grid), dim3(THREADS), lds, st, a);
-    else hipLaunchKernelGGL((k_transition_macs<G, false>), dim3(grid), dim3(THREADS), lds, st, a);
+    switch (mask_fast_path_cols(a.m)) {
+    case 1: hipLaunchKernelGGL((k_transition_macs<G, 1>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_transition_macs<G, 2>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((k_transition_macs<G, 4>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_transition_macs<G, 0>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    }
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs");
     return TAP_OK;
 }
@@ -198,28 +202,19 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     constexpr int EPB = TransGeom<G, SW>::EPB, THREADS = TransGeom<G, SW>::THREADS;
     const int grid = (a.s.d.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
-    if (mask_fast_path_ok(a.m)) {
-        const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
-        hipLaunchKernelGGL((k_transition<D, G, true, SW>), dim3(grid), dim3(THREADS), lds, st, a);
-    } else {
-        hipLaunchKernelGGL((k_transition<D, G, false, SW>), dim3(grid), dim3(THREADS), 0, st, a);
+    const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
+    switch (mask_fast_path_cols(a.m)) {
+    case 1: hipLaunchKernelGGL((k_transition<D, G, 1, SW>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_transition<D, G, 2, SW>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((k_transition<D, G, 4, SW>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_transition<D, G, 0, SW>), dim3(grid), dim3(THREADS), 0, st, a); break;
     }
     TAP_LAUNCH_CHECK(ctx, "k_transition");
     return TAP_OK;
 }
 
-// TAP_TR_VARIANT (tuning knob, read once): 0 = 4 stream waves x 2 slabs (default);
-// 2 = one stream wave per slab.
-static int transition_variant()
-{
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("TAP_TR_VARIANT"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-    if (transition_variant() == 2) return launch_transition_v<D, G, 8>(ctx, a, st);
     return launch_transition_v<D, G, 4>(ctx, a, st);
 }
 

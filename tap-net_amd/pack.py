@@ -84,8 +84,10 @@ def update_dynamic(dynamic, static, chosen_idx, input_type, allow_rot):
     n = nR // R                                                                    # pack.py:367
     ptr = chosen_idx.to(torch.int64).contiguous()
     out = torch.empty_like(dyn)
-    cs_in = _shadow_get(dynamic)
-    cs_out = torch.empty_like(cs_in) if cs_in is not None else None
+    # first call of an episode: build the column-sum shadow once (one extra read of the slab) so this
+    # and every later step run the single-round-trip streaming kernel and update_mask never re-reads
+    cs_in = dynamic_colsum(dynamic, n)
+    cs_out = torch.empty_like(cs_in)
     c = _lib.ctx(dyn.device)
     with torch.cuda.device(dyn.device):
         _lib.check(_lib.lib().tap_update_dynamic(
