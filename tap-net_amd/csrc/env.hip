@@ -24,6 +24,25 @@ extern "C" const char *tap_status_string(int s)
     }
 }
 
+// one thread per (shape, mask): evaluate the hull-free predicate, set the bit
+__global__ void k_build_stab_lut(uint32_t *lut)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int off = 0;
+    for (int bx = 1; bx <= 4; ++bx)
+        for (int by = 1; by <= 4; ++by) {
+            const int count = 1 << (bx * by);
+            if (idx >= off && idx < off + count) {
+                const unsigned mc = (unsigned)(idx - off);
+                u64 m = 0; // row-major (i*by + j) -> stride-8
+                for (int i = 0; i < bx; ++i) m |= (u64)((mc >> (i * by)) & ((1u << by) - 1u)) << (8 * i);
+                if (tap_stable3d(bx, by, m)) atomicOr(&lut[idx >> 5], 1u << (idx & 31));
+                return;
+            }
+            off += count;
+        }
+}
+
 extern "C" int tap_ctx_create(int device, tap_ctx **out)
 {
     if (!out) return TAP_E_INVALID;
@@ -34,11 +53,32 @@ extern "C" int tap_ctx_create(int device, tap_ctx **out)
     tap_ctx *c = new tap_ctx();
     c->device = device;
     c->err[0] = 0;
+    c->stab_lut = nullptr;
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    bool ok = hipSetDevice(device) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&c->stab_lut), TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess &&
+              hipMemset(c->stab_lut, 0, TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_build_stab_lut, dim3((TAP_LUT_BITS + 255) / 256), dim3(256), 0, 0, c->stab_lut);
+        ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    }
+    (void)hipSetDevice(prev);
+    if (!ok) {
+        if (c->stab_lut) (void)hipFree(c->stab_lut);
+        delete c;
+        return TAP_E_HIP;
+    }
     *out = c;
     return TAP_OK;
 }
 
-extern "C" void tap_ctx_destroy(tap_ctx *ctx) { delete ctx; }
+extern "C" void tap_ctx_destroy(tap_ctx *ctx)
+{
+    if (!ctx) return;
+    if (ctx->stab_lut) (void)hipFree(ctx->stab_lut);
+    delete ctx;
+}
 
 extern "C" const char *tap_last_error(const tap_ctx *ctx) { return ctx ? ctx->err : ""; }
 
@@ -179,6 +219,7 @@ static int step_common(tap_ctx *ctx, const tap_env_desc *d, void *state, StepArg
     a.d = *d;
     tap_env_layout(d, state, &a.v);
     a.flen = tap_env_feature_len(d);
+    a.lut = ctx ? ctx->stab_lut : nullptr;
     if (d->strategy == TAP_MACS) return tap_macs2d_step(ctx, a, (hipStream_t)stream);
     TAP_DISPATCH_DG(launch_step, d, ctx, a, (hipStream_t)stream);
 }
@@ -358,6 +399,7 @@ struct EpisodeArgs {
     int static_rows, nR;
     const int64_t *tour;
     const int32_t *blocks; // (B, n, D) explicit block lists when static_ is null (tap_pack_blocks)
+    const uint32_t *lut;
     float *reward_out;
     int32_t *pos_out;
     uint8_t *stable_out;
@@ -371,7 +413,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
     const int env = blockIdx.x * (TAP_BLOCK / G) + grp;
     const int W = a.d.W, L = a.d.L, n = a.n;
     const bool ev = env < a.B, incell = cell < W * L;
-    const PlaceCfg cfg = {W, L, a.d.H, a.d.flags};
+    const PlaceCfg cfg = {W, L, a.d.H, a.d.flags, a.lut};
     int hm = 0, err = 0;
     Counters cnt = {0, 0, 0, 0};
     for (int t = 0; t < n; ++t) {
@@ -431,7 +473,7 @@ extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, in
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
     if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
         return tap_fail(ctx, TAP_E_INVALID, "bad episode arguments");
-    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, reward_out, positions_out, stable_out};
+    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out};
     TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
 }
 
@@ -443,6 +485,6 @@ extern "C" int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n
     if (rc) return rc;
     if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY only");
     if (!blocks || B < 0 || n < 1) return tap_fail(ctx, TAP_E_INVALID, "bad pack_blocks arguments");
-    EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, reward_out, positions_out, stable_out};
+    EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out};
     TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
 }

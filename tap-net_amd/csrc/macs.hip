@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_step(StepArgs a)
         }
     tap_wave_lds_sync();
     const int step = cnt.count;
-    const PlaceCfg cfg = {W, 1, H, a.d.flags};
+    const PlaceCfg cfg = {W, 1, H, a.d.flags, nullptr};
     const Placement pl = tap_macs_place<G>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
     err = group_or<G>(err);
 

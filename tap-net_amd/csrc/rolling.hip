@@ -410,6 +410,7 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     tap_env_layout(d, env_state, &a.s.v);
     a.s.static_ = static_cur; a.s.static_rows = 1 + d->D; a.s.nR = child * R; a.s.ptr = ptr;
     a.s.feature_out = feature_out; a.s.flen = tap_env_feature_len(d);
+    a.s.lut = ctx ? ctx->stab_lut : nullptr;
     const int Gs = tap_group_size(d);
     hipStream_t st = (hipStream_t)stream;
     if (d->D == 2) {

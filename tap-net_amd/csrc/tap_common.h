@@ -12,6 +12,7 @@
 
 struct tap_ctx {
     int device;
+    uint32_t *stab_lut; // device: tap_stable3d for footprints <= 4x4 (tap_place.h), built at create
     char err[512];
 };
 
@@ -94,6 +95,7 @@ struct StepArgs {
     const uint8_t *active;
     float *feature_out;
     int flen;
+    const uint32_t *lut; // ctx->stab_lut
 };
 
 int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d);

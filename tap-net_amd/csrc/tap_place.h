@@ -24,6 +24,7 @@ typedef unsigned long long u64;
 
 struct PlaceCfg {
     int W, L, H, flags;
+    const uint32_t *lut; // is_stable look-up table for footprints <= 4x4 (env.hip), may be null
 };
 
 struct Counters {
@@ -125,6 +126,36 @@ __device__ inline int tap_stable3d(int bx, int by, u64 m)
     return le && ge;
 }
 
+// Table form of tap_stable3d for footprints up to 4x4 (every RAND block: sides 1..4): one bit per
+// (shape, support mask), built once per context by running tap_stable3d itself over all 74 954
+// (shape, mask) pairs (env.hip), 9.4 KB, L2-resident.  In the 3D kernels the hull test was more than
+// half of a placement's time (7.5 of 14.6 us at config c5); the cheap cases (majority, <= 1 support
+// cell) stay inline, the rest become one 32-bit load.
+__device__ __forceinline__ int tap_lut_offset(int bx, int by)
+{
+    int off = 0; // prefix sums of 2^(bx*by) over shapes in (bx, by) row-major order
+    for (int i = 1; i <= 4; ++i)
+        for (int j = 1; j <= 4; ++j) {
+            if (i == bx && j == by) return off;
+            off += 1 << (i * j);
+        }
+    return off;
+}
+constexpr int TAP_LUT_BITS = 74954 + 22; // sum over shapes of 2^(bx*by), padded to a word boundary
+constexpr int TAP_LUT_WORDS = (TAP_LUT_BITS + 31) / 32;
+
+__device__ __forceinline__ int tap_stable3d_any(const uint32_t *lut, int bx, int by, u64 m)
+{
+    if (lut == nullptr || bx > 4 || by > 4) return tap_stable3d(bx, by, m);
+    const int k = __popcll(m);
+    if (2 * k > bx * by) return 1; // tools.py:730
+    if (k <= 1) return 0;          // tools.py:732
+    unsigned mc = 0;               // stride-8 mask -> row-major (i*by + j)
+    for (int i = 0; i < bx; ++i) mc |= (unsigned)((m >> (8 * i)) & ((1u << by) - 1u)) << (i * by);
+    const int idx = tap_lut_offset(bx, by) + (int)mc;
+    return (lut[idx >> 5] >> (idx & 31)) & 1u;
+}
+
 // ---- footprint scan over the group's LDS slice ---------------------------------------------
 // -> mx = max height, eq = cells at that height (2D: bit i; 3D: bit i*8+j), sum = sum of heights
 template <int D>
@@ -223,7 +254,7 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
             tap_scan<D>(s, L, x, y, bx, by, mx, eq, sum);
             z = mx;
             if (z >= c.H) err |= 1;                               // :2109 would raise IndexError
-            stab = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d(bx, by, eq));
+            stab = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d_any(c.lut, bx, by, eq));
             emp = cnt.empty + bx * by * z - sum;                  // :2132-2134
             ratio = tap_score(c, cnt, vol, gmax, z, bz, emp, stab);
             key = ((z * L + y) * 3 + cls) * W + x;                // sort order (z, y, class, x)
@@ -278,7 +309,7 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
                     visited |= pbit;                              // :2107
                     if (z >= c.H) { err |= 1; continue; }         // :2109 IndexError
                     if (mx > z) continue;                         // :2109 not free
-                    const int st = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d(bx, by, eq));
+                    const int st = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d_any(c.lut, bx, by, eq));
                     if (!st) continue;                            // :2112-2114 hard rejects
                     ok = true; spos = _x * 64 + _y; sstab = st;
                     semp = cnt.empty + bx * by * z - sum;

@@ -45,7 +45,7 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
     if (act && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
     g_old[cell] = hm;
     tap_wave_lds_sync();
-    const PlaceCfg cfg = {W, L, s.d.H, s.d.flags};
+    const PlaceCfg cfg = {W, L, s.d.H, s.d.flags, s.lut};
     const int step = cnt.count;
     const Placement pl = tap_place<D, G>(cfg, g_old, cell, hm, cnt, err, bx, by, bz, do_step);
     err = group_or<G>(err);

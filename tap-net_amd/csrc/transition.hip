@@ -138,7 +138,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
         }
     tap_wave_lds_sync();
     const int step = cnt.count;
-    const PlaceCfg cfg = {W, 1, H, a.s.d.flags};
+    const PlaceCfg cfg = {W, 1, H, a.s.d.flags, nullptr};
     const Placement pl = tap_macs_place<G>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
     err = group_or<G>(err);
     tap_wave_lds_sync();
@@ -238,6 +238,7 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     tap_env_layout(d, state, &a.s.v);
     a.s.static_ = static_; a.s.static_rows = static_rows; a.s.nR = n * R; a.s.ptr = ptr;
     a.s.feature_out = feature_out; a.s.flen = tap_env_feature_len(d);
+    a.s.lut = ctx ? ctx->stab_lut : nullptr;
     a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
                    mask_in, colsum_in, colsum_out, current_out, mask_out};
     a.flags = flags;
