@@ -8,7 +8,7 @@ no reference source text.  Usage:
     python tests/golden/make_golden.py [--only NAME ...]
 
 Fixtures:
-  lbg2d.npz, lbg3d.npz, macs2d.npz   tools.Container.add_new_block / calc_ratio step traces
+  lbg2d.npz, lbg3d.npz, macs2d.npz, macs3d.npz   tools.Container.add_new_block / calc_ratio step traces
   stable3d.npz                       tools.is_stable, exhaustive over footprints <= 4x4 (+5xk samples)
   dataset_2d.npz, dataset_3d.npz     pack.create_dataset -> text files -> pack.PACKDataset tensors
   masks_2d.npz, masks_3d.npz         pack.update_dynamic / pack.update_mask traces on random feasible tapes
@@ -146,6 +146,22 @@ def make_macs2d(tools):
             meta = dict(cs=[W, 60], n=10, reward=reward, feat="diff", strategy="MACS")
             cases.append((meta, trace_container(tools, [W, 60], 10, reward, "diff", "MACS", blocks), blocks))
     save("macs2d.npz", **pack_cases(cases))
+
+
+def make_macs3d(tools):
+    """MACS in 3D (tools.calc_one_position_mcs_3d, tools.py:2751-3165)."""
+    cases = []
+    for reward in ("C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "C+P+S-mul-hard", "mcs-soft"):
+        blocks = rand_blocks(501, 24, 10, 3)
+        meta = dict(cs=[5, 5, 50], n=10, reward=reward, feat="diff", strategy="MACS")
+        cases.append((meta, trace_container(tools, [5, 5, 50], 10, reward, "diff", "MACS", blocks), blocks))
+    for cs, n, hi, seed in (([6, 6, 60], 16, 6, 511), ([4, 7, 40], 12, 5, 512), ([7, 4, 40], 12, 5, 513),
+                            ([8, 8, 80], 24, 5, 514)):
+        for reward in ("C+P+S-mcs-soft", "C+P+S-mcs-hard"):
+            blocks = rand_blocks(seed, 8, n, 3, 1, hi, marginal=False)
+            meta = dict(cs=cs, n=n, reward=reward, feat="full", strategy="MACS")
+            cases.append((meta, trace_container(tools, cs, n, reward, "full", "MACS", blocks), blocks))
+    save("macs3d.npz", **pack_cases(cases))
 
 
 def make_stable3d(tools):
@@ -372,6 +388,7 @@ def main():
     if want("lbg2d"): make_lbg2d(tools)
     if want("lbg3d"): make_lbg3d(tools)
     if want("macs2d"): make_macs2d(tools)
+    if want("macs3d"): make_macs3d(tools)
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)

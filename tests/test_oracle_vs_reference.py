@@ -60,6 +60,13 @@ def test_macs2d(ref, reward):
     _diff(ref[0], [5, 50], 10, reward, "diff", "MACS", 40, 32)
 
 
+@pytest.mark.parametrize("reward", ["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft"])
+def test_macs3d(ref, reward):
+    _diff(ref[0], [5, 5, 50], 10, reward, "diff", "MACS", 12, 41)
+    _diff(ref[0], [6, 6, 60], 16, reward, "full", "MACS", 4, 42, 1, 6)
+    _diff(ref[0], [4, 7, 40], 12, reward, "diff", "MACS", 4, 43)
+
+
 def test_masks(ref):
     import torch
     pack = ref[1]
