@@ -140,8 +140,6 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "H or blocks_num too large for the 32-bit sort key");
     if (d->strategy != TAP_LB_GREEDY && d->strategy != TAP_MACS)
         return tap_fail(ctx, TAP_E_INVALID, "bad strategy %d", d->strategy);
-    if (d->strategy == TAP_MACS && d->D != 2)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS/MUL is implemented for 2D only");
     return TAP_OK;
 }
 

@@ -1,7 +1,8 @@
-// macs.hip -- stand-alone MACS / MUL 2D step (tools.Container.add_new_block with
-// packing_strategy 'MACS' / 'MUL'); the placement itself is tap_macs.h.  gfx950 only.
+// macs.hip -- stand-alone MACS / MUL step (tools.Container.add_new_block with packing_strategy
+// 'MACS' / 'MUL'); the placement itself is tap_macs.h (2D) / tap_macs3.h (3D).  gfx950 only.
 #include "tap_common.h"
 #include "tap_macs.h"
+#include "tap_macs3.h"
 
 template <int G>
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_step(StepArgs a)
@@ -90,9 +91,112 @@ template <int G> static int launch_macs(tap_ctx *ctx, const StepArgs &a, hipStre
     return TAP_OK;
 }
 
+// ---- 3D ------------------------------------------------------------------------------------------
+template <int G>
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_step(StepArgs a)
+{
+    extern __shared__ int lds[];
+    const int tid = threadIdx.x, cell = tid % G;
+    const int env = blockIdx.x * ((int)blockDim.x / G) + tid / G;
+    const int B = a.d.B, W = a.d.W, Ld = a.d.L, cells = W * Ld;
+    const bool ev = env < B, incell = cell < cells;
+    const int gl0 = (tid & 63) - cell;
+    const Macs3Lds S = macs3_lds(lds + (tid / G) * macs3_group_words(G, a.d.n_max), G);
+
+    int hm = (ev && incell) ? a.v.hm[(size_t)env * cells + cell] : 0;
+    u64 occ = (ev && incell) ? a.v.occ[(size_t)env * cells + cell] : 0ull;
+    const int cv = (ev && cell < 4) ? a.v.cnt[(size_t)env * 4 + cell] : 0;
+    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
+    int bx = 1, by = 1, bz = 1;
+    bool act = ev;
+    if (ev) {
+        if (a.static_) {
+            const long p = (long)a.ptr[env];
+            bx = (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+            by = (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+            bz = (int)a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
+        } else if (a.blocks_dtype == TAP_DT_F32) {
+            const float *b = (const float *)a.blocks + (size_t)env * 3;
+            bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];
+        } else {
+            const int32_t *b = (const int32_t *)a.blocks + (size_t)env * 3;
+            bx = b[0]; by = b[1]; bz = b[2];
+        }
+        if (a.active) act = a.active[env] != 0;
+    }
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }
+    // sides larger than the container are rejected as invalid input: the reference keeps such a
+    // block in its history at (0,0,0) and its later slices run out of range (tools.py:2858, 2914)
+    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > Ld)) { err |= 4; do_step = false; }
+
+    S.hm[cell] = hm;
+    S.occ[cell] = occ;
+    if (ev) // one round trip for the whole placement history
+        for (int k = cell; k < cnt.count * 6 && k < a.d.n_max * 6; k += G) {
+            const int i = k / 6, f = k - i * 6;
+            const int v = (f < 3 ? a.v.pos : a.v.blk)[(size_t)(i * 3 + (f < 3 ? f : f - 3)) * B + env];
+            S.hist[i * MACS3_HIST + f] = f == 3 ? (v & 0xffff) : v;
+            if (f == 3) S.hist[i * MACS3_HIST + 6] = v >> 16; // placed flag rides on the x size
+        }
+    tap_wave_lds_sync();
+    const int step = cnt.count;
+    const PlaceCfg cfg = {W, Ld, a.d.H, a.d.flags, a.lut};
+    const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, occ, cnt, err, bx, by, bz, do_step);
+    err = group_or<G>(err);
+
+    tap_wave_lds_sync();
+    S.hm[cell] = hm;
+    tap_wave_lds_sync();
+    if (ev) {
+        if (incell) {
+            a.v.hm[(size_t)env * cells + cell] = hm;
+            a.v.occ[(size_t)env * cells + cell] = occ;
+        }
+        if (a.feature_out)
+            tap_write_feature<3, G>(a.d.feature, W, Ld, S.hm, cell, hm, a.feature_out + (size_t)env * a.flen);
+        if (cell == 0) {
+            if (do_step) {
+                reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+                a.v.pos[(size_t)(step * 3) * B + env] = pl.x;
+                a.v.pos[(size_t)(step * 3 + 1) * B + env] = pl.y;
+                a.v.pos[(size_t)(step * 3 + 2) * B + env] = pl.z;
+                a.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
+                a.v.blk[(size_t)(step * 3) * B + env] = bx | (pl.placed << 16); // history of later steps
+                a.v.blk[(size_t)(step * 3 + 1) * B + env] = by;                  // (tools.py:2843-2846),
+                a.v.blk[(size_t)(step * 3 + 2) * B + env] = bz;                  // failures too
+            }
+            if (err) a.v.err[env] |= err;
+        }
+    } else if (a.d.feature == TAP_FEAT_ZERO) {
+        (void)group_min<G>(INT_MAX);
+    }
+}
+
+template <int G> static int launch_macs3(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
+{
+    const tap_env_desc &d = a.d;
+    int threads = TAP_BLOCK;
+    const size_t per_env = (size_t)macs3_group_words(G, d.n_max) * sizeof(int);
+    while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
+    const int epb = threads / G, grid = (d.B + epb - 1) / epb;
+    if (grid == 0) return TAP_OK;
+    const size_t lds = epb * per_env;
+    if (lds > 64 * 1024)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D: blocks_num=%d needs %zu bytes of LDS per workgroup", d.n_max, lds);
+    hipLaunchKernelGGL(k_macs3d_step<G>, dim3(grid), dim3(threads), lds, st, a);
+    TAP_LAUNCH_CHECK(ctx, "k_macs3d_step");
+    return TAP_OK;
+}
+
 int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d)
 {
-    if (d.D != 2) return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS/MUL is implemented for 2D only");
+    if (d.D == 3) {
+        if (d.W > 8 || d.L > 8 || d.H > MACS3_MAX_H)
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D supports W, L <= 8 and H <= %d", MACS3_MAX_H);
+        return TAP_OK;
+    }
     if (d.W > 16 || d.H > MACS_MAX_H)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS supports W <= 16 and H <= %d", MACS_MAX_H);
     if ((d.W + 1) * ((d.W + 1) / 2) + 2 * d.n_max > MACS_EMS_CAP)
@@ -104,5 +208,13 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     int rc = tap_macs_validate(ctx, a.d);
     if (rc) return rc;
+    if (a.d.D == 3) {
+        switch (tap_group_size(&a.d)) {
+        case 8: return launch_macs3<8>(ctx, a, st);
+        case 16: return launch_macs3<16>(ctx, a, st);
+        case 32: return launch_macs3<32>(ctx, a, st);
+        default: return launch_macs3<64>(ctx, a, st);
+        }
+    }
     return a.d.W <= 8 ? launch_macs<8>(ctx, a, st) : launch_macs<16>(ctx, a, st);
 }

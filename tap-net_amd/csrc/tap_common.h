@@ -52,6 +52,7 @@ constexpr int TAP_BLOCK = 256; // threads per workgroup (4 wave64)
 // pos     int32 [n_max*D][B]      positions, step-major so one lock-step is one coalesced row
 // stable  uint8 [n_max][B]
 // blk     int32 [n_max*D][B]      placed block sizes (MACS history only)
+// occ     uint64 [B][cells]       MACS 3D only: complement of the cell's free-list column (tap_macs3.h)
 struct EnvView {
     int32_t *hm;
     int32_t *cnt;
@@ -59,6 +60,7 @@ struct EnvView {
     int32_t *pos;
     uint8_t *stable;
     int32_t *blk;
+    unsigned long long *occ;
 };
 
 inline size_t tap_align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -72,6 +74,7 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
     size_t o_hm = take(B * cells * 4), o_cnt = take(B * 16), o_err = take(B * 4);
     size_t o_pos = take(nD * B * 4), o_st = take((size_t)d->n_max * B);
     size_t o_blk = d->strategy == TAP_MACS ? take(nD * B * 4) : 0;
+    size_t o_occ = (d->strategy == TAP_MACS && d->D == 3) ? take(B * cells * 8) : 0;
     if (v) {
         v->hm = reinterpret_cast<int32_t *>(p + o_hm);
         v->cnt = reinterpret_cast<int32_t *>(p + o_cnt);
@@ -79,6 +82,7 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
         v->pos = reinterpret_cast<int32_t *>(p + o_pos);
         v->stable = reinterpret_cast<uint8_t *>(p + o_st);
         v->blk = d->strategy == TAP_MACS ? reinterpret_cast<int32_t *>(p + o_blk) : nullptr;
+        v->occ = (d->strategy == TAP_MACS && d->D == 3) ? reinterpret_cast<unsigned long long *>(p + o_occ) : nullptr;
     }
     return off;
 }

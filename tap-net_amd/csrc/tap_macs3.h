@@ -1,0 +1,462 @@
+// tap_macs3.h -- device code: one MACS / MUL 3D placement for one container, G lanes per container
+// (lane = height-map cell).  tools.calc_one_position_mcs_3d (tools.py:2751-3165) re-stated on the
+// height-map, the placement history and one 64-bit word per cell; used by macs.hip.
+//
+// State.  The reference keeps a voxel grid and, per (level z, row y), a list of free x-intervals.
+//   * voxel (x,y,z) == 0  <=>  z >= hm[x,y]: update_container (tools.py:3043-3047) fills the block
+//     and marks everything below it, so the height-map carries every voxel test of the function.
+//   * the interval lists are NOT a function of the height-map: update_level_free_space
+//     (tools.py:2989-3041) forgets to shrink an interval of a lower level when the new block's
+//     shadow falls strictly inside it, so a list can keep cells that are no longer free.  The lists
+//     are, however, always the maximal runs of a bit-grid F(x,y,z) with the update rule
+//         levels [z, z+bz):  clear the footprint;
+//         levels below z, per footprint row: clear the row's cells unless F also holds both
+//         x-neighbours of the row AND every cell of the row (the "strictly inside" case)
+//     (checked against the reference's lists over 2.3e5 rows, scratch notes in DESIGN.md).  Each
+//     cell carries its column of F as one u64 (bit z), stored complemented so that a zeroed state
+//     blob is the empty container; hence H <= 64.
+//   * voxel *values* (which block) are only compared in the "partly covered top" case
+//     (tools.py:2924-2942) and are recomputed from the placement history when that case occurs.
+//
+// Structure, as in tap_macs.h: (1) the EMS list is built by every lane of the group redundantly
+// (identical LDS writes), level masks come from one ballot each, rows are W-bit fields of a
+// y-major mask; the reference's function-scope variable `x1` that the "left part" case reads stale
+// (tools.py:2865) is carried exactly; (2) whether a block settles at (x,y,Z) depends on the position
+// only, and a position can only settle at Z = max of the height-map under it, so the four corner
+// walks of every EMS are find-first-set operations on good(Z) & ~taken & rectangle in the walk's
+// order, and `visited` reduces to one `taken` bit per position; (3) each settled position is scored
+// by its own lane in fp64; the usable-space tie-break (tools.py:3049-3077) is the sum over levels
+// of the largest free rectangle, computed per tied candidate from one ballot per distinct height.
+#pragma once
+
+#include "tap_place.h"
+
+constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 8x8, 40 blocks)
+constexpr int MACS3_MAX_H = 64;
+constexpr int MACS3_HIST = 8;      // ints per history entry: x y z xx yy zz placed pad
+
+// LDS words per env group: occ u64[G] | hm[G] | ord[G] | ems[CAP] | hist[8 n_max]
+__host__ __device__ constexpr int macs3_group_words(int G, int n_max)
+{
+    return 2 * G + G + G + MACS3_EMS_CAP + MACS3_HIST * n_max;
+}
+
+struct Macs3Lds {
+    u64 *occ;
+    int *hm, *ord, *ems, *hist;
+};
+
+__device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G)
+{
+    Macs3Lds m;
+    m.occ = reinterpret_cast<u64 *>(base);
+    m.hm = base + 2 * G;
+    m.ord = m.hm + G;
+    m.ems = m.ord + G;
+    m.hist = m.ems + MACS3_EMS_CAP;
+    return m;
+}
+
+template <int G> __device__ __forceinline__ u64 ballot_g(bool p, int gl0)
+{
+    const u64 b = __ballot(p);
+    return G == 64 ? b : ((b >> gl0) & ((1ull << (G & 63)) - 1ull));
+}
+
+template <int G> __device__ __forceinline__ u64 group_or64(u64 v)
+{
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) {
+        const unsigned lo = __shfl_xor((unsigned)v, o, G), hi = __shfl_xor((unsigned)(v >> 32), o, G);
+        v |= ((u64)hi << 32) | lo;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned m3_bits(int a, int b) // bits a..b inclusive, empty when a > b
+{
+    return a > b ? 0u : (((2u << (b - a)) - 1u) << a);
+}
+__device__ __forceinline__ bool m3_bit(unsigned r, int i) { return (r >> i) & 1u; }
+// list semantics on a row mask: is [x1, x2] (bits `run`) exactly one interval of the row?
+__device__ __forceinline__ bool m3_has_run(unsigned r, unsigned run, int x1, int x2)
+{
+    return (r & run) == run && !(x1 > 0 && m3_bit(r, x1 - 1)) && !m3_bit(r, x2 + 1);
+}
+// `v in list`: v is the first or the last cell of an interval
+__device__ __forceinline__ bool m3_inlist(unsigned r, int v)
+{
+    return m3_bit(r, v) && (v == 0 || !m3_bit(r, v - 1) || !m3_bit(r, v + 1));
+}
+__device__ __forceinline__ int m3_longest_run(unsigned v)
+{
+    int r = 0;
+    while (v) { v &= v << 1; ++r; }
+    return r;
+}
+
+// One placement.  Preconditions: S.hm[cell] = hm, S.occ[cell] = occ (x-major cells, 0 beyond W*L),
+// S.hist[0..8*cnt.count) filled, visible to the group (wave-level sync by the caller).  do_step is
+// group-uniform.  On return hm/occ/cnt are updated and res describes the placement.
+template <int G>
+__device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S, int cell, int gl0, int &hm,
+                                            u64 &occ, Counters &cnt, int &err, int bx, int by, int bz,
+                                            bool do_step)
+{
+    const int W = c.W, L = c.L, H = c.H, cells = W * L;
+    Placement res = {0, 0, 0, 0, 0};
+    if (!do_step) return res;
+    const int hard = c.flags & TAP_F_HARD;
+    const int vol = bx * by * bz, step = cnt.count;
+    const u64 hmask = H >= 64 ? ~0ull : ((1ull << H) - 1ull);
+    const unsigned wmask = (1u << W) - 1u, lmask = (1u << L) - 1u;
+    const int wl = threadIdx.x & 63;
+
+    // this lane in the y-major view: position / cell (tx, ty), bit ty*W + tx of every level mask
+    const bool inT = cell < cells;
+    const int ty = cell / W, tx = cell - ty * W;
+    const int hmT = inT ? S.hm[tx * L + ty] : INT_MAX;
+    const u64 FT = inT ? (~S.occ[tx * L + ty] & hmask) : 0ull;
+    const int gmax = group_max<G>(inT ? hmT : 0);
+    u64 colsel = 0; // bit y*W for every row
+    for (int y = 0; y < L; ++y) colsel |= 1ull << (y * W);
+
+    auto rowT = [&](u64 m, int y) -> unsigned { return (unsigned)(m >> (y * W)) & wmask; };
+    auto levelF = [&](int z) -> u64 { return ballot_g<G>(inT && ((FT >> z) & 1ull), gl0); };
+    auto levelT = [&](int z) -> u64 { return ballot_g<G>(hmT <= z, gl0); }; // container[.., z] == 0
+
+    // ---- phase 1: EMS list (identical on every lane of the group) -------------------------------
+    int n_ems = 0;
+#define M3_PACK(x1, y1, z, x2, y2) (((x1) & 15) | (((y1) & 15) << 4) | (((x2) & 15) << 8) | (((y2) & 15) << 12) | ((z) << 16))
+#define M3_PUSH(x1, y1, z, x2, y2)                                                           \
+    do {                                                                                     \
+        if (n_ems < MACS3_EMS_CAP) S.ems[n_ems++] = M3_PACK(x1, y1, z, x2, y2);              \
+        else err |= 16;                                                                      \
+    } while (0)
+    // y2 := last row reached going +y from `from` while rows keep `span` free at level mask T
+#define M3_EXT_UP(T, span, from, y2)                                                         \
+    for (y2 = (from);; ++y2) {                                                               \
+        if (y2 == L - 1) break;                                                              \
+        if ((rowT(T, y2 + 1) & (span)) != (span)) break;                                     \
+    }
+#define M3_EXT_DOWN(T, span, from, y1)                                                       \
+    for (y1 = (from);; --y1) {                                                               \
+        if (y1 == 0) break;                                                                  \
+        if ((rowT(T, y1 - 1) & (span)) != (span)) break;                                     \
+    }
+    int sx1 = 0;          // python's function-scope `x1` (tools.py:2823, 2870, 2901 assign it)
+    bool x1def = false;   // ... which :2865 may read before any assignment (UnboundLocalError)
+
+    // (a) per-(level, row) free intervals (tools.py:2813-2841); level z is skipped when all its
+    //     lists equal those of z-1 (:2816), i.e. when no cell's F column changes between the two
+    {
+        u64 chg = group_or64<G>(FT ^ (FT << 1)) | 1ull;
+        const int zmax = H - bz;                                                     // :2815
+        chg = zmax < 0 ? 0ull : (zmax >= 63 ? chg : (chg & ((2ull << zmax) - 1ull)));
+        while (chg) {
+            const int z = __ffsll((long long)chg) - 1;
+            chg &= chg - 1ull;
+            const u64 Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : 0ull, Tz = levelT(z);
+            for (int y = 0; y < L; ++y) {
+                if (y + by > L) break;                                               // :2818
+                const unsigned row = rowT(Fz, y), prow = y > 0 ? rowT(Fz, y - 1) : 0u;
+                if (y > 0 && row == prow) continue;                                  // :2819
+                const unsigned brow = z > 0 ? rowT(Fb, y) : 0u;
+                unsigned m = row;
+                while (m) {
+                    const int x1 = __ffs((int)m) - 1;
+                    const int len = __ffs((int)~(m >> x1)) - 1;
+                    const unsigned run = ((1u << len) - 1u) << x1;
+                    const int x2 = x1 + len - 1;
+                    m &= ~run;
+                    sx1 = x1; x1def = true;                                          // :2823
+                    if (x1 + bx > W) break;                                          // :2824
+                    if (y > 0 && m3_has_run(prow, run, x1, x2)) continue;            // :2825-2827
+                    if (z > 0 && m3_has_run(brow, run, x1, x2)) continue;            // :2828-2830
+                    bool xspace = true;                                              // :2831-2840
+                    int y2;
+                    for (y2 = y;; ++y2) {
+                        if (y2 == L - 1) break;
+                        if ((rowT(Tz, y2 + 1) & run) != run) break;
+                        if (xspace) {
+                            const unsigned f = rowT(Fz, y2 + 1);
+                            if (!(m3_inlist(f, x1) && m3_inlist(f, x2))) { xspace = false; M3_PUSH(x1, y, z, x2, y2); }
+                        }
+                    }
+                    M3_PUSH(x1, y, z, x2, y2);
+                }
+            }
+        }
+    }
+    // (b) spaces next to and on top of the blocks placed so far (tools.py:2843-2942); a block that
+    //     could not be placed sits at (0,0,0) in `positions` and is visited all the same
+    for (int bi = 0; bi < step; ++bi) {
+        const int *hb = S.hist + bi * MACS3_HIST;
+        const int x = hb[0], y = hb[1], z = hb[2], xx = hb[3], yy = hb[4], zz = hb[5];
+        const int xe = x + xx - 1;
+        const u64 T = levelT(z);
+        const unsigned spanx = m3_bits(x, xe);
+        if (y + yy < L) {                                                            // :2847 beyond +y
+            const unsigned r = rowT(T, y + yy);
+            int y2;
+            if ((r & spanx) == spanx) {                                              // :2849
+                if ((x > 0 && m3_bit(r, x - 1)) || (x + xx < W && m3_bit(r, x + xx))) {
+                    M3_EXT_UP(T, spanx, y + yy, y2);
+                    M3_PUSH(x, y + yy, z, xe, y2);
+                }
+            } else {
+                if (m3_bit(r, x) && x > 0 && m3_bit(r, x - 1)) {                     // :2858 left part
+                    const int x2 = x + min(__ffs((int)~(r >> x)) - 1, xx) - 1;       // :2860-2862
+                    if (!x1def) err |= 8;
+                    const unsigned sp = m3_bits(sx1, x2);                            // :2865 (sic: stale x1)
+                    M3_EXT_UP(T, sp, y + yy, y2);
+                    M3_PUSH(x, y + yy, z, x2, y2);
+                }
+                if (m3_bit(r, xe) && x + xx < W && m3_bit(r, x + xx)) {              // :2868 right part
+                    const int down = __clz((int)~(r << (31 - xe)));                  // free cells from xe leftwards
+                    const int x1 = xe - min(down, xx) + 1;                           // :2870-2872
+                    sx1 = x1; x1def = true;
+                    const unsigned sp = m3_bits(x1, xe);
+                    M3_EXT_UP(T, sp, y + yy, y2);
+                    M3_PUSH(x1, y + yy, z, xe, y2);
+                }
+            }
+        }
+        if (y > 0) {                                                                 // :2878 beyond -y
+            const unsigned r = rowT(T, y - 1);
+            int y1;
+            if ((r & spanx) == spanx) {
+                if ((x > 0 && m3_bit(r, x - 1)) || (x + xx < W && m3_bit(r, x + xx))) {
+                    M3_EXT_DOWN(T, spanx, y - 1, y1);
+                    M3_PUSH(x, y1, z, xe, y - 1);
+                }
+            } else {
+                if (m3_bit(r, x) && x > 0 && m3_bit(r, x - 1)) {                     // :2889
+                    const int x2 = x + min(__ffs((int)~(r >> x)) - 1, xx) - 1;
+                    const unsigned sp = m3_bits(x, x2);                              // :2896 uses x here
+                    M3_EXT_DOWN(T, sp, y - 1, y1);
+                    M3_PUSH(x, y1, z, x2, y - 1);
+                }
+                if (m3_bit(r, xe) && x + xx < W && m3_bit(r, x + xx)) {              // :2899
+                    const int down = __clz((int)~(r << (31 - xe)));
+                    const int x1 = xe - min(down, xx) + 1;
+                    sx1 = x1; x1def = true;
+                    const unsigned sp = m3_bits(x1, xe);
+                    M3_EXT_DOWN(T, sp, y - 1, y1);
+                    M3_PUSH(x1, y1, z, xe, y - 1);
+                }
+            }
+        }
+        if (z + zz < H) {                                                            // :2909 on top
+            const int t = z + zz;
+            const u64 Tt = levelT(t);
+            bool full = true;
+            for (int j = 0; j < yy; ++j) full = full && (rowT(Tt, y + j) & spanx) == spanx;
+            if (full) {                                                              // :2911-2913
+                const int want = M3_PACK(x, y, t, xe, y + yy - 1);
+                int dup = 0;
+                for (int k = cell; k < n_ems; k += G) dup |= S.ems[k] == want;
+                if (!group_or<G>(dup)) M3_PUSH(x, y, t, xe, y + yy - 1);
+            } else {
+                // voxel value at level t under this lane's (tx, ty): block index, -1 below a block, 0 free
+                int id = inT ? (hmT > t ? -1 : 0) : 0;
+                for (int k = 0; k < step; ++k) {
+                    const int *hk = S.hist + k * MACS3_HIST;
+                    if (hk[6] && tx >= hk[0] && tx < hk[0] + hk[3] && ty >= hk[1] && ty < hk[1] + hk[4] &&
+                        t >= hk[2] && t < hk[2] + hk[5]) id = k + 1;
+                }
+                const int idl = __shfl(id, (wl + 63) & 63);                          // the cell at x-1 (same row)
+                const u64 EQ = ballot_g<G>(inT && tx > 0 && id == idl, gl0);
+                auto hist = [&](int i, int j) -> int {                               // :2915-2922
+                    const unsigned v = (rowT(Tt, y + j) >> (x + i)) & ((1u << (xx - i)) - 1u);
+                    return __ffs((int)~v) - 1;
+                };
+                auto rows_equal = [&](int i, int ja, int jb) -> bool {               // rows x+i, x+i-1 over [ja, jb)
+                    bool eq = true;
+                    for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((y + j) * W + x + i)) & 1ull);
+                    return eq;
+                };
+                for (int i = 0; i < xx; ++i)                                         // :2924-2942
+                    for (int j = 0; j < yy; ++j) {
+                        const int hv = hist(i, j);
+                        if (hv == 0) continue;
+                        if (j > 0 && hv == hist(i, j - 1)) continue;
+                        if (i > 0 && rows_equal(i, j, yy)) continue;                 // :2928
+                        const int i2 = i + hv - 1;
+                        int j2, j1;
+                        for (j2 = j;; ++j2) { if (j2 == yy - 1) break; if (hist(i, j2 + 1) < hv) break; }
+                        if (i > 0 && rows_equal(i, j, j2)) continue;                 // :2934 (empty range is "equal")
+                        for (j1 = j;; --j1) { if (j1 == 0) break; if (hist(i, j1 - 1) < hv) break; }
+                        const int want = M3_PACK(x + i, y + j1, z, x + i2, y + j2);  // :2940 (sic: level z, not z+zz)
+                        int dup = 0;
+                        for (int k = cell; k < n_ems; k += G) dup |= S.ems[k] == want;
+                        if (!group_or<G>(dup)) M3_PUSH(x + i, y + j1, z, x + i2, y + j2);
+                    }
+            }
+        }
+    }
+
+    // ---- phase 2: the four corner walks of every EMS (tools.py:3080-3115) -------------------------
+    // this lane's position (tx, ty): it can only settle at Z = max height under the footprint
+    const bool posv = inT && tx + bx <= W && ty + by <= L;
+    int mp = -1, sum_p = 0, stab_p = 0;
+    if (posv) {
+        u64 eq;
+        tap_scan<3>(S.hm, L, tx, ty, bx, by, mp, eq, sum_p);
+        stab_p = mp == 0 ? 1 : tap_stable3d_any(c.lut, bx, by, eq);                  // tools.is_stable
+    }
+    const bool okp = posv && (stab_p || !hard);                                      // :2963-2965
+    const int X = W - bx + 1, Y = L - by + 1;
+    u64 taken = 0;
+    int n_slots = 0;
+    S.ord[cell] = -1;
+    auto rect = [&](int xa, int xb, int ya, int yb) -> u64 { // [xa, xb) x [ya, yb), y-major
+        const u64 rows = colsel & ((yb >= L ? ~0ull : ((1ull << (yb * W)) - 1ull)) & ~((1ull << (ya * W)) - 1ull));
+        return (u64)m3_bits(xa, xb - 1) * rows;
+    };
+    auto fold = [&](u64 m) -> unsigned {
+        unsigned f = 0;
+        for (int y = 0; y < L; ++y) f |= rowT(m, y);
+        return f;
+    };
+    auto settle = [&](int px, int py) {
+        const int p = py * W + px;
+        taken |= 1ull << p;
+        S.ord[p] = n_slots++; // same value from every lane of the group
+    };
+    for (int e = 0; e < n_ems; ++e) {
+        const int pk = S.ems[e];
+        const int X1 = pk & 15, Y1 = (pk >> 4) & 15, X2 = (pk >> 8) & 15, Y2 = (pk >> 12) & 15, Z = pk >> 16;
+        const u64 gm = ballot_g<G>(okp && mp == Z, gl0);
+        if (!(gm & ~taken)) continue;
+        const int xr = X2 - bx + 2, yr = Y2 - by + 2;
+        if (X1 < X && Y1 < Y) {                                                      // :3085 x up, then y up
+            const u64 m = gm & ~taken & rect(X1, X, Y1, Y);
+            if (m) {
+                const int px = __ffs((int)fold(m)) - 1;
+                const int py = (__ffsll((long long)((m >> px) & colsel)) - 1) / W;
+                settle(px, py);
+            }
+        }
+        if (xr > 0 && Y1 < Y) {                                                      // :3093 y up, then x down
+            const u64 m = gm & ~taken & rect(0, xr, Y1, Y);
+            if (m) {
+                const int py = (__ffsll((long long)m) - 1) / W;
+                settle(31 - __clz((int)rowT(m, py)), py);
+            }
+        }
+        if (xr > 0 && yr > 0) {                                                      // :3101 x down, then y down
+            const u64 m = gm & ~taken & rect(0, xr, 0, yr);
+            if (m) {
+                const int px = 31 - __clz((int)fold(m));
+                const int py = (63 - __clzll((long long)((m >> px) & colsel))) / W;
+                settle(px, py);
+            }
+        }
+        if (X1 < X && yr > 0) {                                                      // :3109 y down, then x up
+            const u64 m = gm & ~taken & rect(X1, X, 0, yr);
+            if (m) {
+                const int py = (63 - __clzll((long long)m)) / W;
+                settle(__ffs((int)rowT(m, py)) - 1, py);
+            }
+        }
+    }
+    tap_wave_lds_sync();
+    const int ord = S.ord[cell];
+    const bool settled = ord >= 0;
+
+    // ---- phase 3: score (tools.py:2973-2987), every settled position by its own lane --------------
+    const int valid2 = cnt.valid + vol;
+    const bool tiebreak = (c.flags & TAP_F_MCS_TIE) != 0, zero = (c.flags & TAP_F_MCS_ZERO) != 0;
+    const int emp_p = cnt.empty + bx * by * mp - sum_p;                              // :2982-2983
+    double r = -1.0;
+    if (settled) {
+        if (zero) r = 0.0;                                                           // :3125
+        else {
+            int height = max(gmax, mp + bz);
+            if (mp + bx > height) height = mp + bz;                                  // :2977 (sic block_x)
+            const double C = (double)valid2 / (double)((long long)height * W * L);
+            const double P = (c.flags & TAP_F_USE_P) ? (double)valid2 / (double)(emp_p + valid2) : 0.0;
+            const double S_ = (c.flags & TAP_F_USE_S) ? (double)(cnt.nstable + stab_p) / (double)(cnt.count + 1) : 0.0;
+            r = (C + P) + S_;
+        }
+    }
+    double rmax = r;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, G));
+    int win = -1; // y-major position of the winner
+    if (n_slots > 0) {
+        const u64 tied = ballot_g<G>(settled && r == rmax, gl0);
+        const int nt = zero ? 4 * n_ems : __popcll(tied); // len(best_ems_indexes), unsettled entries are 0.0
+        if (!(tiebreak && nt > 1)) {                                                 // :3145-3148
+            const int wo = group_min<G>((settled && r == rmax) ? ord : INT_MAX);
+            win = __ffsll((long long)ballot_g<G>(settled && ord == wo, gl0)) - 1;
+        } else {                                                                     // :3132-3144
+            // calc_maximal_usable_spaces (:3049-3077) = sum over levels h < max_height of the largest
+            // free rectangle; max_height is common, above max(hm') a level is all free, so candidates
+            // are ordered by  sum_{h < max(hm')} rect(h) - max(hm') * W * L
+            const int max_height = max(gmax, group_max<G>(settled ? mp + bz : 0));   // :3133
+            if (max_height > H) err |= 1;                                            // container[:, :, h] IndexError
+            const int cx = cell / L, cy = cell - cx * L;                             // x-major: own cell
+            int best_adj = INT_MIN, best_ord = INT_MAX;
+            u64 todo = tied;
+            while (todo) {
+                const int p = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const int Z = __shfl(mp, gl0 + p), po = __shfl(ord, gl0 + p);
+                const int py = p / W, px = p - py * W;
+                const bool foot = cx >= px && cx < px + bx && cy >= py && cy < py + by;
+                const int h2 = cell < cells ? (foot ? Z + bz : hm) : INT_MAX;
+                const int M = max(gmax, Z + bz);
+                int base = 0;
+                for (int h = 0; h < M;) {
+                    const u64 fm = ballot_g<G>(h2 <= h, gl0);                        // x-major free mask of level h
+                    const int nxt = min(M, group_min<G>(h2 > h ? h2 : INT_MAX));     // next level that differs
+                    int area = 0;
+                    if (cell < W) {
+                        unsigned acc = lmask;
+                        for (int i2 = cell; i2 < W; ++i2) {
+                            acc &= (unsigned)(fm >> (i2 * L)) & lmask;
+                            if (!acc) break;
+                            area = max(area, (i2 - cell + 1) * m3_longest_run(acc));
+                        }
+                    }
+                    base += (nxt - h) * group_max<G>(area);
+                    h = nxt;
+                }
+                const int adj = base - M * cells;
+                if (adj > best_adj || (adj == best_adj && po < best_ord)) { best_adj = adj; best_ord = po; win = p; }
+            }
+        }
+    }
+
+    // ---- commit (tools.py:3150-3163) -----------------------------------------------------------------
+    if (win >= 0) {
+        const int Z = __shfl(mp, gl0 + win), stab = __shfl(stab_p, gl0 + win), emp = __shfl(emp_p, gl0 + win);
+        const int py = win / W, px = win - py * W;
+        res.placed = 1; res.x = px; res.y = py; res.z = Z; res.stab = stab;
+        const int cx = cell / L, cy = cell - cx * L;
+        if (cell < cells && cx >= px && cx < px + bx && cy >= py && cy < py + by) {
+            // update_level_free_space (:2989-3041) on this cell's column of F
+            u64 keep = 0;
+            if (px > 0 && px + bx < W) {
+                keep = ~0ull;
+                for (int x = px - 1; x <= px + bx; ++x) keep &= ~S.occ[x * L + cy];
+            }
+            const u64 low = (1ull << Z) - 1ull; // Z < H <= 64
+            const u64 blk = (bz >= 64 ? ~0ull : ((1ull << bz) - 1ull)) << Z;
+            occ |= blk | (low & ~keep);
+            hm = Z + bz;                                                             // :3161
+        }
+        cnt.valid += vol;
+        cnt.empty = emp;
+        cnt.nstable += stab;
+        if (Z + bz > H) err |= 1;                                                    // level_free_space[zz] IndexError
+    }
+    cnt.count += 1;
+#undef M3_PACK
+#undef M3_PUSH
+#undef M3_EXT_UP
+#undef M3_EXT_DOWN
+    return res;
+}

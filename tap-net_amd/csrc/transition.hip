@@ -228,6 +228,8 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
+    if (d->strategy == TAP_MACS && d->D == 3)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition: MACS 3D runs unfused (tap_env_step_gather + tap_mask_step)");
     if (!state || !dyn_in || !static_ || !ptr || !mask_in || !colsum_in || !dyn_out || !colsum_out ||
         !current_out || !mask_out || n < 1 || R < 1 || rows < 1 || static_rows < 1 + d->D ||
         update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))

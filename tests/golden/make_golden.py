@@ -156,7 +156,7 @@ def make_macs3d(tools):
         meta = dict(cs=[5, 5, 50], n=10, reward=reward, feat="diff", strategy="MACS")
         cases.append((meta, trace_container(tools, [5, 5, 50], 10, reward, "diff", "MACS", blocks), blocks))
     for cs, n, hi, seed in (([6, 6, 60], 16, 6, 511), ([4, 7, 40], 12, 5, 512), ([7, 4, 40], 12, 5, 513),
-                            ([8, 8, 80], 24, 5, 514)):
+                            ([8, 8, 64], 24, 5, 514)):
         for reward in ("C+P+S-mcs-soft", "C+P+S-mcs-hard"):
             blocks = rand_blocks(seed, 8, n, 3, 1, hi, marginal=False)
             meta = dict(cs=cs, n=n, reward=reward, feat="full", strategy="MACS")
