@@ -96,82 +96,9 @@ template <int G>
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_step(StepArgs a)
 {
     extern __shared__ int lds[];
-    const int tid = threadIdx.x, cell = tid % G;
-    const int env = blockIdx.x * ((int)blockDim.x / G) + tid / G;
-    const int B = a.d.B, W = a.d.W, Ld = a.d.L, cells = W * Ld;
-    const bool ev = env < B, incell = cell < cells;
-    const int gl0 = (tid & 63) - cell;
-    const Macs3Lds S = macs3_lds(lds + (tid / G) * macs3_group_words(G, a.d.n_max), G);
-
-    int hm = (ev && incell) ? a.v.hm[(size_t)env * cells + cell] : 0;
-    u64 occ = (ev && incell) ? a.v.occ[(size_t)env * cells + cell] : 0ull;
-    const int cv = (ev && cell < 4) ? a.v.cnt[(size_t)env * 4 + cell] : 0;
-    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
-    int bx = 1, by = 1, bz = 1;
-    bool act = ev;
-    if (ev) {
-        if (a.static_) {
-            const long p = (long)a.ptr[env];
-            bx = (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
-            by = (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
-            bz = (int)a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
-        } else if (a.blocks_dtype == TAP_DT_F32) {
-            const float *b = (const float *)a.blocks + (size_t)env * 3;
-            bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];
-        } else {
-            const int32_t *b = (const int32_t *)a.blocks + (size_t)env * 3;
-            bx = b[0]; by = b[1]; bz = b[2];
-        }
-        if (a.active) act = a.active[env] != 0;
-    }
-    int err = 0;
-    bool do_step = act;
-    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }
-    // sides larger than the container are rejected as invalid input: the reference keeps such a
-    // block in its history at (0,0,0) and its later slices run out of range (tools.py:2858, 2914)
-    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > Ld)) { err |= 4; do_step = false; }
-
-    S.hm[cell] = hm;
-    S.occ[cell] = occ;
-    if (ev) // one round trip for the whole placement history
-        for (int k = cell; k < cnt.count * 6 && k < a.d.n_max * 6; k += G) {
-            const int i = k / 6, f = k - i * 6;
-            const int v = (f < 3 ? a.v.pos : a.v.blk)[(size_t)(i * 3 + (f < 3 ? f : f - 3)) * B + env];
-            S.hist[i * MACS3_HIST + f] = f == 3 ? (v & 0xffff) : v;
-            if (f == 3) S.hist[i * MACS3_HIST + 6] = v >> 16; // placed flag rides on the x size
-        }
-    tap_wave_lds_sync();
-    const int step = cnt.count;
-    const PlaceCfg cfg = {W, Ld, a.d.H, a.d.flags, a.lut};
-    const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, occ, cnt, err, bx, by, bz, do_step);
-    err = group_or<G>(err);
-
-    tap_wave_lds_sync();
-    S.hm[cell] = hm;
-    tap_wave_lds_sync();
-    if (ev) {
-        if (incell) {
-            a.v.hm[(size_t)env * cells + cell] = hm;
-            a.v.occ[(size_t)env * cells + cell] = occ;
-        }
-        if (a.feature_out)
-            tap_write_feature<3, G>(a.d.feature, W, Ld, S.hm, cell, hm, a.feature_out + (size_t)env * a.flen);
-        if (cell == 0) {
-            if (do_step) {
-                reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
-                a.v.pos[(size_t)(step * 3) * B + env] = pl.x;
-                a.v.pos[(size_t)(step * 3 + 1) * B + env] = pl.y;
-                a.v.pos[(size_t)(step * 3 + 2) * B + env] = pl.z;
-                a.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
-                a.v.blk[(size_t)(step * 3) * B + env] = bx | (pl.placed << 16); // history of later steps
-                a.v.blk[(size_t)(step * 3 + 1) * B + env] = by;                  // (tools.py:2843-2846),
-                a.v.blk[(size_t)(step * 3 + 2) * B + env] = bz;                  // failures too
-            }
-            if (err) a.v.err[env] |= err;
-        }
-    } else if (a.d.feature == TAP_FEAT_ZERO) {
-        (void)group_min<G>(INT_MAX);
-    }
+    const int tid = threadIdx.x;
+    tap_macs3_wave<G>(a, 0, nullptr, blockIdx.x * ((int)blockDim.x / G) + tid / G, tid % G, tid & 63,
+                      lds + (tid / G) * macs3_group_words(G, a.d.n_max));
 }
 
 template <int G> static int launch_macs3(tap_ctx *ctx, const StepArgs &a, hipStream_t st)

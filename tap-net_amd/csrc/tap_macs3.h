@@ -29,6 +29,7 @@
 // of the largest free rectangle, computed per tied candidate from one ballot per distinct height.
 #pragma once
 
+#include "tap_common.h"
 #include "tap_place.h"
 
 constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 8x8, 40 blocks)
@@ -459,4 +460,105 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
 #undef M3_EXT_UP
 #undef M3_EXT_DOWN
     return res;
+}
+
+// One env's whole step as executed by its lane group (stand-alone step in macs.hip, placement waves
+// of the fused transition in transition.hip): load state + history, place, store state, feature,
+// and -- for the fused form -- the fresh-container start and calc_ratio (flags: TAP_T_*).
+template <int G>
+__device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio_out, int env, int cell, int lane,
+                                      int *lds_group)
+{
+    const int B = a.d.B, W = a.d.W, Ld = a.d.L, cells = W * Ld;
+    const bool ev = env < B, incell = cell < cells, fresh = flags & TAP_T_FRESH;
+    const int gl0 = lane - cell;
+    const Macs3Lds S = macs3_lds(lds_group, G);
+
+    int hm = 0, cv = 0;
+    u64 occ = 0;
+    if (ev && !fresh) {
+        if (incell) {
+            hm = a.v.hm[(size_t)env * cells + cell];
+            occ = a.v.occ[(size_t)env * cells + cell];
+        }
+        if (cell < 4) cv = a.v.cnt[(size_t)env * 4 + cell];
+    }
+    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
+    int bx = 1, by = 1, bz = 1;
+    bool act = ev;
+    if (ev) {
+        if (a.static_) {
+            const long p = (long)a.ptr[env];
+            bx = (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+            by = (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+            bz = (int)a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
+        } else if (a.blocks_dtype == TAP_DT_F32) {
+            const float *b = (const float *)a.blocks + (size_t)env * 3;
+            bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];
+        } else {
+            const int32_t *b = (const int32_t *)a.blocks + (size_t)env * 3;
+            bx = b[0]; by = b[1]; bz = b[2];
+        }
+        if (a.active) act = a.active[env] != 0;
+    }
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }
+    // sides larger than the container are rejected as invalid input: the reference keeps such a
+    // block in its history at (0,0,0) and its later slices run out of range (tools.py:2858, 2914)
+    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > Ld)) { err |= 4; do_step = false; }
+
+    S.hm[cell] = hm;
+    S.occ[cell] = occ;
+    if (ev) // one round trip for the whole placement history
+        for (int k = cell; k < cnt.count * 6 && k < a.d.n_max * 6; k += G) {
+            const int i = k / 6, f = k - i * 6;
+            const int v = (f < 3 ? a.v.pos : a.v.blk)[(size_t)(i * 3 + (f < 3 ? f : f - 3)) * B + env];
+            S.hist[i * MACS3_HIST + f] = f == 3 ? (v & 0xffff) : v;
+            if (f == 3) S.hist[i * MACS3_HIST + 6] = v >> 16; // placed flag rides on the x size
+        }
+    tap_wave_lds_sync();
+    const int step = cnt.count;
+    const PlaceCfg cfg = {W, Ld, a.d.H, a.d.flags, a.lut};
+    const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, occ, cnt, err, bx, by, bz, do_step);
+    err = group_or<G>(err);
+
+    tap_wave_lds_sync();
+    S.hm[cell] = hm;
+    tap_wave_lds_sync();
+    const int gmax = (flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
+    if (ev) {
+        if (incell && (do_step || fresh)) {
+            a.v.hm[(size_t)env * cells + cell] = hm;
+            a.v.occ[(size_t)env * cells + cell] = occ;
+        }
+        if (a.feature_out)
+            tap_write_feature<3, G>(a.d.feature, W, Ld, S.hm, cell, hm, a.feature_out + (size_t)env * a.flen);
+        if (cell == 0) {
+            if (do_step || fresh)
+                reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+            if (do_step) {
+                a.v.pos[(size_t)(step * 3) * B + env] = pl.x;
+                a.v.pos[(size_t)(step * 3 + 1) * B + env] = pl.y;
+                a.v.pos[(size_t)(step * 3 + 2) * B + env] = pl.z;
+                a.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
+                a.v.blk[(size_t)(step * 3) * B + env] = bx | (pl.placed << 16); // history of later steps
+                a.v.blk[(size_t)(step * 3 + 1) * B + env] = by;                  // (tools.py:2843-2846),
+                a.v.blk[(size_t)(step * 3 + 2) * B + env] = bz;                  // failures too
+            }
+            if (fresh) a.v.err[env] = err;
+            else if (err) a.v.err[env] |= err;
+            if (flags & TAP_T_RATIO) {                                            // tools.py:3887-3966
+                double C = 0.0, P = 0.0, S_ = 0.0;
+                if (cnt.count != 0) {
+                    C = (double)cnt.valid / (double)((long long)W * Ld * gmax);
+                    P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
+                    S_ = (double)cnt.nstable / (double)cnt.count;
+                }
+                ratio_out[env] = (float)tap_ratio_formula(a.d.ratio_mode, C, P, S_);
+            }
+        }
+    } else if (a.d.feature == TAP_FEAT_ZERO) {
+        (void)group_min<G>(INT_MAX);
+    }
 }

@@ -18,6 +18,7 @@
 
 #include "tap_common.h"
 #include "tap_macs.h"
+#include "tap_macs3.h"
 #include "tap_masks.h"
 #include "tap_place.h"
 #include "tap_waves.h"
@@ -176,6 +177,44 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
     }
 }
 
+// ---- and for MACS / MUL 3D (tap_macs3.h): G = 8..64 lanes per env --------------------------------
+template <int G, int NC>
+__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3(TransArgs a)
+{
+    using Geo = TransGeom<G, 4>;
+    constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
+    extern __shared__ float trans_lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int env_base = blockIdx.x * EPB;
+    if (wave >= ENV_WAVES) {
+        trans_stream_wave<SPW, NC>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+                                     trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
+        return;
+    }
+    __builtin_amdgcn_s_setprio(2);
+    int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
+    tap_macs3_wave<G>(a.s, a.flags, a.ratio_out, env_base + tid / G, tid % G, lane,
+                      macs_base + (tid / G) * macs3_group_words(G, a.s.d.n_max));
+}
+
+template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
+{
+    constexpr int EPB = TransGeom<G, 4>::EPB, THREADS = TransGeom<G, 4>::THREADS;
+    const int grid = (a.s.d.B + EPB - 1) / EPB;
+    if (grid == 0) return TAP_OK;
+    const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
+                       (size_t)EPB * macs3_group_words(G, a.s.d.n_max) * sizeof(int);
+    if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
+    switch (mask_fast_path_cols(a.m)) {
+    case 1: hipLaunchKernelGGL((k_transition_macs3<G, 1>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((k_transition_macs3<G, 2>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((k_transition_macs3<G, 4>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    default: hipLaunchKernelGGL((k_transition_macs3<G, 0>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    }
+    TAP_LAUNCH_CHECK(ctx, "k_transition_macs3");
+    return TAP_OK;
+}
+
 int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d); // macs.hip
 
 template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
@@ -228,8 +267,6 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
-    if (d->strategy == TAP_MACS && d->D == 3)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition: MACS 3D runs unfused (tap_env_step_gather + tap_mask_step)");
     if (!state || !dyn_in || !static_ || !ptr || !mask_in || !colsum_in || !dyn_out || !colsum_out ||
         !current_out || !mask_out || n < 1 || R < 1 || rows < 1 || static_rows < 1 + d->D ||
         update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
@@ -246,6 +283,14 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     a.flags = flags;
     a.ratio_out = ratio_out;
     const int Gs = tap_group_size(d);
+    if (d->strategy == TAP_MACS && d->D == 3) {
+        switch (Gs) {
+        case 8: return launch_transition_macs3<8>(ctx, a, (hipStream_t)stream);
+        case 16: return launch_transition_macs3<16>(ctx, a, (hipStream_t)stream);
+        case 32: return launch_transition_macs3<32>(ctx, a, (hipStream_t)stream);
+        default: return launch_transition_macs3<64>(ctx, a, (hipStream_t)stream);
+        }
+    }
     if (d->strategy == TAP_MACS)
         return d->W <= 8 ? launch_transition_macs<8>(ctx, a, (hipStream_t)stream)
                          : launch_transition_macs<16>(ctx, a, (hipStream_t)stream);
