@@ -36,24 +36,28 @@ constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 
 constexpr int MACS3_MAX_H = 64;
 constexpr int MACS3_HIST = 8;      // ints per history entry: x y z xx yy zz placed pad
 
-// LDS words per env group: occ u64[G] | hm[G] | ord[G] | ems[CAP] | hist[8 n_max]
+// LDS words per env group: occ u64[G] | lvm u64[G+2] | hm[G] | ord[G] | lvh[G+2] | lvr[G+2] | ems[CAP] |
+// hist[8 n_max]   (lv*: the distinct levels of the height-map, at most cells + 1 of them)
 __host__ __device__ constexpr int macs3_group_words(int G, int n_max)
 {
-    return 2 * G + G + G + MACS3_EMS_CAP + MACS3_HIST * n_max;
+    return 2 * G + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + MACS3_HIST * n_max;
 }
 
 struct Macs3Lds {
-    u64 *occ;
-    int *hm, *ord, *ems, *hist;
+    u64 *occ, *lvm;
+    int *hm, *ord, *lvh, *lvr, *ems, *hist;
 };
 
 __device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G)
 {
     Macs3Lds m;
     m.occ = reinterpret_cast<u64 *>(base);
-    m.hm = base + 2 * G;
+    m.lvm = m.occ + G;
+    m.hm = base + 2 * G + 2 * (G + 2);
     m.ord = m.hm + G;
-    m.ems = m.ord + G;
+    m.lvh = m.ord + G;
+    m.lvr = m.lvh + G + 2;
+    m.ems = m.lvr + G + 2;
     m.hist = m.ems + MACS3_EMS_CAP;
     return m;
 }
@@ -94,6 +98,20 @@ __device__ __forceinline__ int m3_longest_run(unsigned v)
     int r = 0;
     while (v) { v &= v << 1; ++r; }
     return r;
+}
+// largest all-free axis-aligned rectangle of an x-major W x L bit grid (bit x*L + y)
+__device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask)
+{
+    int best = 0;
+    for (int i1 = 0; i1 < W; ++i1) {
+        unsigned acc = lmask;
+        for (int i2 = i1; i2 < W; ++i2) {
+            acc &= (unsigned)(fm >> (i2 * L)) & lmask;
+            if (!acc) break;
+            best = max(best, (i2 - i1 + 1) * m3_longest_run(acc));
+        }
+    }
+    return best;
 }
 
 // One placement.  Preconditions: S.hm[cell] = hm, S.occ[cell] = occ (x-major cells, 0 beyond W*L),
@@ -395,39 +413,49 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         } else {                                                                     // :3132-3144
             // calc_maximal_usable_spaces (:3049-3077) = sum over levels h < max_height of the largest
             // free rectangle; max_height is common, above max(hm') a level is all free, so candidates
-            // are ordered by  sum_{h < max(hm')} rect(h) - max(hm') * W * L
+            // are ordered by  sum_{h < max(hm')} rect(h) - max(hm') * W * L.
+            // The current map's distinct levels (height, free mask, largest rectangle) are tabulated
+            // once by the group; a candidate's map differs only under its footprint, and only below
+            // its top, so every tied lane then sums its own candidate serially from that table.
             const int max_height = max(gmax, group_max<G>(settled ? mp + bz : 0));   // :3133
             if (max_height > H) err |= 1;                                            // container[:, :, h] IndexError
-            const int cx = cell / L, cy = cell - cx * L;                             // x-major: own cell
-            int best_adj = INT_MIN, best_ord = INT_MAX;
-            u64 todo = tied;
-            while (todo) {
-                const int p = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const int Z = __shfl(mp, gl0 + p), po = __shfl(ord, gl0 + p);
-                const int py = p / W, px = p - py * W;
-                const bool foot = cx >= px && cx < px + bx && cy >= py && cy < py + by;
-                const int h2 = cell < cells ? (foot ? Z + bz : hm) : INT_MAX;
-                const int M = max(gmax, Z + bz);
-                int base = 0;
-                for (int h = 0; h < M;) {
-                    const u64 fm = ballot_g<G>(h2 <= h, gl0);                        // x-major free mask of level h
-                    const int nxt = min(M, group_min<G>(h2 > h ? h2 : INT_MAX));     // next level that differs
-                    int area = 0;
-                    if (cell < W) {
-                        unsigned acc = lmask;
-                        for (int i2 = cell; i2 < W; ++i2) {
-                            acc &= (unsigned)(fm >> (i2 * L)) & lmask;
-                            if (!acc) break;
-                            area = max(area, (i2 - cell + 1) * m3_longest_run(acc));
-                        }
-                    }
-                    base += (nxt - h) * group_max<G>(area);
-                    h = nxt;
-                }
-                const int adj = base - M * cells;
-                if (adj > best_adj || (adj == best_adj && po < best_ord)) { best_adj = adj; best_ord = po; win = p; }
+            const int hx = cell < cells ? hm : INT_MAX;                              // x-major: own cell
+            int nl = 0;
+            for (int h = 0;;) {
+                S.lvh[nl] = h;                                                       // same value from every lane
+                S.lvm[nl] = ballot_g<G>(hx <= h, gl0);
+                ++nl;
+                const int nxt = group_min<G>(hx > h ? hx : INT_MAX);
+                if (nxt == INT_MAX) break;
+                h = nxt;
             }
+            for (int k = cell; k < nl; k += G) S.lvr[k] = m3_maxrect(S.lvm[k], W, L, lmask);
+            tap_wave_lds_sync();
+            int adj = INT_MIN;
+            if (settled && r == rmax) {
+                const int Zt = mp + bz, M = max(gmax, Zt);
+                u64 footm = 0;
+                for (int i = 0; i < bx; ++i) footm |= (u64)(((1u << by) - 1u) << ty) << ((tx + i) * L);
+                int base = 0;
+                for (int k = 0; k < nl; ++k) {
+                    const int lo = S.lvh[k];
+                    if (lo >= M) break;
+                    const int hi = min(M, k + 1 < nl ? S.lvh[k + 1] : INT_MAX);
+                    const u64 fm = S.lvm[k];
+                    const int a_hi = min(hi, Zt), b_lo = max(lo, Zt);
+                    if (a_hi > lo)                                                   // below the block's top
+                        base += (a_hi - lo) * ((fm & footm) ? m3_maxrect(fm & ~footm, W, L, lmask) : S.lvr[k]);
+                    if (hi > b_lo) base += (hi - b_lo) * S.lvr[k];
+                }
+                adj = base - M * cells;
+            }
+            int best_ord = (settled && r == rmax) ? ord : INT_MAX;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) { // lexicographic (adj desc, order asc)
+                const int a2 = __shfl_xor(adj, o, G), o2 = __shfl_xor(best_ord, o, G);
+                if (a2 > adj || (a2 == adj && o2 < best_ord)) { adj = a2; best_ord = o2; }
+            }
+            win = __ffsll((long long)ballot_g<G>(settled && ord == best_ord, gl0)) - 1;
         }
     }
 
