@@ -49,6 +49,8 @@ CONFIGS = {
     "c5": ("3D nodes=50 (5 consecutive 10-node precedence windows) container_width=5x5 H=250 LB_GREEDY "
            "batch=8192 per GPU (BASELINE configs[4] shard)",
            3, [5, 5, 250], 50, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
+    "c6": ("3D RAND nodes=10 container_width=5x5 MACS batch=4096 on 1xMI355X (not a BASELINE config: SURVEY 8(f) f3)",
+           3, [5, 5, 50], 10, 4096, "C+P+S-mcs-soft", "MACS"),
 }
 
 
@@ -69,14 +71,14 @@ class HotPath(object):
     An episode is `windows` consecutive precedence windows of `nw` nodes each over ONE long-lived
     container per env (windows = 1 except for the rolling-sized config c5)."""
 
-    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None):
+    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None, bits=True):
         _, D, cs, n, _, reward, strategy = cfg
         self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
         self.nw = window or n
         assert n % self.nw == 0
         self.windows = n // self.nw
         f32 = dict(dtype=torch.float32, device=device)
-        self.static, self.dynamic0, self.tape, self.cs0 = [], [], [], []
+        self.static, self.dynamic0, self.tape, self.cs0, self.bits0 = [], [], [], [], []
         for w in range(self.windows):
             static, dynamic = synth.rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start)
             tape = synth.random_feasible_tape(static, dynamic, self.nw, seed=seed + 100 * w + 1, start=start)
@@ -84,11 +86,18 @@ class HotPath(object):
             self.dynamic0.append(dynamic.to(device))
             self.tape.append(tape.t().contiguous().to(device))  # (nw, B): one contiguous ptr row per step
             self.cs0.append(T.pack.dynamic_colsum(self.dynamic0[-1], self.nw).clone())
+            # the instance's bit shadow, like its column sums, is dataset-time data (built once per
+            # instance, not per pass); only valid for 0/1 tensors of a supported shape
+            ok = bits and T.pack.bits_supported(self.dynamic0[-1].shape[1], self.dynamic0[-1].shape[2])
+            shadow, bad = T.pack.dynamic_bits(self.dynamic0[-1]) if ok else (None, None)
+            self.bits0.append(shadow if ok and int(bad.item()) == 0 else None)
+        self.bits = all(b is not None for b in self.bits0)
         self.R = self.static[0].shape[2] // self.nw
         self.nR, self.rows = self.static[0].shape[2], self.dynamic0[0].shape[1]
         self.env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=device)
         self.dyn = [torch.empty_like(self.dynamic0[0]), torch.empty_like(self.dynamic0[0])]
         self.csb = [torch.empty_like(self.cs0[0]), torch.empty_like(self.cs0[0])]
+        self.bitb = [torch.empty_like(self.bits0[0]), torch.empty_like(self.bits0[0])] if self.bits else None
         self.mask0 = torch.ones(B, self.nR, **f32)
         self.maskb = [torch.empty(B, self.nR, **f32), torch.empty(B, self.nR, **f32)]
         self.cur = torch.empty(B, self.nR, **f32)
@@ -117,14 +126,27 @@ class HotPath(object):
         for w in range(self.windows):
             st = self.static[w]
             dyn_in, cs_in, mask_in = self.dynamic0[w], self.cs0[w], self.mask0
+            bits_in = self.bits0[w]
             for t in range(self.nw):
                 ptr = self.tape[w][t]
                 o = t & 1
-                if self.fused:
-                    flags = (_lib.TAP_T_FRESH if step == 0 else 0) | (_lib.TAP_T_RATIO if step == self.n - 1 else 0)
+                flags = (_lib.TAP_T_FRESH if step == 0 else 0) | (_lib.TAP_T_RATIO if step == self.n - 1 else 0)
+                if self.fused and self.bits:
+                    self._k("transition", L.tap_transition_bits, self.ctx, d, P(e._state), self.nw, self.R,
+                            self.rows, 3, P(bits_in), P(st), st.shape[1], P(ptr), P(mask_in), P(self.bitb[o]),
+                            P(self.dyn[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
+                    bits_in = self.bitb[o]
+                elif self.fused:
                     self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.nw, self.R, self.rows,
                             3, P(dyn_in), P(st), st.shape[1], P(ptr), P(mask_in), P(cs_in), P(self.dyn[o]),
                             P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
+                elif self.bits:
+                    self._k("mask_step", L.tap_mask_step_bits, self.ctx, self.B, self.nw, self.R, self.rows, 3,
+                            P(bits_in), P(st), st.shape[1], P(ptr), P(mask_in), P(self.bitb[o]), P(self.dyn[o]),
+                            P(self.cur), P(self.maskb[o]))
+                    self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st),
+                            st.shape[1], self.nR, P(ptr), None, P(self.feat))
+                    bits_in = self.bitb[o]
                 else:
                     self._k("mask_step", L.tap_mask_step, self.ctx, self.B, self.nw, self.R, self.rows, 3,
                             P(dyn_in), P(st), st.shape[1], P(ptr), P(mask_in), P(cs_in),
@@ -423,6 +445,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bits", action="store_true",
+                    help="precedence update as an fp32 copy (tap_transition) instead of on the bit shadow (tap_transition_bits)")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
     ap.add_argument("--fused-rolling", action="store_true", help="c5: tap_rolling_step instead of env_step + rolling_window")
     ap.add_argument("--approx-windows", action="store_true",
@@ -446,7 +470,7 @@ def main():
     if rolling:
         hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=args.fused_rolling)
     else:
-        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config))
+        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits)
     use_graph = not args.no_graph
     dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
     hp.env.check()
@@ -481,8 +505,10 @@ def main():
                        "reward_type": reward, "packing_strategy": strategy,
                        "pass": ("rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window) "
                                 "[or tap_rolling_step with --fused-rolling], then window x tap_transition on the last graph") if rolling else
-                               ("n x tap_transition (update_dynamic+update_mask+gather+add_new_block in one launch; "
-                                "first starts a fresh container, last emits calc_ratio)") if hp.fused else
+                               ("n x tap_transition%s (update_dynamic+update_mask+gather+add_new_block in one launch; "
+                                "first starts a fresh container, last emits calc_ratio)%s" %
+                                (("_bits", "; dynamic carried between steps as a bit shadow, the fp32 tensor is written "
+                                  "every step but not re-read") if getattr(hp, "bits", False) else ("", ""))) if hp.fused else
                                "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

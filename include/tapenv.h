@@ -234,6 +234,27 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
                   const float *mask_in, const float *colsum_in, float *dyn_out, float *colsum_out,
                   float *current_out, float *mask_out, void *stream);
 
+/* ---- the same two seams on a bit shadow of `dynamic` ------------------------------------ */
+/* `dynamic` only ever holds 0 and 1 (the precedence matrices PACKDataset builds, pack.py:101-195;
+ * update_dynamic only writes zeros, pack.py:370-374).  Carried as a (B, nR) uint64 shadow -- word j
+ * of env b = column j, bit r = dynamic[b, r, j] != 0, rows <= 64 -- a step no longer re-reads the
+ * fp32 tensor: clearing the chosen rows is an AND, the column sums of pack.py:323-326 are popcounts,
+ * and the fp32 tensor the network consumes next (model.py:378) is expanded from the bits, so the
+ * step WRITES rows*nR*4 bytes per env and reads nR*8.  Outputs are bit-identical to tap_mask_step /
+ * tap_transition for 0/1 input. */
+
+/* bits_out = shadow of dynamic; *nonbinary_out (device int32, nullable, caller zeroes it) is
+ * incremented by the number of elements that are neither 0 nor 1 -- the shadow is only valid at 0. */
+int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
+                 unsigned long long *bits_out, int32_t *nonbinary_out, void *stream);
+
+/* tap_mask_step on the shadow.  dyn_out nullable (callers that only need the masks).  Requires
+ * nR % 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers, bits_in != bits_out. */
+int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
+                       const unsigned long long *bits_in, const float *static_, int static_rows,
+                       const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
+                       float *dyn_out, float *current_out, float *mask_out, void *stream);
+
 /* ---- one whole lock-step in one launch --------------------------------------------------- */
 
 enum {
@@ -252,6 +273,14 @@ int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int 
                    const int64_t *ptr, const float *mask_in, const float *colsum_in,
                    float *dyn_out, float *colsum_out, float *current_out, float *mask_out,
                    float *feature_out, float *ratio_out, int flags, void *stream);
+
+/* tap_transition with the precedence update done on the bit shadow (tap_mask_step_bits). */
+int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                        int update_rows, const unsigned long long *bits_in, const float *static_,
+                        int static_rows, const int64_t *ptr, const float *mask_in,
+                        unsigned long long *bits_out, float *dyn_out, float *current_out,
+                        float *mask_out, float *feature_out, float *ratio_out, int flags,
+                        void *stream);
 
 #ifdef __cplusplus
 }

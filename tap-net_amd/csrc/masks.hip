@@ -31,6 +31,27 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_colsum(int B, int n, int nR, 
     }
 }
 
+// ---- bit shadow: bits[b, j] bit r = dynamic[b, r, j] != 0; counts the elements that are not 0 / 1 ----
+__global__ void __launch_bounds__(TAP_BLOCK) k_dyn_bits(int B, int nR, int rows, const float *__restrict__ dyn,
+                                                        unsigned long long *__restrict__ bits, int *nonbinary)
+{
+    const int env = blockIdx.x * ENVS_PER_BLOCK + threadIdx.x / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (env >= B) return;
+    const float *slab = dyn + (size_t)env * rows * nR;
+    int bad = 0;
+    for (int j = lane; j < nR; j += WAVE) {
+        unsigned long long w = 0;
+        for (int r = 0; r < rows; ++r) {
+            const float v = slab[(size_t)r * nR + j];
+            w |= (unsigned long long)(v != 0.f) << r;
+            bad += (v != 0.f && v != 1.f);
+        }
+        bits[(size_t)env * nR + j] = w;
+    }
+    if (bad && nonbinary) atomicAdd(nonbinary, bad);
+}
+
 // ---- fused step: copy-with-zeroed-rows + incremental column sums + both masks ----------------
 // NC > 0 = stream_wave_fast with NC columns per lane (nR % 4 == 0, nR <= 256, aligned, shadow
 // given); NC == 0 = the generic
@@ -46,7 +67,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     if (env >= a.B) return;
     if (NC > 0) {
         const bool on[1] = {true};
-        stream_wave_fast<1, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
+        if (a.bits_in) stream_wave_bits<1, (NC > 0 ? NC : 1)>(a, env, lane, on);
+        else stream_wave_fast<1, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         return;
     }
     const int nR = a.nR;
@@ -101,6 +123,37 @@ extern "C" int tap_dyn_colsum(tap_ctx *ctx, int B, int n, int nR, int rows, cons
                        rows, dynamic, colsum_out);
     TAP_LAUNCH_CHECK(ctx, "k_dyn_colsum");
     return TAP_OK;
+}
+
+extern "C" int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
+                            unsigned long long *bits_out, int32_t *nonbinary_out, void *stream)
+{
+    if (B < 0 || nR < 1 || rows < 1) return tap_fail(ctx, TAP_E_INVALID, "bad shape B=%d nR=%d rows=%d", B, nR, rows);
+    if (rows > 64) return tap_fail(ctx, TAP_E_UNSUPPORTED, "the bit shadow holds at most 64 rows (rows=%d)", rows);
+    if (!dynamic || !bits_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    const int grid = (B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    if (grid == 0) return TAP_OK;
+    hipLaunchKernelGGL(k_dyn_bits, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, B, nR, rows, dynamic,
+                       bits_out, nonbinary_out);
+    TAP_LAUNCH_CHECK(ctx, "k_dyn_bits");
+    return TAP_OK;
+}
+
+extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
+                                  const unsigned long long *bits_in, const float *static_, int static_rows,
+                                  const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
+                                  float *dyn_out, float *current_out, float *mask_out, void *stream)
+{
+    int rc = check_shape(ctx, B, n, n * R, rows);
+    if (rc) return rc;
+    if (!bits_in || !static_ || !ptr || !mask_in || !bits_out || !current_out || !mask_out || static_rows < 1 ||
+        update_rows < 0 || update_rows > 3 || bits_in == bits_out)
+        return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_bits arguments");
+    MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
+                  mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};
+    if (!mask_bits_ok(a))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+    return launch_mask_step(ctx, a, (hipStream_t)stream);
 }
 
 extern "C" int tap_update_dynamic(tap_ctx *ctx, int B, int n, int nR, int rows, int update_rows,

@@ -16,7 +16,20 @@ struct MaskArgs {
     float *cs_out;
     float *cur_out;
     float *mask_out;
+    // bit shadow of a 0/1-valued dynamic tensor (tap_dyn_bits): word j of env b holds column j, bit r =
+    // dynamic[b, r, j] != 0.  When bits_in is set the step never reads dyn_in or the colsum shadow.
+    const unsigned long long *bits_in;
+    unsigned long long *bits_out;
 };
+
+// 16-byte store of a tensor this kernel will not touch again (nontemporal: measured +9 % on the
+// write-bound bit-shadow step at B = 8192)
+__device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
+{
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f nv = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+}
 
 // mask math for one column: pack.py:318-329
 __device__ __forceinline__ void mask_column(const MaskArgs &a, int env, int j, long real_m,
@@ -154,7 +167,7 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
                         *reinterpret_cast<float4 *>(lds + (k * 3 + s) * nR + (f - cr[k].lo[s])) = v[u];
                         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                d4[q] = v[u];
+                d4[q] = v[u]; // regular store: the next step reads this tensor back (nontemporal: -16 %)
             }
         }
     }
@@ -187,9 +200,106 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
     }
 }
 
+// ---- the same step on the bit shadow ---------------------------------------------------------------
+// `dynamic` only ever holds 0 and 1 (precedence matrices, pack.py:101-195), so the step can carry it
+// as rows <= 64 bits per column: clearing the chosen rows is one AND per column, the three column
+// sums of pack.py:323-326 are popcounts, and the fp32 tensor the network consumes (model.py:378) is
+// EXPANDED from the bits instead of copied -- the step writes `rows*nR*4` bytes per env and reads
+// `nR*8`, half the traffic of the copy.  One round trip: every input is loaded up front and `real`
+// comes out of the row-0 registers by shuffle, as above.  Lane (rsub, c4) = lane / (nR/4), lane %
+// (nR/4) keeps four column words and writes the float4 of rows rsub, rsub + 64/(nR/4), ...: a wave
+// store instruction covers whole consecutive rows.  Requirements: nR % 4 == 0, nR <= 64*NC, rows <= 64.
+template <int NS, int NC>
+__device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS])
+{
+    typedef unsigned long long u64;
+    const int nR = a.nR, C4 = nR >> 2, rows = a.rows;
+    const int rsub = lane / C4, c4 = lane - rsub * C4, RP = 64 / C4;
+    const bool lane_on = rsub < RP;
+    long p[NS];
+    float row0[NS][NC], keep[NS][NC];
+    u64 bj[NS][NC];
+    ulonglong2 w[NS][2];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int env = senv0 + k;
+        p[k] = on[k] ? (long)a.ptr[env] : 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            const bool ok = on[k] && j < nR;
+            row0[k][c] = ok ? a.static_[(size_t)env * a.static_rows * nR + j] : 0.f;
+            keep[k][c] = ok ? (a.mask_in ? a.mask_in[(size_t)env * nR + j] : 1.f) : 0.f;
+            bj[k][c] = ok ? a.bits_in[(size_t)env * nR + j] : 0ull;
+        }
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + c4 * 4);
+        const bool ok = on[k] && lane_on;
+        w[k][0] = ok ? src[0] : make_ulonglong2(0, 0);
+        w[k][1] = ok ? src[1] : make_ulonglong2(0, 0);
+    }
+    const u64 nmask = (a.n >= 64) ? ~0ull : ((1ull << a.n) - 1ull);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (!on[k]) continue;
+        const int env = senv0 + k;
+        float r0 = 0.f;                                                       // pack.py:339 via shuffle
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float t = __shfl(row0[k][c], (int)(p[k] & 63));
+            if ((p[k] >> 6) == c) r0 = t;
+        }
+        const long real = (long)r0;
+        u64 clr = 0;                                                          // pack.py:370-374
+        for (int i = 0; i < a.update_rows; ++i) {
+            const long r = real + (long)a.n * i;
+            if (real >= 0 && r < rows) clr |= 1ull << r;
+        }
+        if (lane_on) {
+            const u64 n0 = w[k][0].x & ~clr, n1 = w[k][0].y & ~clr, n2 = w[k][1].x & ~clr, n3 = w[k][1].y & ~clr;
+            if (a.dyn_out) {
+                float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
+                for (int r = rsub; r < rows; r += RP) {
+                    const float4 v = make_float4((float)((n0 >> r) & 1ull), (float)((n1 >> r) & 1ull),
+                                                 (float)((n2 >> r) & 1ull), (float)((n3 >> r) & 1ull));
+                    store_stream(&dst[(size_t)r * C4], v);
+                }
+            }
+            if (rsub == 0 && a.bits_out) {
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + (size_t)env * nR + c4 * 4);
+                dst[0] = make_ulonglong2(n0, n1);
+                dst[1] = make_ulonglong2(n2, n3);
+            }
+        }
+        long real_m = p[k];
+        while (real_m >= a.n) real_m -= a.n;                                  // pack.py:314-316
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            if (j >= nR) continue;
+            const u64 nb = bj[k][c] & ~clr;
+            const int move = __popcll(nb & nmask), small = a.n >= 64 ? 0 : __popcll((nb >> a.n) & nmask);
+            const int large = a.n >= 32 ? 0 : __popcll((nb >> (2 * a.n)) & nmask); // rows <= 64
+            float kp = keep[k][c];
+            for (int r = 0; r < a.R; ++r)
+                if (j == real_m + (long)a.n * r) kp = 0.f;                    // pack.py:320-321
+            if (a.mask_out) a.mask_out[(size_t)env * nR + j] = kp;
+            if (a.cur_out) a.cur_out[(size_t)env * nR + j] = (small * large + move) != 0 ? 0.f : kp; // :327-329
+        }
+    }
+}
+
+// the bit shadow needs 16-byte rows of words and float4 rows
+inline bool mask_bits_ok(const MaskArgs &a)
+{
+    return a.bits_in && a.ptr && a.static_ && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 && a.rows <= 64 &&
+           (reinterpret_cast<uintptr_t>(a.dyn_out) % 16 == 0) &&
+           ((reinterpret_cast<uintptr_t>(a.bits_in) | reinterpret_cast<uintptr_t>(a.bits_out)) % 16 == 0);
+}
+
 // columns per lane the fast path needs: 1, 2 or 4; 0 = use the generic element-wise path
 inline int mask_fast_path_cols(const MaskArgs &a)
 {
+    if (a.bits_in) return a.nR <= 64 ? 1 : a.nR <= 128 ? 2 : 4; // mask_bits_ok checked by the caller
     const bool ok = a.dyn_out && a.ptr && a.static_ && a.cs_in && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 &&
                     ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
     return !ok ? 0 : a.nR <= 64 ? 1 : a.nR <= 128 ? 2 : 4;

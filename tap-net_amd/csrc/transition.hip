@@ -39,7 +39,8 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
 #pragma unroll
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
     if (NC > 0) {
-        stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
+        if (m.bits_in) stream_wave_bits<SPW, (NC > 0 ? NC : 1)>(m, senv0, lane, on);
+        else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         return;
     }
     const size_t slab = (size_t)m.rows * m.nR;
@@ -254,7 +255,30 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 
 template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-    return launch_transition_v<D, G, 4>(ctx, a, st);
+    return launch_transition_v<D, G, 4>(ctx, a, st); // 4 stream waves: best of 1/2/4/8 for both forms of the update
+}
+
+static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
+
+static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                             int update_rows, const float *static_, int static_rows, const int64_t *ptr,
+                             const float *mask_in, float *current_out, float *mask_out, float *feature_out,
+                             float *ratio_out, int flags, TransArgs &a)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
+    if (!state || !static_ || !ptr || !mask_in || !current_out || !mask_out || n < 1 || R < 1 || rows < 1 ||
+        static_rows < 1 + d->D || update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
+        return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
+    a.s.d = *d;
+    tap_env_layout(d, state, &a.s.v);
+    a.s.static_ = static_; a.s.static_rows = static_rows; a.s.nR = n * R; a.s.ptr = ptr;
+    a.s.feature_out = feature_out; a.s.flen = tap_env_feature_len(d);
+    a.s.lut = ctx ? ctx->stab_lut : nullptr;
+    a.flags = flags;
+    a.ratio_out = ratio_out;
+    return TAP_OK;
 }
 
 extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
@@ -264,24 +288,40 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
                               float *current_out, float *mask_out, float *feature_out,
                               float *ratio_out, int flags, void *stream)
 {
-    int rc = tap_desc_validate(ctx, d);
+    TransArgs a = {};
+    int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
+                               current_out, mask_out, feature_out, ratio_out, flags, a);
     if (rc) return rc;
-    if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
-    if (!state || !dyn_in || !static_ || !ptr || !mask_in || !colsum_in || !dyn_out || !colsum_out ||
-        !current_out || !mask_out || n < 1 || R < 1 || rows < 1 || static_rows < 1 + d->D ||
-        update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
+    if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "transition is out of place (pack.py:370)");
-    TransArgs a = {};
-    a.s.d = *d;
-    tap_env_layout(d, state, &a.s.v);
-    a.s.static_ = static_; a.s.static_rows = static_rows; a.s.nR = n * R; a.s.ptr = ptr;
-    a.s.feature_out = feature_out; a.s.flen = tap_env_feature_len(d);
-    a.s.lut = ctx ? ctx->stab_lut : nullptr;
     a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
-                   mask_in, colsum_in, colsum_out, current_out, mask_out};
-    a.flags = flags;
-    a.ratio_out = ratio_out;
+                   mask_in, colsum_in, colsum_out, current_out, mask_out, nullptr, nullptr};
+    return transition_dispatch(ctx, d, a, stream);
+}
+
+extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                   int update_rows, const unsigned long long *bits_in, const float *static_,
+                                   int static_rows, const int64_t *ptr, const float *mask_in,
+                                   unsigned long long *bits_out, float *dyn_out, float *current_out,
+                                   float *mask_out, float *feature_out, float *ratio_out, int flags,
+                                   void *stream)
+{
+    TransArgs a = {};
+    int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
+                               current_out, mask_out, feature_out, ratio_out, flags, a);
+    if (rc) return rc;
+    if (!bits_in || !bits_out || bits_in == bits_out)
+        return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
+    a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
+                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};
+    if (!mask_bits_ok(a.m))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+    return transition_dispatch(ctx, d, a, stream);
+}
+
+static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream)
+{
     const int Gs = tap_group_size(d);
     if (d->strategy == TAP_MACS && d->D == 3) {
         switch (Gs) {

@@ -132,11 +132,35 @@ def initial_mask(dynamic, blocks_num):
     return cur, mask
 
 
+def bits_supported(rows, nR):
+    """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_mask_step_bits)."""
+    return rows <= 64 and nR % 4 == 0 and nR <= 256
+
+
+def dynamic_bits(dynamic):
+    """Bit shadow of a 0/1-valued ``dynamic`` (B, rows <= 64, nR): -> (bits (B, nR) int64 with bit r of
+    word j = dynamic[b, r, j] != 0, nonbinary (1,) int32 = number of elements that are neither 0 nor 1;
+    the shadow stands for the tensor only when that count is 0)."""
+    dyn = _f32c(dynamic)
+    B, rows, nR = dyn.shape
+    bits = torch.empty(B, nR, dtype=torch.int64, device=dyn.device)
+    bad = torch.zeros(1, dtype=torch.int32, device=dyn.device)
+    c = _lib.ctx(dyn.device)
+    with torch.cuda.device(dyn.device):
+        _lib.check(_lib.lib().tap_dyn_bits(c, B, nR, rows, _lib.ptr(dyn), _lib.ptr(bits), _lib.ptr(bad),
+                                           _lib.stream_of(dyn.device)), c)
+    return bits, bad
+
+
 class MaskStepper(object):
     """update_dynamic + update_mask fused into one launch per step (model.py:376-386), for callers
-    that drive the episode loop themselves (tap-net_amd.rollout, bench.py)."""
+    that drive the episode loop themselves (tap-net_amd.rollout, bench.py).
 
-    def __init__(self, static, dynamic, input_type='bot', allow_rot=True):
+    ``bits``: carry ``dynamic`` as its bit shadow between steps (the fp32 tensor is then written,
+    never re-read).  None = whenever the shape allows and the tensor is 0/1-valued (one device->host
+    read of a counter at construction), True = required (ValueError otherwise), False = never."""
+
+    def __init__(self, static, dynamic, input_type='bot', allow_rot=True, bits=None):
         self.static = _f32c(static)
         self.dynamic = _f32c(dynamic)
         self.block_dim = _block_dim(static, input_type)
@@ -146,15 +170,32 @@ class MaskStepper(object):
         self.update_rows = _UPDATE_ROWS[input_type]
         self.colsum = dynamic_colsum(self.dynamic, self.n)
         self.current_mask, self.mask = initial_mask(self.dynamic, self.n)
+        self.bits = None
+        if bits is not False and bits_supported(self.rows, self.nR):
+            shadow, bad = dynamic_bits(self.dynamic)
+            if int(bad.item()) == 0:
+                self.bits = shadow
+        if bits is True and self.bits is None:
+            raise ValueError("dynamic cannot be carried as a bit shadow (needs rows <= 64, nR % 4 == 0, "
+                             "nR <= 256 and only 0/1 values)")
 
     def step(self, ptr, dyn_out=None):
         """-> (new_dynamic, current_mask, mask).  ``dyn_out`` lets a caller recycle buffers."""
         ptr = ptr.to(torch.int64).contiguous()
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
-        cs = torch.empty_like(self.colsum)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
         c = _lib.ctx(out.device)
+        if self.bits is not None:
+            nb = torch.empty_like(self.bits)
+            with torch.cuda.device(out.device):
+                _lib.check(_lib.lib().tap_mask_step_bits(
+                    c, self.B, self.n, self.R, self.rows, self.update_rows, _lib.ptr(self.bits),
+                    _lib.ptr(self.static), self.static.shape[1], _lib.ptr(ptr), _lib.ptr(self.mask),
+                    _lib.ptr(nb), _lib.ptr(out), _lib.ptr(cur), _lib.ptr(new), _lib.stream_of(out.device)), c)
+            self.dynamic, self.bits, self.current_mask, self.mask = out, nb, cur, new
+            return out, cur, new
+        cs = torch.empty_like(self.colsum)
         with torch.cuda.device(out.device):
             _lib.check(_lib.lib().tap_mask_step(
                 c, self.B, self.n, self.R, self.rows, self.update_rows, _lib.ptr(self.dynamic),
@@ -170,8 +211,8 @@ class EnvTransition(MaskStepper):
     (tap_transition), optionally starting from a fresh container and optionally emitting
     calc_ratio."""
 
-    def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True):
-        super(EnvTransition, self).__init__(static, dynamic, input_type, allow_rot)
+    def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True, bits=None):
+        super(EnvTransition, self).__init__(static, dynamic, input_type, allow_rot, bits)
         self.env = env
         if env.batch_size != self.B or env.block_dim != self.block_dim:
             raise ValueError("container batch / dimension does not match the instance tensors")
@@ -181,13 +222,23 @@ class EnvTransition(MaskStepper):
         import ctypes as C
         ptr = ptr.to(torch.int64).contiguous()
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
-        cs = torch.empty_like(self.colsum)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
         feat = self.env._new_feature() if want_feature else None
         ratio = torch.empty(self.B, dtype=torch.float32, device=out.device) if want_ratio else None
         flags = (_lib.TAP_T_FRESH if fresh else 0) | (_lib.TAP_T_RATIO if want_ratio else 0)
         c = _lib.ctx(out.device)
+        if self.bits is not None:
+            nb = torch.empty_like(self.bits)
+            with torch.cuda.device(out.device):
+                _lib.check(_lib.lib().tap_transition_bits(
+                    c, C.byref(self.env.desc), _lib.ptr(self.env._state), self.n, self.R, self.rows,
+                    self.update_rows, _lib.ptr(self.bits), _lib.ptr(self.static), self.static.shape[1],
+                    _lib.ptr(ptr), _lib.ptr(self.mask), _lib.ptr(nb), _lib.ptr(out), _lib.ptr(cur),
+                    _lib.ptr(new), _lib.ptr(feat), _lib.ptr(ratio), flags, _lib.stream_of(out.device)), c)
+            self.dynamic, self.bits, self.current_mask, self.mask = out, nb, cur, new
+            return out, cur, new, feat, ratio
+        cs = torch.empty_like(self.colsum)
         with torch.cuda.device(out.device):
             _lib.check(_lib.lib().tap_transition(
                 c, C.byref(self.env.desc), _lib.ptr(self.env._state), self.n, self.R, self.rows,

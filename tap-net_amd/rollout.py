@@ -36,14 +36,15 @@ class RandomFeasiblePolicy(object):
 
 def run_episode(static, dynamic, policy, container_width, container_height,
                 reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
-                input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True):
+                input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True, bits=None):
     """One episode for a batch (model.py:254-515 minus the network).
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
     returns ptr (B,) int64.  With ``fused`` (LB_GREEDY) every step is ONE launch (tap_transition),
     the first one starting from a fresh container and the last one emitting calc_ratio; otherwise
     a step is two launches (tap_mask_step, tap_env_step_gather).  Returns a dict: tour_idx (B, steps), reward = -scores (B,) fp32
-    (model.py:515), env, and with ``record`` the per-step features / masks.
+    (model.py:515), env, and with ``record`` the per-step features / masks.  ``bits``: carry
+    ``dynamic`` as its bit shadow between the steps (pack.MaskStepper), None = when possible.
     """
     if input_type in ('mul', 'mul-with'):
         return _run_episode_mul(static, dynamic, policy, container_width, container_height, reward_type,
@@ -56,9 +57,9 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     if env is None:
         env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
     if fused:
-        masks = EnvTransition(static.to(dev), dynamic.to(dev), env, input_type, allow_rot)
+        masks = EnvTransition(static.to(dev), dynamic.to(dev), env, input_type, allow_rot, bits)
     else:
-        masks = MaskStepper(static.to(dev), dynamic.to(dev), input_type, allow_rot)
+        masks = MaskStepper(static.to(dev), dynamic.to(dev), input_type, allow_rot, bits)
         env.reset()
     static_part = masks.static[:, 1:, :]
     decoder_static = torch.zeros(B, D, 1, device=dev)
