@@ -512,7 +512,7 @@ def main():
                                "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
                        "launch": "hipGraph replay" if use_graph else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(args.config + ":" + dom),
+                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")),
                          "alg_bytes_per_env_step": per_launch[dom] // B,
                          "units_per_launch": B, "avg_launch_us": kt[dom]["avg_us"],
                          "event_pair_overhead_us": empty_us},

@@ -47,11 +47,15 @@ with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.csv" % (tag, cfg)), 
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 short = {"k_mask_step": "mask_step", "k_env_step": "env_step", "k_transition": "transition",
-         "k_rolling_window": "rolling_window", "k_rolling_step": "rolling_step", "k_macs2d_step": "macs_step"}
+         "k_rolling_window": "rolling_window", "k_rolling_step": "rolling_step", "k_macs2d_step": "macs_step", "k_macs3d_step": "macs_step"}
 for k, m in means.items():
     for pat, name in short.items():
         if pat in k:
             traffic["%s:%s" % (cfg, name)] = int((2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024)
+traffic.setdefault("_note", "")
 traffic["_source"] = "profiles/summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes per launch"
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+bj = os.path.join(src, "prof_%s" % tag, "%s_bench.json" % cfg)
+if os.path.exists(bj) and os.path.getsize(bj):
+    shutil.copy(bj, os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, cfg)))
 print(json.dumps(traffic, indent=1))
