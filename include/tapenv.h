@@ -248,8 +248,10 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
 int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
                  unsigned long long *bits_out, int32_t *nonbinary_out, void *stream);
 
-/* tap_mask_step on the shadow.  dyn_out nullable (callers that only need the masks).  Requires
- * nR % 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers, bits_in != bits_out. */
+/* tap_mask_step on the shadow.  Every output is nullable (at least one must be given) and mask_in
+ * NULL means ones, so the same entry serves pack.update_dynamic alone (no mask outputs) and
+ * pack.update_mask alone (update_rows = 0, masks only).  Requires nR % 4 == 0, nR <= 256,
+ * rows <= 64, 16-byte aligned buffers, bits_in != bits_out. */
 int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
                        const unsigned long long *bits_in, const float *static_, int static_rows,
                        const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,

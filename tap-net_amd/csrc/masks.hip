@@ -146,8 +146,8 @@ extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, i
 {
     int rc = check_shape(ctx, B, n, n * R, rows);
     if (rc) return rc;
-    if (!bits_in || !static_ || !ptr || !mask_in || !bits_out || !current_out || !mask_out || static_rows < 1 ||
-        update_rows < 0 || update_rows > 3 || bits_in == bits_out)
+    if (!bits_in || !static_ || !ptr || static_rows < 1 || update_rows < 0 || update_rows > 3 ||
+        bits_in == bits_out || (!bits_out && !dyn_out && !current_out && !mask_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_bits arguments");
     MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};

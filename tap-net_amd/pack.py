@@ -75,6 +75,41 @@ def dynamic_colsum(dynamic, blocks_num):
     return cs
 
 
+# ---- (B, nR) bit shadow of a 0/1-valued dynamic tensor (tapenv.h: tap_dyn_bits) -------------------
+# Preferred over the column sums when the tensor allows it: the step then writes the new fp32 tensor
+# from the bits and never reads the old one.  False is cached for tensors that cannot be carried.
+_bshadow = {}
+
+
+def _bits_put(dynamic, bits):
+    key = id(dynamic)
+    _bshadow[key] = (weakref.ref(dynamic, lambda _r, k=key: _bshadow.pop(k, None)), dynamic._version, bits)
+
+
+def _bits_get(dynamic, build=False):
+    hit = _bshadow.get(id(dynamic))
+    if hit is not None and hit[0]() is dynamic and hit[1] == dynamic._version:
+        return hit[2] if hit[2] is not False else None
+    if not build:
+        return None
+    bits = False
+    if dynamic.dim() == 3 and bits_supported(int(dynamic.shape[1]), int(dynamic.shape[2])):
+        shadow, bad = dynamic_bits(dynamic)
+        if int(bad.item()) == 0:                     # one device->host read per episode
+            bits = shadow
+    _bits_put(dynamic, bits)
+    return bits if bits is not False else None
+
+
+def _mask_step_bits(bits_in, st, ptr, n, R, rows, update_rows, mask_in, bits_out, dyn_out, cur, new):
+    c = _lib.ctx(st.device)
+    with torch.cuda.device(st.device):
+        _lib.check(_lib.lib().tap_mask_step_bits(
+            c, st.shape[0], n, R, rows, update_rows, _lib.ptr(bits_in), _lib.ptr(st), st.shape[1], _lib.ptr(ptr),
+            _lib.ptr(mask_in), _lib.ptr(bits_out), _lib.ptr(dyn_out), _lib.ptr(cur), _lib.ptr(new),
+            _lib.stream_of(st.device)), c)
+
+
 def update_dynamic(dynamic, static, chosen_idx, input_type, allow_rot):
     """pack.update_dynamic (pack.py:333-376): zero the chosen block's rows, out of place."""
     block_dim = _block_dim(static, input_type)
@@ -84,6 +119,12 @@ def update_dynamic(dynamic, static, chosen_idx, input_type, allow_rot):
     n = nR // R                                                                    # pack.py:367
     ptr = chosen_idx.to(torch.int64).contiguous()
     out = torch.empty_like(dyn)
+    bits_in = _bits_get(dynamic, build=True)
+    if bits_in is not None:                          # 0/1 tensor: expand the new one from its bit shadow
+        bits_out = torch.empty_like(bits_in)
+        _mask_step_bits(bits_in, st, ptr, n, R, rows, _UPDATE_ROWS[input_type], None, bits_out, out, None, None)
+        _bits_put(out, bits_out)
+        return out
     # first call of an episode: build the column-sum shadow once (one extra read of the slab) so this
     # and every later step run the single-round-trip streaming kernel and update_mask never re-reads
     cs_in = dynamic_colsum(dynamic, n)
@@ -105,12 +146,16 @@ def update_mask(mask, dynamic, static, chosen_idx, input_type, allow_rot):
     R = _rotate_types(block_dim, allow_rot)
     nR = int(dynamic.shape[-1])
     n = nR // R                                                                    # pack.py:311
-    cs = dynamic_colsum(dynamic, n)
     m = _f32c(mask)
     ptr = chosen_idx.to(torch.int64).contiguous()
     B = m.shape[0]
     cur = torch.empty_like(m)
     new = torch.empty_like(m)
+    bits = _bits_get(dynamic)
+    if bits is not None:                             # column sums = popcounts of the shadow
+        _mask_step_bits(bits, _f32c(static), ptr, n, R, int(dynamic.shape[1]), 0, m, None, None, cur, new)
+        return cur, new
+    cs = dynamic_colsum(dynamic, n)
     c = _lib.ctx(m.device)
     with torch.cuda.device(m.device):
         _lib.check(_lib.lib().tap_update_mask(c, B, n, R, _lib.ptr(m), _lib.ptr(cs), _lib.ptr(ptr),
