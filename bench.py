@@ -194,6 +194,8 @@ class RollingHotPath(HotPath):
         self.feat = torch.empty(self.env._feature_shape(), **f32)
         self.reward = torch.empty(B, **f32)
         self.state = torch.zeros(B, 2, dtype=torch.int64, device=device)
+        self.bits = T.pack.bits_supported(self.rows, self.nR)    # the windows' bit shadow (tap_rolling_window emits it)
+        self.bitb = [torch.empty(B, self.nR, dtype=torch.int64, device=device) for _ in range(3)] if self.bits else [None] * 3
         self.want = rec["reward"].clone()
 
     def episode(self):
@@ -203,29 +205,35 @@ class RollingHotPath(HotPath):
         self._k("reset", L.tap_env_reset, self.ctx, d, P(e._state))
         n1 = self.n - self.nw
         st = [self.static, self.static2]
+        cs2 = None if self.bits else self.csb[2]          # the column sums are only needed without the bit shadow
         self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
-                P(rw.blocks), P(rw.rel), P(self.state), None, P(st[0]), P(self.dyn[2]), P(self.csb[2]),
-                P(self.cur), None, None)
+                P(rw.blocks), P(rw.rel), P(self.state), None, P(st[0]), P(self.dyn[2]), P(cs2),
+                P(self.bitb[2]), P(self.cur), None, None)
         for t in range(n1):
             if self.fused_rolling:                                # placement t + window t+1: one launch
                 self._k("rolling_step", L.tap_rolling_step, self.ctx, d, P(e._state), self.n, self.nw, P(rw.blocks),
                         P(rw.rel), P(self.state), P(self.tape[t]), P(st[t & 1]), P(st[(t + 1) & 1]), P(self.dyn[2]),
-                        P(self.csb[2]), P(self.cur), None, None, P(self.feat))
+                        P(cs2), P(self.bitb[2]), P(self.cur), None, None, P(self.feat))
             else:                                                 # measured 4 % faster at B = 8192 (occupancy)
                 self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st[t & 1]),
                         self.static.shape[1], self.nR, P(self.tape[t]), None, P(self.feat))
                 self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
                         P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
-                        P(self.csb[2]), P(self.cur), None, None)
+                        P(cs2), P(self.bitb[2]), P(self.cur), None, None)
         self.static_last = st[n1 & 1]
-        dyn_in, cs_in, mask_in = self.dyn[2], self.csb[2], self.mask0
+        dyn_in, cs_in, mask_in, bits_in = self.dyn[2], self.csb[2], self.mask0, self.bitb[2]
         for t in range(self.nw):                                  # the last graph: a whole episode
             o = t & 1
             flags = _lib.TAP_T_RATIO if t == self.nw - 1 else 0
-            self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.nw, self.R, self.rows, 3,
-                    P(dyn_in), P(self.static_last), self.static.shape[1], P(self.tape[n1 + t]), P(mask_in), P(cs_in),
-                    P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
-            dyn_in, cs_in, mask_in = self.dyn[o], self.csb[o], self.maskb[o]
+            if self.bits:
+                self._k("transition", L.tap_transition_bits, self.ctx, d, P(e._state), self.nw, self.R, self.rows, 3,
+                        P(bits_in), P(self.static_last), self.static.shape[1], P(self.tape[n1 + t]), P(mask_in),
+                        P(self.bitb[o]), P(self.dyn[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
+            else:
+                self._k("transition", L.tap_transition, self.ctx, d, P(e._state), self.nw, self.R, self.rows, 3,
+                        P(dyn_in), P(self.static_last), self.static.shape[1], P(self.tape[n1 + t]), P(mask_in), P(cs_in),
+                        P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
+            dyn_in, cs_in, mask_in, bits_in = self.dyn[o], self.csb[o], self.maskb[o], self.bitb[o]
 
 
 GATHER_EVERY = 8   # passes whose (B,) reward vectors share one RCCL all-gather (fewer, larger collectives)

@@ -188,11 +188,12 @@ int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container
  * previous window (remove_ptr (B,) int64, NULL on the first call), then convert_to_input():
  * top the window up to `child` nodes and emit static_out (B, 1+D, child*R), dynamic_out
  * (B, 3*child, child*R) f32.  Optional by-products: colsum_out (B, 3, child*R) (the column sums
- * update_mask needs), current_mask_out (B, child*R) (model.py:297-307), nodes_out (B, child) i32
+ * update_mask needs), bits_out (B, child*R) uint64 (the bit shadow of dynamic_out for
+ * tap_transition_bits / tap_mask_step_bits; needs 3*child <= 64, child*R % 4 == 0), current_mask_out (B, child*R) (model.py:297-307), nodes_out (B, child) i32
  * (sorted global block ids = static's columns), err_out (B,) i32 (1 = window could not be filled). */
 int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
                        const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
-                       float *static_out, float *dynamic_out, float *colsum_out,
+                       float *static_out, float *dynamic_out, float *colsum_out, uint64_t *bits_out,
                        float *current_mask_out, int32_t *nodes_out, int32_t *err_out, void *stream);
 
 /* One decoding step of rolling.validate in one launch: add_new_block for the column `ptr` picked
@@ -202,7 +203,7 @@ int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32
 int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
                      const int32_t *blocks, const uint64_t *rel, uint64_t *state, const int64_t *ptr,
                      const float *static_cur, float *static_next, float *dynamic_out,
-                     float *colsum_out, float *current_mask_out, int32_t *nodes_out,
+                     float *colsum_out, uint64_t *bits_out, float *current_mask_out, int32_t *nodes_out,
                      int32_t *err_out, float *feature_out, void *stream);
 
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) --------------------------- */

@@ -61,9 +61,9 @@ _PROTOS = {
     "tap_pack_blocks": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_precedence": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_rolling_init": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
-    "tap_rolling_window": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tap_rolling_window": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_rolling_step": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp, _vp, _vp]),
+                              _vp, _vp, _vp, _vp, _vp]),
     "tap_dyn_colsum": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "tap_update_dynamic": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_update_mask": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -18,6 +18,7 @@
 // Objects/setobject.c for small ints (hash(n) == n): 9 linear probes, perturb shift 5, growth x4
 // once fill*5 >= mask*3.
 #include "tap_common.h"
+#include "tap_masks.h"
 #include "tap_place.h"
 #include "tap_waves.h"
 
@@ -31,6 +32,7 @@ struct RollArgs {
     float *static_out;        // (B, 1+D, child*R)
     float *dynamic_out;       // (B, 3*child, child*R)
     float *colsum_out;        // (B, 3, child*R) nullable
+    unsigned long long *bits_out; // (B, child*R) nullable: bit shadow of dynamic_out (tap_dyn_bits layout)
     float *cur_mask_out;      // (B, child*R) nullable
     int32_t *nodes_out;       // (B, child) nullable
     int32_t *err_out;         // (B,) nullable: 1 = window could not be filled
@@ -133,7 +135,7 @@ __device__ inline int pyset_probe(const int *table, int mask, int key)
 constexpr int PYSET_CAP = 256;
 
 // keys[0..n) in list order -> order[0..n) in set iteration order; tbl/tmp: PYSET_CAP ints each
-__device__ inline void pyset_order(const int *keys, int n, int *order, int *tbl, int *tmp)
+__device__ inline void pyset_order(const unsigned char *keys, int n, unsigned char *order, int *tbl, int *tmp)
 {
     int size = 8, fill = 0;
     for (int i = 0; i < size; ++i) tbl[i] = -1;
@@ -152,16 +154,65 @@ __device__ inline void pyset_order(const int *keys, int n, int *order, int *tbl,
         }
     }
     int m = 0;
-    for (int i = 0; i < size; ++i) if (tbl[i] >= 0) order[m++] = tbl[i];
+    for (int i = 0; i < size; ++i) if (tbl[i] >= 0) order[m++] = (unsigned char)tbl[i];
+}
+
+// The same for tables of at most 64 slots (n <= 18 keys: 8 -> 32 slots), held across the wave: lane l
+// owns slot l, occupancy is one 64-bit mask, a probe is bit arithmetic on it and a re-insert reads the
+// key with a lane broadcast -- no memory, no dependent LDS chain.  Every lane of the wave must call.
+__device__ __forceinline__ int pyset_probe_mask(u64 occ, int mask, int key)
+{
+    unsigned long long perturb = (unsigned long long)key;
+    int i = key & mask;
+    for (;;) {
+        const int probes = (i + 9 <= mask) ? 9 : 0;
+        const u64 span = (2ull << probes) - 1ull, free_ = ~(occ >> i) & span;
+        if (free_) return i + __ffsll((long long)free_) - 1;
+        perturb >>= 5;
+        i = (int)((i * 5ull + 1ull + perturb) & (unsigned long long)mask);
+    }
+}
+
+__device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsigned char *order, int lane)
+{
+    int val = -1, size = 8, fill = 0;
+    u64 occ = 0;
+    for (int k = 0; k < n; ++k) {
+        const int key = keys[k];
+        const int slot = pyset_probe_mask(occ, size - 1, key);
+        if (lane == slot) val = key;
+        occ |= 1ull << slot;
+        ++fill;
+        if (fill * 5 >= (size - 1) * 3) {                  // set_table_resize(used * 4)
+            int newsize = 8;
+            while (newsize <= fill * 4) newsize <<= 1;
+            u64 old = occ;
+            const int oldval = val;
+            val = -1; occ = 0; size = newsize;
+            while (old) {                                  // re-insert in slot order
+                const int s0 = __ffsll((long long)old) - 1;
+                old &= old - 1ull;
+                const int key2 = __shfl(oldval, s0);
+                const int slot2 = pyset_probe_mask(occ, size - 1, key2);
+                if (lane == slot2) val = key2;
+                occ |= 1ull << slot2;
+            }
+        }
+    }
+    if ((occ >> lane) & 1ull) order[__popcll(occ & ((1ull << lane) - 1ull))] = (unsigned char)val;
 }
 
 // ---- one window step: remove, top up, cut sub-graphs, emit tensors ----------------------------------
-struct RollLds {          // one wavefront's scratch
-    int lst[64];          // sub_graph_nodes in list order
-    int ord[64];          // sub-graph node order (matrix index -> node)
-    int pos[64];          // node -> matrix index
-    int srt[64];          // sorted position -> node
-    int tbl[2 * PYSET_CAP];
+struct RollLds {          // one wavefront's scratch: 4.8 KB, so that 8 workgroups (all 32 waves a CU
+                          // gets at B = 8192) fit the 160 KB of LDS
+    unsigned char lst[64]; // sub_graph_nodes in list order
+    unsigned char ord[64]; // sub-graph node order (matrix index -> node)
+    unsigned char pos[64]; // node -> matrix index
+    unsigned char srt[64]; // sorted position -> node
+    union {
+        int tbl[2 * PYSET_CAP]; // set-order emulation (step 3)
+        u64 cw[PYSET_CAP];      // later: dynamic's column words, bit (sec*child + rm) of cw[col]
+    };
     u64 side[5][64];      // column masks by sub-graph index
 };
 
@@ -177,9 +228,12 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     const u64 bit = 1ull << v, below = bit - 1ull;
     const bool isnode = v < N;
     u64 rel[5] = {0, 0, 0, 0, 0};
+    int bdim[3] = {0, 0, 0};                         // this node's block (rotation 0)
     if (isnode) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) rel[k] = a.rel[((size_t)inst * 5 + k) * N + v];
+#pragma unroll
+        for (int k = 0; k < D; ++k) bdim[k] = a.blocks[((size_t)inst * N + v) * D + k];
     }
     u64 entered = a.state[(size_t)inst * 2], window = a.state[(size_t)inst * 2 + 1];
 
@@ -193,7 +247,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     // (2) top the window up: in-degree-0 nodes of gm_copy, layer by layer, ascending ids
     //     (generate.py:1724-1750); list order = old window (sorted by the previous call) + appended
     int count = __popcll(window);
-    if (window & bit) S.lst[__popcll(window & below)] = v;
+    if (window & bit) S.lst[__popcll(window & below)] = (unsigned char)v;
     u64 added = 0;
     while (count < child) {
         const u64 gmc = all & ~(entered | added);                    // nodes still in gm_copy
@@ -202,7 +256,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (fm == 0) break;
         const int need = child - count;
         const bool take = free_ && __popcll(fm & below) < need;
-        if (take) S.lst[count + __popcll(fm & below)] = v;
+        if (take) S.lst[count + __popcll(fm & below)] = (unsigned char)v;
         const u64 tm = __ballot(take);
         added |= tm;
         count += __popcll(tm);
@@ -214,12 +268,13 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
 
     // (3) node order of the induced sub-graphs (:1684-1688, 1758-1761)
     if (2 * child < N) {
-        if (v == 0 && !short_window) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
+        if (child <= 18) { if (!short_window) pyset_order_wave(S.lst, child, S.ord, v); } // wave-uniform branch
+        else if (v == 0 && !short_window) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
     } else if (window & bit) {
-        S.ord[__popcll(window & below)] = v;
+        S.ord[__popcll(window & below)] = (unsigned char)v;
     }
     tap_wave_lds_sync();
-    if (v < child && !short_window) S.pos[S.ord[v]] = v;
+    if (v < child && !short_window) S.pos[S.ord[v]] = (unsigned char)v;
     tap_wave_lds_sync();
 
     if (v == 0) {
@@ -239,7 +294,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         S.side[0][midx] = rel[0] & window;
 #pragma unroll
         for (int k = 1; k < 5; ++k) S.side[k][midx] = (rel[k] & window) | ((rel[k] & after) ? bit : 0ull);
-        S.srt[__popcll(window & below)] = v;     // sorted position -> node (static's column order)
+        S.srt[__popcll(window & below)] = (unsigned char)v;     // sorted position -> node (static's column order)
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + __popcll(window & below)] = v;
     }
     tap_wave_lds_sync();
@@ -255,14 +310,27 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (D == 3 && p[D - 1] == 1) return 2 + sec; // forward / backward
         return -1;                                   // up / down: empty
     };
-    // lane = column (r, cm); rows are walked in order, so each store instruction writes one row
-    // segment of up to 64 consecutive floats and nothing is divided per element
-    for (int col = v; col < nRc; col += 64) {
-        const int r = col / child, cm = col - r * child;
+    // lane = column (r, cm): static, column sums, initial mask, and the column's word of `dynamic`
+    // (rows re-indexed from node ids to sub-graph order).  When the tensor fits the bit-shadow form
+    // (3*child <= 64 rows, nRc % 4 == 0, nRc <= 256) the words go through LDS and the fp32 tensor is
+    // expanded from them as in stream_wave_bits (tap_masks.h): a store instruction covers 64/(nRc/4)
+    // whole rows with 16 bytes per lane, nontemporal.  Otherwise each lane walks its column.
+    const int rows = 3 * child;
+    const bool packed = rows <= 64 && (nRc & 3) == 0 && nRc <= 256;
+    for (int col0 = 0; col0 < nRc; col0 += 64) {
+        const int col = col0 + v;
+        const bool oncol = col < nRc;
+        const int r = oncol ? col / child : 0, cm = oncol ? col - r * child : 0;
         const int *p = D == 2 ? perm2[r] : perm3[r];
-        const int32_t *blk = a.blocks + ((size_t)inst * N + S.srt[cm]) * D;  // static: cm = sorted slot
+        // static: cm = sorted slot; the node's sides come from its own lane (loaded with `rel`)
+        const int node_s = S.srt[cm];
+        int side_len[3];
+#pragma unroll
+        for (int k = 0; k < D; ++k) side_len[k] = __shfl(bdim[k], node_s);
+        if (!oncol) continue;
         st[col] = (float)cm;                                                      // :1795-1801
-        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)blk[p[k]];
+        for (int k = 0; k < D; ++k)
+            st[(size_t)(1 + k) * nRc + col] = (float)(p[k] == 0 ? side_len[0] : p[k] == 1 ? side_len[1] : side_len[2]);
         u64 m[3];
         float sum[3];
 #pragma unroll
@@ -274,12 +342,33 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         }
         if (a.cur_mask_out)                                                       // model.py:297-307
             a.cur_mask_out[(size_t)inst * nRc + col] = (sum[1] * sum[2] + sum[0] != 0.f) ? 0.f : 1.f;
-        for (int rm = 0; rm < child; ++rm) {
-            const int node = S.ord[rm];
+        if (packed) {
+            u64 w = 0;
+            for (int rm = 0; rm < child; ++rm) {
+                const int node = S.ord[rm];
 #pragma unroll
-            for (int sec = 0; sec < 3; ++sec)
-                dy[(size_t)(sec * child + rm) * nRc + col] = (float)((m[sec] >> node) & 1ull);
+                for (int sec = 0; sec < 3; ++sec) w |= ((m[sec] >> node) & 1ull) << (sec * child + rm);
+            }
+            S.cw[col] = w;
+            if (a.bits_out) a.bits_out[(size_t)inst * nRc + col] = w;
+        } else {
+            for (int rm = 0; rm < child; ++rm) {
+                const int node = S.ord[rm];
+#pragma unroll
+                for (int sec = 0; sec < 3; ++sec)
+                    dy[(size_t)(sec * child + rm) * nRc + col] = (float)((m[sec] >> node) & 1ull);
+            }
         }
+    }
+    if (!packed) return;
+    tap_wave_lds_sync();
+    const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
+    if (rsub < RP) {
+        const u64 w0 = S.cw[c4 * 4], w1 = S.cw[c4 * 4 + 1], w2 = S.cw[c4 * 4 + 2], w3 = S.cw[c4 * 4 + 3];
+        float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
+        for (int r = rsub; r < rows; r += RP)
+            store_stream(&dst[(size_t)r * C4], make_float4((float)((w0 >> r) & 1ull), (float)((w1 >> r) & 1ull),
+                                                           (float)((w2 >> r) & 1ull), (float)((w3 >> r) & 1ull)));
     }
 }
 
@@ -355,8 +444,8 @@ extern "C" int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t
 extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
                                   const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
                                   float *static_out, float *dynamic_out, float *colsum_out,
-                                  float *current_mask_out, int32_t *nodes_out, int32_t *err_out,
-                                  void *stream)
+                                  uint64_t *bits_out, float *current_mask_out, int32_t *nodes_out,
+                                  int32_t *err_out, void *stream)
 {
     int rc = roll_check(ctx, B, D, N, child);
     if (rc) return rc;
@@ -367,6 +456,9 @@ extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, 
     a.state = reinterpret_cast<unsigned long long *>(state);
     a.remove_ptr = remove_ptr; a.static_out = static_out; a.dynamic_out = dynamic_out;
     a.colsum_out = colsum_out; a.cur_mask_out = current_mask_out; a.nodes_out = nodes_out; a.err_out = err_out;
+    a.bits_out = reinterpret_cast<unsigned long long *>(bits_out);
+    if (bits_out && (3 * child > 64 || (child * (D == 2 ? 2 : 6)) % 4 != 0 || child * (D == 2 ? 2 : 6) > 256))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bits_out needs 3*child <= 64, (child*R) %% 4 == 0, child*R <= 256");
     const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
     if (grid == 0) return TAP_OK;
     if (D == 2) hipLaunchKernelGGL(k_rolling_window<2>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
@@ -388,8 +480,9 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
 extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
                                 const int32_t *blocks, const uint64_t *rel, uint64_t *state,
                                 const int64_t *ptr, const float *static_cur, float *static_next,
-                                float *dynamic_out, float *colsum_out, float *current_mask_out,
-                                int32_t *nodes_out, int32_t *err_out, float *feature_out, void *stream)
+                                float *dynamic_out, float *colsum_out, uint64_t *bits_out,
+                                float *current_mask_out, int32_t *nodes_out, int32_t *err_out,
+                                float *feature_out, void *stream)
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
@@ -406,6 +499,9 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     a.r.state = reinterpret_cast<unsigned long long *>(state);
     a.r.remove_ptr = ptr; a.r.static_out = static_next; a.r.dynamic_out = dynamic_out;
     a.r.colsum_out = colsum_out; a.r.cur_mask_out = current_mask_out; a.r.nodes_out = nodes_out; a.r.err_out = err_out;
+    a.r.bits_out = reinterpret_cast<unsigned long long *>(bits_out);
+    if (bits_out && (3 * child > 64 || (child * R) % 4 != 0 || child * R > 256))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bits_out needs 3*child <= 64, (child*R) %% 4 == 0, child*R <= 256");
     a.s.d = *d;
     tap_env_layout(d, env_state, &a.s.v);
     a.s.static_ = static_cur; a.s.static_rows = 1 + d->D; a.s.nR = child * R; a.s.ptr = ptr;

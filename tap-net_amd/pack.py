@@ -203,7 +203,8 @@ class MaskStepper(object):
 
     ``bits``: carry ``dynamic`` as its bit shadow between steps (the fp32 tensor is then written,
     never re-read).  None = whenever the shape allows and the tensor is 0/1-valued (one device->host
-    read of a counter at construction), True = required (ValueError otherwise), False = never."""
+    read of a counter at construction), True = required (ValueError otherwise), False = never, a
+    tensor = the shadow itself (dynamic_bits layout) when the caller already has it."""
 
     def __init__(self, static, dynamic, input_type='bot', allow_rot=True, bits=None):
         self.static = _f32c(static)
@@ -216,7 +217,9 @@ class MaskStepper(object):
         self.colsum = dynamic_colsum(self.dynamic, self.n)
         self.current_mask, self.mask = initial_mask(self.dynamic, self.n)
         self.bits = None
-        if bits is not False and bits_supported(self.rows, self.nR):
+        if isinstance(bits, torch.Tensor):               # a shadow the caller already holds (rolling windows)
+            self.bits = bits
+        elif bits is not False and bits_supported(self.rows, self.nR):
             shadow, bad = dynamic_bits(self.dynamic)
             if int(bad.item()) == 0:
                 self.bits = shadow

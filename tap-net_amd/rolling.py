@@ -45,7 +45,8 @@ class RollingWindows(object):
 
     def next(self, remove_ptr=None, want_masks=True):
         """convert_to_input() after remove_block(sub_graph_nodes[ptr % child]).
-        -> dict(static, dynamic, nodes, colsum, current_mask)."""
+        -> dict(static, dynamic, nodes, colsum, bits, current_mask): ``bits`` is the window tensor's bit
+        shadow (pack.dynamic_bits layout) when its shape has one, else ``colsum`` holds the column sums."""
         if (remove_ptr is None) != (self.steps_done == 0):
             raise ValueError("pass the previous window's pick to every call but the first")
         f32 = dict(dtype=torch.float32, device=self.device)
@@ -53,7 +54,8 @@ class RollingWindows(object):
         static = torch.empty(self.B, 1 + self.D, nRc, **f32)
         dynamic = torch.empty(self.B, 3 * self.child, nRc, **f32)
         nodes = torch.empty(self.B, self.child, dtype=torch.int32, device=self.device)
-        colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks else None
+        bits = self._new_bits(nRc) if want_masks else None
+        colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks and bits is None else None
         cur = torch.empty(self.B, nRc, **f32) if want_masks else None
         err = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         ptr = None if remove_ptr is None else remove_ptr.to(device=self.device, dtype=torch.int64).contiguous()
@@ -61,10 +63,17 @@ class RollingWindows(object):
             _lib.check(_lib.lib().tap_rolling_window(
                 self._ctx, self.B, self.D, self.N, self.child, _lib.ptr(self.blocks), _lib.ptr(self.rel),
                 _lib.ptr(self.state), _lib.ptr(ptr), _lib.ptr(static), _lib.ptr(dynamic), _lib.ptr(colsum),
-                _lib.ptr(cur), _lib.ptr(nodes), _lib.ptr(err), _lib.stream_of(self.device)), self._ctx)
+                _lib.ptr(bits), _lib.ptr(cur), _lib.ptr(nodes), _lib.ptr(err), _lib.stream_of(self.device)), self._ctx)
         self.steps_done += 1
         self._err = err
-        return dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, current_mask=cur)
+        return dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, bits=bits, current_mask=cur)
+
+    def _new_bits(self, nRc):
+        """Buffer for the window tensor's bit shadow (pack.dynamic_bits layout), None if the shape has none."""
+        from .pack import bits_supported
+        if not bits_supported(3 * self.child, nRc):
+            return None
+        return torch.empty(self.B, nRc, dtype=torch.int64, device=self.device)
 
     def step(self, ptr, env, static_cur, want_masks=True, want_feature=True):
         """One decoding step in ONE launch (tap_rolling_step): place the block picked in the current
@@ -75,7 +84,8 @@ class RollingWindows(object):
         static = torch.empty(self.B, 1 + self.D, nRc, **f32)
         dynamic = torch.empty(self.B, 3 * self.child, nRc, **f32)
         nodes = torch.empty(self.B, self.child, dtype=torch.int32, device=self.device)
-        colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks else None
+        bits = self._new_bits(nRc) if want_masks else None
+        colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks and bits is None else None
         cur = torch.empty(self.B, nRc, **f32) if want_masks else None
         err = torch.zeros(self.B, dtype=torch.int32, device=self.device)
         feat = env._new_feature() if want_feature else None
@@ -85,11 +95,11 @@ class RollingWindows(object):
             _lib.check(_lib.lib().tap_rolling_step(
                 self._ctx, C.byref(env.desc), _lib.ptr(env._state), self.N, self.child, _lib.ptr(self.blocks),
                 _lib.ptr(self.rel), _lib.ptr(self.state), _lib.ptr(ptr), _lib.ptr(static_cur), _lib.ptr(static),
-                _lib.ptr(dynamic), _lib.ptr(colsum), _lib.ptr(cur), _lib.ptr(nodes), _lib.ptr(err), _lib.ptr(feat),
-                _lib.stream_of(self.device)), self._ctx)
+                _lib.ptr(dynamic), _lib.ptr(colsum), _lib.ptr(bits), _lib.ptr(cur), _lib.ptr(nodes), _lib.ptr(err),
+                _lib.ptr(feat), _lib.stream_of(self.device)), self._ctx)
         self.steps_done += 1
         self._err = err
-        return feat, dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, current_mask=cur)
+        return feat, dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, bits=bits, current_mask=cur)
 
     def check(self):
         if int(self._err.sum().item()):
@@ -134,8 +144,9 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
             feats.append(decoder_dynamic)
         step += 1
     assert rw.is_last_graph()                                    # `win` is the last graph: a whole episode on it
-    tpack._shadow_put(win['dynamic'], win['colsum'])
-    trans = EnvTransition(win['static'], win['dynamic'], env)
+    if win['colsum'] is not None:
+        tpack._shadow_put(win['dynamic'], win['colsum'])
+    trans = EnvTransition(win['static'], win['dynamic'], env, bits=win['bits'] if win['bits'] is not None else False)
     for t in range(child):
         ptr = policy(step=step, static=trans.static, dynamic=trans.dynamic, current_mask=trans.current_mask,
                      mask=trans.mask, decoder_static=decoder_static, decoder_dynamic=decoder_dynamic).to(torch.int64)
