@@ -164,8 +164,10 @@ class RollingHotPath(HotPath):
     7x7x250 as scripts/rolling.sh); actions replayed from a tape recorded with a random feasible
     policy."""
 
-    def __init__(self, cfg, B, start, device, seed=12345, window=10, fused_rolling=False):
+    def __init__(self, cfg, B, start, device, seed=12345, window=10, fused_rolling=False, overlap=False):
         _, D, cs, n, _, reward, strategy = cfg
+        self.overlap = overlap
+        self.side = torch.cuda.Stream(device=device)
         self.D, self.cs, self.n, self.B, self.device, self.nw = D, cs, n, B, device, window
         self.fused, self.hook, self.rolling, self.fused_rolling = True, None, True, fused_rolling
         self.lib, self.ctx = _lib.lib(), _lib.ctx(device)
@@ -209,17 +211,38 @@ class RollingHotPath(HotPath):
         self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
                 P(rw.blocks), P(rw.rel), P(self.state), None, P(st[0]), P(self.dyn[2]), P(cs2),
                 P(self.bitb[2]), P(self.cur), None, None)
+        prev_ev = None
         for t in range(n1):
             if self.fused_rolling:                                # placement t + window t+1: one launch
                 self._k("rolling_step", L.tap_rolling_step, self.ctx, d, P(e._state), self.n, self.nw, P(rw.blocks),
                         P(rw.rel), P(self.state), P(self.tape[t]), P(st[t & 1]), P(st[(t + 1) & 1]), P(self.dyn[2]),
                         P(cs2), P(self.bitb[2]), P(self.cur), None, None, P(self.feat))
-            else:                                                 # measured 4 % faster at B = 8192 (occupancy)
+            elif not self.overlap:
                 self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st[t & 1]),
                         self.static.shape[1], self.nR, P(self.tape[t]), None, P(self.feat))
                 self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
                         P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
                         P(cs2), P(self.bitb[2]), P(self.cur), None, None)
+            else:
+                # placement t (reads window t's static, owns the container state) and window t+1 (owns
+                # the window state, writes the OTHER static buffer) both depend only on the pick of step
+                # t: two HIP streams, so the latency-bound placement runs under the write-bound window
+                # kernel.  window t+1 overwrites the static buffer placement t-1 read: wait for that one.
+                main = torch.cuda.current_stream(self.device)
+                self.side.wait_stream(main)
+                with torch.cuda.stream(self.side):
+                    self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st[t & 1]),
+                            self.static.shape[1], self.nR, P(self.tape[t]), None, P(self.feat))
+                    ev = torch.cuda.Event()
+                    ev.record(self.side)
+                if prev_ev is not None:
+                    main.wait_event(prev_ev)
+                prev_ev = ev
+                self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
+                        P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
+                        P(cs2), P(self.bitb[2]), P(self.cur), None, None)
+        if self.overlap and not self.fused_rolling:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
         self.static_last = st[n1 & 1]
         dyn_in, cs_in, mask_in, bits_in = self.dyn[2], self.csb[2], self.mask0, self.bitb[2]
         for t in range(self.nw):                                  # the last graph: a whole episode
@@ -457,6 +480,10 @@ def main():
                     help="precedence update as an fp32 copy (tap_transition) instead of on the bit shadow (tap_transition_bits)")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
     ap.add_argument("--fused-rolling", action="store_true", help="c5: tap_rolling_step instead of env_step + rolling_window")
+    ap.add_argument("--overlap", action="store_true",
+                    help="c5: placement t and window t+1 on two HIP streams (measured slower on this stack: "
+                         "285 vs 297 M env-steps/s in a graph, 251 vs 299 eager -- the cross-stream waits cost more "
+                         "than the 8.6 us placement they hide)")
     ap.add_argument("--approx-windows", action="store_true",
                     help="c5: consecutive independent 10-node windows instead of true rolling windows")
     args = ap.parse_args()
@@ -476,7 +503,8 @@ def main():
         cfg = (name, D, cs, n, B, reward, strategy)
     rolling = args.config in ROLLING and not args.approx_windows
     if rolling:
-        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=args.fused_rolling)
+        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=args.fused_rolling,
+                            overlap=args.overlap)
     else:
         hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits)
     use_graph = not args.no_graph
