@@ -343,12 +343,15 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (a.cur_mask_out)                                                       // model.py:297-307
             a.cur_mask_out[(size_t)inst * nRc + col] = (sum[1] * sum[2] + sum[0] != 0.f) ? 0.f : 1.f;
         if (packed) {
-            u64 w = 0;
+            unsigned ws[3] = {0u, 0u, 0u};               // child <= 21 bits per section: 32-bit arithmetic
             for (int rm = 0; rm < child; ++rm) {
-                const int node = S.ord[rm];
+                const int node = S.ord[rm], sh = node & 31;
+                const bool hi = node >= 32;
 #pragma unroll
-                for (int sec = 0; sec < 3; ++sec) w |= ((m[sec] >> node) & 1ull) << (sec * child + rm);
+                for (int sec = 0; sec < 3; ++sec)
+                    ws[sec] |= (((hi ? (unsigned)(m[sec] >> 32) : (unsigned)m[sec]) >> sh) & 1u) << rm;
             }
+            const u64 w = (u64)ws[0] | ((u64)ws[1] << child) | ((u64)ws[2] << (2 * child));
             S.cw[col] = w;
             if (a.bits_out) a.bits_out[(size_t)inst * nRc + col] = w;
         } else {
@@ -373,8 +376,10 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
 }
 
 
+// 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
+// were resident, so one workgroup in eight ran as a second round
 template <int D>
-__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window(RollArgs a)
+__global__ void __launch_bounds__(TAP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rolling_window(RollArgs a)
 {
     __shared__ RollLds S[TAP_BLOCK / 64];
     const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
