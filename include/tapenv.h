@@ -160,9 +160,13 @@ int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const 
  * int32 in placement order, one launch.  This is what generate.generate_blocks calls with
  * 'C+P+S-lb-hard' on the initial container (generate.py:908); an instance is accepted when every
  * stable_out flag is 1 (generate.py:909-910).  reward_out (B,) f32 = -(C+P+S), positions_out
- * (B, n, D) i32, stable_out (B, n) u8 -- each nullable. */
+ * (B, n, D) i32, stable_out (B, n) u8, score64_out (B,) f64 = C+P+S -- each nullable.
+ * A block with a side < 1 is not part of its list (lists of different length in one batch: the
+ * two-container reward of pack.py:451-466 packs the blocks of each target id separately); S is
+ * taken over the blocks that are, and an empty list scores 0 (pack.py:459-460). */
 int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const int32_t *blocks,
-                    float *reward_out, int32_t *positions_out, uint8_t *stable_out, void *stream);
+                    float *reward_out, int32_t *positions_out, uint8_t *stable_out,
+                    double *score64_out, void *stream);
 
 /* generate.calc_dependent (generate.py:575-771) + the rotation bookkeeping of
  * generate.generate_blocks (generate.py:935-971) + pack.PACKDataset's layout (pack.py:101-195,

@@ -58,7 +58,7 @@ _PROTOS = {
     "tap_env_export": (_i, [_vp, C.POINTER(EnvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_env_check": (_i, [_vp, C.POINTER(EnvDesc), _vp, C.POINTER(C.c_int32), _vp]),
     "tap_episode_reward": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "tap_pack_blocks": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tap_pack_blocks": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_precedence": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_rolling_init": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_rolling_window": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

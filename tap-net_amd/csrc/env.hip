@@ -401,6 +401,7 @@ struct EpisodeArgs {
     float *reward_out;
     int32_t *pos_out;
     uint8_t *stable_out;
+    double *score64_out; // C+P+S as fp64, 0 for an empty list (pack.py:462-470 averages two of them)
 };
 
 template <int D, int G>
@@ -445,9 +446,13 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
         const long long box = (long long)gmax * W * L;
         const double C = (double)cnt.valid / (double)box;
         const double P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
-        const double S = (double)cnt.nstable / (double)n;
+        // S over blocks_num = len(blocks) (tools.py:2440): entries with a side < 1 are not part of the
+        // list (pack.py:455-457 filters by target id; the host marks the other container's blocks so)
+        const double S = (double)cnt.nstable / (double)cnt.count;
+        const double score = cnt.count ? (C + P) + S : 0.0;                          // pack.py:459-466
         // the reference raises on a height overflow; here the reward becomes NaN
-        if (a.reward_out) a.reward_out[env] = err ? __int_as_float(0x7fc00000) : -(float)((C + P) + S);
+        if (a.reward_out) a.reward_out[env] = err ? __int_as_float(0x7fc00000) : -(float)score;
+        if (a.score64_out) a.score64_out[env] = err ? __longlong_as_double(0x7ff8000000000000ll) : score;
     }
 }
 
@@ -471,18 +476,18 @@ extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, in
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
     if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
         return tap_fail(ctx, TAP_E_INVALID, "bad episode arguments");
-    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out};
+    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, nullptr};
     TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
 }
 
 extern "C" int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const int32_t *blocks,
                                float *reward_out, int32_t *positions_out, uint8_t *stable_out,
-                               void *stream)
+                               double *score64_out, void *stream)
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY only");
     if (!blocks || B < 0 || n < 1) return tap_fail(ctx, TAP_E_INVALID, "bad pack_blocks arguments");
-    EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out};
+    EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, score64_out};
     TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
 }

@@ -55,7 +55,7 @@ def pack_blocks(blocks, container_size, reward_type='C+P+S-lb-hard'):
     c = _lib.ctx(dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().tap_pack_blocks(c, C.byref(desc), B, n, _lib.ptr(blocks), _lib.ptr(rew),
-                                              _lib.ptr(pos), _lib.ptr(st), _lib.stream_of(dev)), c)
+                                              _lib.ptr(pos), _lib.ptr(st), None, _lib.stream_of(dev)), c)
     return pos, st.bool(), rew
 
 

@@ -298,15 +298,46 @@ class EnvTransition(MaskStepper):
         return out, cur, new, feat, ratio
 
 
+def _reward_mul(static, tour_indices, reward_type, input_type, allow_rot, container_width, container_height):
+    """The two-container branch of pack.reward (pack.py:451-466): the last row of ``static`` is each
+    block's target id; the blocks of id 0 and of id 1 are packed separately, in tour order, each into
+    its own empty container, and the score is the mean of the two (0 for an empty list)."""
+    import ctypes as C
+    block_dim = _block_dim(static, input_type)
+    R = _rotate_types(block_dim, allow_rot)
+    st = _f32c(static)
+    B, rows, nR = st.shape
+    n = nR // R
+    tour = tour_indices.to(torch.int64)
+    idx = tour.unsqueeze(1).repeat(1, rows, R)                                      # pack.py:438
+    sample = torch.gather(st, 2, idx)[:, :, :n]                                     # pack.py:441
+    blocks = sample[:, 1:1 + block_dim, :].transpose(1, 2).to(torch.int32)         # pack.py:449-450, astype(int)
+    ids = sample[:, -1, :]
+    cs = [container_width, container_height] if block_dim == 2 else \
+        [container_width, container_width, container_height]
+    desc = _lib.make_desc(B, cs, n, reward_type, 'full', 'LB_GREEDY')
+    c = _lib.ctx(st.device)
+    scores = []
+    for target in (0, 1):
+        # a zero side marks "not in this list" for tap_pack_blocks
+        mine = (blocks * (ids == target).unsqueeze(2).to(torch.int32)).contiguous()
+        s64 = torch.empty(B, dtype=torch.float64, device=st.device)
+        with torch.cuda.device(st.device):
+            _lib.check(_lib.lib().tap_pack_blocks(c, C.byref(desc), B, n, _lib.ptr(mine), None, None, None,
+                                                  _lib.ptr(s64), _lib.stream_of(st.device)), c)
+        scores.append(s64)
+    return -((scores[0] + scores[1]) / 2).to(torch.float32)                          # pack.py:466, 473
+
+
 def reward(static, tour_indices, reward_type, input_type, allow_rot, container_width, container_height,
            packing_strategy='LB_GREEDY'):
     """pack.reward (pack.py:378-473): pack every env's blocks in tour order from an empty
     container and return ``-scores`` (un-normalised C+P+S, tools.py:2442-2449), one launch."""
-    if input_type in ('mul', 'mul-with'):
-        raise NotImplementedError("reward() for the two-container input types is not implemented")
     if packing_strategy in ('MACS', 'MUL'):
         # pack.py:431 names tools.calc_positions_mus, which does not exist in the reference
         raise AttributeError("module 'tools' has no attribute 'calc_positions_mus'")
+    if input_type in ('mul', 'mul-with'):
+        return _reward_mul(static, tour_indices, reward_type, input_type, allow_rot, container_width, container_height)
     block_dim = _block_dim(static, input_type)
     R = _rotate_types(block_dim, allow_rot)
     st = _f32c(static)

@@ -221,6 +221,32 @@ def calc_positions_lb_greedy(blocks, container_size, reward_type):
     return rc, pos, st.astype(bool), ratio.value, scores
 
 
+def reward_mul(static, tour, reward_type, container_width, container_height, R):
+    """pack.reward for input types 'mul' / 'mul-with' (pack.py:451-466) on top of the oracle's
+    calc_positions_lb_greedy: static (B, 1+D+1, n*R) with the target id in the last row."""
+    static = np.asarray(static, dtype=np.float32)
+    tour = np.asarray(tour, dtype=np.int64)
+    B, rows, nR = static.shape
+    n, D = nR // R, rows - 2
+    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    out = np.zeros(B, np.float32)
+    for b in range(B):
+        sample = static[b][:, tour[b][:n]]                       # gather by tour, first n steps
+        blocks = sample[1:1 + D].T.astype(np.int32)
+        ids = sample[-1]
+        sc = []
+        for target in (0, 1):
+            mine = blocks[ids == target]
+            if len(mine) == 0:
+                sc.append(0.0)
+                continue
+            rc, _, _, ratio, _ = calc_positions_lb_greedy(mine, cs, reward_type)
+            assert rc == 0
+            sc.append(ratio)
+        out[b] = np.float32((sc[0] + sc[1]) / 2)
+    return -out
+
+
 def reward(static, tour, reward_type, container_width, container_height, nthreads=1):
     static = np.ascontiguousarray(static, dtype=np.float32)
     tour = np.ascontiguousarray(tour, dtype=np.int64)

@@ -82,3 +82,24 @@ def test_masks(ref):
     od = O.update_dynamic(dyn, static, ptr, n, 3)
     oc, om = O.update_mask(mask, od, ptr, n, R)
     assert np.array_equal(rd.numpy(), od) and np.array_equal(rc.numpy(), oc) and np.array_equal(rm.numpy(), om)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_reward_mul(ref, D):
+    """pack.reward for the two-container input type: blocks split by target id, packed separately."""
+    import torch
+    pack = ref[1]
+    rng = np.random.RandomState(17 + D)
+    B, n = 24, 8
+    R = 2 if D == 2 else 6
+    blocks = rng.randint(1, 5, size=(B, D, n)).astype(np.float32)
+    static = np.zeros((B, 1 + D + 1, n * R), np.float32)
+    for r in range(R):
+        static[:, 0, r * n:(r + 1) * n] = np.arange(n)
+        static[:, 1:1 + D, r * n:(r + 1) * n] = blocks          # same sides in every rotation slot: enough here
+        static[:, -1, r * n:(r + 1) * n] = rng.randint(0, 2, size=(B, n))
+    static[0, -1, :] = 0                                         # one env with an empty second container
+    tour = np.stack([rng.permutation(n * R)[:n] for _ in range(B)]).astype(np.int64)
+    want = pack.reward(torch.from_numpy(static), torch.from_numpy(tour), "C+P+S-lb-soft", "mul", True, 5, 60).numpy()
+    got = O.reward_mul(static, tour, "C+P+S-lb-soft", 5, 60, R)
+    assert np.array_equal(got, want)
