@@ -178,7 +178,8 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
     int val = -1, size = 8, fill = 0;
     u64 occ = 0;
     for (int k = 0; k < n; ++k) {
-        const int key = keys[k];
+        // the table state is wave-uniform: say so, and the probe arithmetic runs on the scalar unit
+        const int key = __builtin_amdgcn_readfirstlane((int)keys[k]);
         const int slot = pyset_probe_mask(occ, size - 1, key);
         if (lane == slot) val = key;
         occ |= 1ull << slot;
@@ -192,7 +193,7 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
             while (old) {                                  // re-insert in slot order
                 const int s0 = __ffsll((long long)old) - 1;
                 old &= old - 1ull;
-                const int key2 = __shfl(oldval, s0);
+                const int key2 = __builtin_amdgcn_readlane(oldval, s0);
                 const int slot2 = pyset_probe_mask(occ, size - 1, key2);
                 if (lane == slot2) val = key2;
                 occ |= 1ull << slot2;
@@ -235,11 +236,16 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
 #pragma unroll
         for (int k = 0; k < D; ++k) bdim[k] = a.blocks[((size_t)inst * N + v) * D + k];
     }
-    u64 entered = a.state[(size_t)inst * 2], window = a.state[(size_t)inst * 2 + 1];
+    // (entered, window) are wave-uniform: in scalar registers the set arithmetic below costs no VALU slots
+    auto uniform64 = [](u64 x) -> u64 {
+        return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+    };
+    u64 entered = uniform64(a.state[(size_t)inst * 2]), window = uniform64(a.state[(size_t)inst * 2 + 1]);
 
     // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
     if (a.remove_ptr) {
-        long slot = (long)a.remove_ptr[inst];
+        long slot = (long)uniform64((u64)a.remove_ptr[inst]);
         while (slot >= child) slot -= child;
         const bool hit = (window & bit) && __popcll(window & below) == slot;
         window &= ~__ballot(hit);
@@ -345,7 +351,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (packed) {
             unsigned ws[3] = {0u, 0u, 0u};               // child <= 21 bits per section: 32-bit arithmetic
             for (int rm = 0; rm < child; ++rm) {
-                const int node = S.ord[rm], sh = node & 31;
+                const int node = __builtin_amdgcn_readfirstlane((int)S.ord[rm]), sh = node & 31; // wave-uniform
                 const bool hi = node >= 32;
 #pragma unroll
                 for (int sec = 0; sec < 3; ++sec)
@@ -370,8 +376,8 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         const u64 w0 = S.cw[c4 * 4], w1 = S.cw[c4 * 4 + 1], w2 = S.cw[c4 * 4 + 2], w3 = S.cw[c4 * 4 + 3];
         float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
         for (int r = rsub; r < rows; r += RP)
-            store_stream(&dst[(size_t)r * C4], make_float4((float)((w0 >> r) & 1ull), (float)((w1 >> r) & 1ull),
-                                                           (float)((w2 >> r) & 1ull), (float)((w3 >> r) & 1ull)));
+            store_stream(&dst[(size_t)r * C4], make_float4(bit_as_float(w0, r), bit_as_float(w1, r),
+                                                           bit_as_float(w2, r), bit_as_float(w3, r)));
     }
 }
 

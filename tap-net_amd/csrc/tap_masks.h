@@ -31,6 +31,13 @@ __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
     __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
 }
 
+// bit r of a 64-bit column word as 0.f / 1.f without a 64-bit variable shift (quarter rate on CDNA)
+__device__ __forceinline__ float bit_as_float(unsigned long long w, int r)
+{
+    const unsigned half = r < 32 ? (unsigned)w : (unsigned)(w >> 32);
+    return (float)((half >> (r & 31)) & 1u);
+}
+
 // mask math for one column: pack.py:318-329
 __device__ __forceinline__ void mask_column(const MaskArgs &a, int env, int j, long real_m,
                                             float move, float small, float large)
@@ -259,8 +266,8 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
             if (a.dyn_out) {
                 float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
                 for (int r = rsub; r < rows; r += RP) {
-                    const float4 v = make_float4((float)((n0 >> r) & 1ull), (float)((n1 >> r) & 1ull),
-                                                 (float)((n2 >> r) & 1ull), (float)((n3 >> r) & 1ull));
+                    const float4 v = make_float4(bit_as_float(n0, r), bit_as_float(n1, r), bit_as_float(n2, r),
+                                                 bit_as_float(n3, r));
                     store_stream(&dst[(size_t)r * C4], v);
                 }
             }
