@@ -98,14 +98,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_step(StepArgs a)
     extern __shared__ int lds[];
     const int tid = threadIdx.x;
     tap_macs3_wave<G>(a, 0, nullptr, blockIdx.x * ((int)blockDim.x / G) + tid / G, tid % G, tid & 63,
-                      lds + (tid / G) * macs3_group_words(G, a.d.n_max));
+                      lds + (tid / G) * macs3_group_words(G, a.d.n_max, a.d.H));
 }
 
 template <int G> static int launch_macs3(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     const tap_env_desc &d = a.d;
     int threads = TAP_BLOCK;
-    const size_t per_env = (size_t)macs3_group_words(G, d.n_max) * sizeof(int);
+    const size_t per_env = (size_t)macs3_group_words(G, d.n_max, d.H) * sizeof(int);
     while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
     const int epb = threads / G, grid = (d.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;

@@ -52,7 +52,8 @@ constexpr int TAP_BLOCK = 256; // threads per workgroup (4 wave64)
 // pos     int32 [n_max*D][B]      positions, step-major so one lock-step is one coalesced row
 // stable  uint8 [n_max][B]
 // blk     int32 [n_max*D][B]      placed block sizes (MACS history only)
-// occ     uint64 [B][cells]       MACS 3D only: complement of the cell's free-list column (tap_macs3.h)
+// occ     uint64 [B][cells][HW]   MACS 3D only: complement of the cell's free-list column, HW = ceil(H/64)
+//                                 words (tap_macs3.h)
 struct EnvView {
     int32_t *hm;
     int32_t *cnt;
@@ -74,7 +75,7 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
     size_t o_hm = take(B * cells * 4), o_cnt = take(B * 16), o_err = take(B * 4);
     size_t o_pos = take(nD * B * 4), o_st = take((size_t)d->n_max * B);
     size_t o_blk = d->strategy == TAP_MACS ? take(nD * B * 4) : 0;
-    size_t o_occ = (d->strategy == TAP_MACS && d->D == 3) ? take(B * cells * 8) : 0;
+    size_t o_occ = (d->strategy == TAP_MACS && d->D == 3) ? take(B * cells * 8 * (size_t)((d->H + 63) / 64)) : 0;
     if (v) {
         v->hm = reinterpret_cast<int32_t *>(p + o_hm);
         v->cnt = reinterpret_cast<int32_t *>(p + o_cnt);

@@ -1,6 +1,6 @@
 // tap_macs3.h -- device code: one MACS / MUL 3D placement for one container, G lanes per container
 // (lane = height-map cell).  tools.calc_one_position_mcs_3d (tools.py:2751-3165) re-stated on the
-// height-map, the placement history and one 64-bit word per cell; used by macs.hip.
+// height-map, the placement history and ceil(H/64) 64-bit words per cell; used by macs.hip and transition.hip.
 //
 // State.  The reference keeps a voxel grid and, per (level z, row y), a list of free x-intervals.
 //   * voxel (x,y,z) == 0  <=>  z >= hm[x,y]: update_container (tools.py:3043-3047) fills the block
@@ -13,8 +13,8 @@
 //         levels below z, per footprint row: clear the row's cells unless F also holds both
 //         x-neighbours of the row AND every cell of the row (the "strictly inside" case)
 //     (checked against the reference's lists over 2.3e5 rows, scratch notes in DESIGN.md).  Each
-//     cell carries its column of F as one u64 (bit z), stored complemented so that a zeroed state
-//     blob is the empty container; hence H <= 64.
+//     cell carries its column of F as ceil(H/64) u64 (bit z), stored complemented so that a zeroed state
+//     blob is the empty container; ceil(H/64) <= 4 words per cell, hence H <= 256.
 //   * voxel *values* (which block) are only compared in the "partly covered top" case
 //     (tools.py:2924-2942) and are recomputed from the placement history when that case occurs.
 //
@@ -33,14 +33,16 @@
 #include "tap_place.h"
 
 constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 8x8, 40 blocks)
-constexpr int MACS3_MAX_H = 64;
+constexpr int MACS3_MAX_H = 256;   // HW = ceil(H / 64) <= 4 words per cell
 constexpr int MACS3_HIST = 8;      // ints per history entry: x y z xx yy zz placed pad
 
-// LDS words per env group: occ u64[G] | lvm u64[G+2] | hm[G] | ord[G] | lvh[G+2] | lvr[G+2] | ems[CAP] |
+__host__ __device__ constexpr int macs3_hw(int H) { return (H + 63) / 64; }
+
+// LDS words per env group: occ u64[G*HW] | lvm u64[G+2] | hm[G] | ord[G] | lvh[G+2] | lvr[G+2] | ems[CAP] |
 // hist[8 n_max]   (lv*: the distinct levels of the height-map, at most cells + 1 of them)
-__host__ __device__ constexpr int macs3_group_words(int G, int n_max)
+__host__ __device__ constexpr int macs3_group_words(int G, int n_max, int H)
 {
-    return 2 * G + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + MACS3_HIST * n_max;
+    return 2 * G * macs3_hw(H) + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + MACS3_HIST * n_max;
 }
 
 struct Macs3Lds {
@@ -48,12 +50,13 @@ struct Macs3Lds {
     int *hm, *ord, *lvh, *lvr, *ems, *hist;
 };
 
-__device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G)
+__device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G, int H)
 {
     Macs3Lds m;
-    m.occ = reinterpret_cast<u64 *>(base);
-    m.lvm = m.occ + G;
-    m.hm = base + 2 * G + 2 * (G + 2);
+    const int HW = macs3_hw(H);
+    m.occ = reinterpret_cast<u64 *>(base);           // cell-major: word w of cell c at occ[c*HW + w]
+    m.lvm = m.occ + G * HW;
+    m.hm = base + 2 * G * HW + 2 * (G + 2);
     m.ord = m.hm + G;
     m.lvh = m.ord + G;
     m.lvr = m.lvh + G + 2;
@@ -116,18 +119,18 @@ __device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask)
 
 // One placement.  Preconditions: S.hm[cell] = hm, S.occ[cell] = occ (x-major cells, 0 beyond W*L),
 // S.hist[0..8*cnt.count) filled, visible to the group (wave-level sync by the caller).  do_step is
-// group-uniform.  On return hm/occ/cnt are updated and res describes the placement.
+// group-uniform.  On return hm/cnt and the cell's words in S.occ are updated and res describes the
+// placement.
 template <int G>
 __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S, int cell, int gl0, int &hm,
-                                            u64 &occ, Counters &cnt, int &err, int bx, int by, int bz,
-                                            bool do_step)
+                                            Counters &cnt, int &err, int bx, int by, int bz, bool do_step)
 {
     const int W = c.W, L = c.L, H = c.H, cells = W * L;
     Placement res = {0, 0, 0, 0, 0};
     if (!do_step) return res;
     const int hard = c.flags & TAP_F_HARD;
     const int vol = bx * by * bz, step = cnt.count;
-    const u64 hmask = H >= 64 ? ~0ull : ((1ull << H) - 1ull);
+    const int HW = macs3_hw(H);
     const unsigned wmask = (1u << W) - 1u, lmask = (1u << L) - 1u;
     const int wl = threadIdx.x & 63;
 
@@ -135,13 +138,17 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     const bool inT = cell < cells;
     const int ty = cell / W, tx = cell - ty * W;
     const int hmT = inT ? S.hm[tx * L + ty] : INT_MAX;
-    const u64 FT = inT ? (~S.occ[tx * L + ty] & hmask) : 0ull;
+    const u64 *occT = S.occ + (size_t)(inT ? tx * L + ty : 0) * HW;   // this lane's column of F, complemented
+    auto wordF = [&](int w) -> u64 {                                     // F bits of levels [64w, 64w + 64)
+        const int nb = H - 64 * w;
+        return inT ? (~occT[w] & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull))) : 0ull;
+    };
     const int gmax = group_max<G>(inT ? hmT : 0);
     u64 colsel = 0; // bit y*W for every row
     for (int y = 0; y < L; ++y) colsel |= 1ull << (y * W);
 
     auto rowT = [&](u64 m, int y) -> unsigned { return (unsigned)(m >> (y * W)) & wmask; };
-    auto levelF = [&](int z) -> u64 { return ballot_g<G>(inT && ((FT >> z) & 1ull), gl0); };
+    auto levelF = [&](int z) -> u64 { return ballot_g<G>((wordF(z >> 6) >> (z & 63)) & 1ull, gl0); };
     auto levelT = [&](int z) -> u64 { return ballot_g<G>(hmT <= z, gl0); }; // container[.., z] == 0
 
     // ---- phase 1: EMS list (identical on every lane of the group) -------------------------------
@@ -168,12 +175,13 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
 
     // (a) per-(level, row) free intervals (tools.py:2813-2841); level z is skipped when all its
     //     lists equal those of z-1 (:2816), i.e. when no cell's F column changes between the two
-    {
-        u64 chg = group_or64<G>(FT ^ (FT << 1)) | 1ull;
-        const int zmax = H - bz;                                                     // :2815
-        chg = zmax < 0 ? 0ull : (zmax >= 63 ? chg : (chg & ((2ull << zmax) - 1ull)));
+    const int zmax = H - bz;                                                         // :2815
+    for (int w = 0; w < HW && 64 * w <= zmax; ++w) {
+        const u64 Fw = wordF(w), carry = w > 0 ? (wordF(w - 1) >> 63) : 0ull;
+        u64 chg = group_or64<G>(Fw ^ ((Fw << 1) | carry)) | (w == 0 ? 1ull : 0ull);
+        if (zmax - 64 * w < 63) chg &= (2ull << (zmax - 64 * w)) - 1ull;
         while (chg) {
-            const int z = __ffsll((long long)chg) - 1;
+            const int z = 64 * w + __ffsll((long long)chg) - 1;
             chg &= chg - 1ull;
             const u64 Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : 0ull, Tz = levelT(z);
             for (int y = 0; y < L; ++y) {
@@ -465,17 +473,29 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         const int py = win / W, px = win - py * W;
         res.placed = 1; res.x = px; res.y = py; res.z = Z; res.stab = stab;
         const int cx = cell / L, cy = cell - cx * L;
-        if (cell < cells && cx >= px && cx < px + bx && cy >= py && cy < py + by) {
-            // update_level_free_space (:2989-3041) on this cell's column of F
-            u64 keep = 0;
-            if (px > 0 && px + bx < W) {
-                keep = ~0ull;
-                for (int x = px - 1; x <= px + bx; ++x) keep &= ~S.occ[x * L + cy];
+        const bool foot = cell < cells && cx >= px && cx < px + bx && cy >= py && cy < py + by;
+        u64 nw[4] = {0, 0, 0, 0};
+        if (foot) {
+            // update_level_free_space (:2989-3041) on this cell's column of F, 64 levels at a time
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                if (w >= HW) break;
+                u64 keep = 0;
+                if (px > 0 && px + bx < W) {
+                    keep = ~0ull;
+                    for (int x = px - 1; x <= px + bx; ++x) keep &= ~S.occ[(size_t)(x * L + cy) * HW + w];
+                }
+                const int lo = Z - 64 * w, hi = Z + bz - 64 * w;        // block = bits [lo, hi) of this word
+                const u64 below = lo <= 0 ? 0ull : (lo >= 64 ? ~0ull : ((1ull << lo) - 1ull));
+                const u64 upto = hi <= 0 ? 0ull : (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull));
+                nw[w] = S.occ[(size_t)cell * HW + w] | (upto & ~below) | (below & ~keep);
             }
-            const u64 low = (1ull << Z) - 1ull; // Z < H <= 64
-            const u64 blk = (bz >= 64 ? ~0ull : ((1ull << bz) - 1ull)) << Z;
-            occ |= blk | (low & ~keep);
             hm = Z + bz;                                                             // :3161
+        }
+        tap_wave_lds_sync(); // every neighbour word is read before any is replaced
+        if (foot) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) if (w < HW) S.occ[(size_t)cell * HW + w] = nw[w];
         }
         cnt.valid += vol;
         cnt.empty = emp;
@@ -500,17 +520,16 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     const int B = a.d.B, W = a.d.W, Ld = a.d.L, cells = W * Ld;
     const bool ev = env < B, incell = cell < cells, fresh = flags & TAP_T_FRESH;
     const int gl0 = lane - cell;
-    const Macs3Lds S = macs3_lds(lds_group, G);
+    const int HW = macs3_hw(a.d.H);
+    const Macs3Lds S = macs3_lds(lds_group, G, a.d.H);
 
     int hm = 0, cv = 0;
-    u64 occ = 0;
     if (ev && !fresh) {
-        if (incell) {
-            hm = a.v.hm[(size_t)env * cells + cell];
-            occ = a.v.occ[(size_t)env * cells + cell];
-        }
+        if (incell) hm = a.v.hm[(size_t)env * cells + cell];
         if (cell < 4) cv = a.v.cnt[(size_t)env * 4 + cell];
     }
+    for (int k = cell; k < G * HW; k += G)           // the env's words are contiguous: coalesced
+        S.occ[k] = (ev && !fresh && k < cells * HW) ? a.v.occ[(size_t)env * cells * HW + k] : 0ull;
     Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
     int bx = 1, by = 1, bz = 1;
     bool act = ev;
@@ -537,7 +556,6 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > Ld)) { err |= 4; do_step = false; }
 
     S.hm[cell] = hm;
-    S.occ[cell] = occ;
     if (ev) // one round trip for the whole placement history
         for (int k = cell; k < cnt.count * 6 && k < a.d.n_max * 6; k += G) {
             const int i = k / 6, f = k - i * 6;
@@ -548,7 +566,7 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     tap_wave_lds_sync();
     const int step = cnt.count;
     const PlaceCfg cfg = {W, Ld, a.d.H, a.d.flags, a.lut};
-    const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, occ, cnt, err, bx, by, bz, do_step);
+    const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, cnt, err, bx, by, bz, do_step);
     err = group_or<G>(err);
 
     tap_wave_lds_sync();
@@ -556,10 +574,9 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     tap_wave_lds_sync();
     const int gmax = (flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
     if (ev) {
-        if (incell && (do_step || fresh)) {
-            a.v.hm[(size_t)env * cells + cell] = hm;
-            a.v.occ[(size_t)env * cells + cell] = occ;
-        }
+        if (incell && (do_step || fresh)) a.v.hm[(size_t)env * cells + cell] = hm;
+        if (do_step || fresh)
+            for (int k = cell; k < cells * HW; k += G) a.v.occ[(size_t)env * cells * HW + k] = S.occ[k];
         if (a.feature_out)
             tap_write_feature<3, G>(a.d.feature, W, Ld, S.hm, cell, hm, a.feature_out + (size_t)env * a.flen);
         if (cell == 0) {

@@ -195,7 +195,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3
     __builtin_amdgcn_s_setprio(2);
     int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
     tap_macs3_wave<G>(a.s, a.flags, a.ratio_out, env_base + tid / G, tid % G, lane,
-                      macs_base + (tid / G) * macs3_group_words(G, a.s.d.n_max));
+                      macs_base + (tid / G) * macs3_group_words(G, a.s.d.n_max, a.s.d.H));
 }
 
 template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
@@ -204,7 +204,7 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
     const int grid = (a.s.d.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
-                       (size_t)EPB * macs3_group_words(G, a.s.d.n_max) * sizeof(int);
+                       (size_t)EPB * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
     if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
     switch (mask_fast_path_cols(a.m)) {
     case 1: hipLaunchKernelGGL((k_transition_macs3<G, 1>), dim3(grid), dim3(THREADS), lds, st, a); break;
