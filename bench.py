@@ -479,7 +479,8 @@ def main():
     ap.add_argument("--no-bits", action="store_true",
                     help="precedence update as an fp32 copy (tap_transition) instead of on the bit shadow (tap_transition_bits)")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
-    ap.add_argument("--fused-rolling", action="store_true", help="c5: tap_rolling_step instead of env_step + rolling_window")
+    ap.add_argument("--two-launch-rolling", action="store_true",
+                    help="c5: tap_env_step_gather + tap_rolling_window per step instead of the fused tap_rolling_step")
     ap.add_argument("--overlap", action="store_true",
                     help="c5: placement t and window t+1 on two HIP streams (measured slower on this stack: "
                          "285 vs 297 M env-steps/s in a graph, 251 vs 299 eager -- the cross-stream waits cost more "
@@ -503,7 +504,7 @@ def main():
         cfg = (name, D, cs, n, B, reward, strategy)
     rolling = args.config in ROLLING and not args.approx_windows
     if rolling:
-        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=args.fused_rolling,
+        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=not args.two_launch_rolling,
                             overlap=args.overlap)
     else:
         hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits)
@@ -539,8 +540,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy,
-                       "pass": ("rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window) "
-                                "[or tap_rolling_step with --fused-rolling], then window x tap_transition on the last graph") if rolling else
+                       "pass": (("rolling.validate's loop: (n - window) x tap_rolling_step (placement t + window t+1 in one launch), "
+                                 "then window x tap_transition_bits on the last graph") if getattr(hp, "fused_rolling", False) else
+                                ("rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window), "
+                                 "then window x tap_transition_bits on the last graph")) if rolling else
                                ("n x tap_transition%s (update_dynamic+update_mask+gather+add_new_block in one launch; "
                                 "first starts a fresh container, last emits calc_ratio)%s" %
                                 (("_bits", "; dynamic carried between steps as a bit shadow, the fp32 tensor is written "

@@ -402,7 +402,8 @@ struct RollStepArgs {
 };
 
 template <int D, int G>
-__global__ void __launch_bounds__((64 * (4 + 4 * G / 64 + (4 * G % 64 ? 1 : 0)))) k_rolling_step(RollStepArgs a)
+__global__ void __launch_bounds__((64 * (4 + 4 * G / 64 + (4 * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_rolling_step(RollStepArgs a)
 {
     constexpr int EPB = 4;                                  // instances per workgroup
     constexpr int ENV_WAVES = (EPB * G + 63) / 64;
