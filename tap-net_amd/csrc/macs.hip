@@ -13,7 +13,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_step(StepArgs a)
     const int B = a.d.B, W = a.d.W, H = a.d.H;
     const bool ev = env < B, incell = cell < W;
     const int gl0 = (tid & 63) - cell;
-    const MacsLds L = macs_lds(lds + (tid / G) * macs_group_words(G, H, a.d.n_max), G, H);
+    const MacsLds L = macs_lds(lds + (tid / G) * macs_group_words(G, H, a.d.n_max, W), G, H, macs_ems_cap(W, a.d.n_max));
 
     int hm = (ev && incell) ? a.v.hm[(size_t)env * W + cell] : 0;
     const int cv = (ev && cell < 4) ? a.v.cnt[(size_t)env * 4 + cell] : 0;
@@ -79,7 +79,7 @@ template <int G> static int launch_macs(tap_ctx *ctx, const StepArgs &a, hipStre
 {
     const tap_env_desc &d = a.d;
     int threads = TAP_BLOCK; // as many envs per workgroup as fit the 64 KB dynamic-LDS window
-    const size_t per_env = (size_t)macs_group_words(G, d.H, d.n_max) * sizeof(int);
+    const size_t per_env = (size_t)macs_group_words(G, d.H, d.n_max, d.W) * sizeof(int);
     while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
     const int epb = threads / G, grid = (d.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
@@ -126,8 +126,6 @@ int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d)
     }
     if (d.W > 16 || d.H > MACS_MAX_H)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS supports W <= 16 and H <= %d", MACS_MAX_H);
-    if ((d.W + 1) * ((d.W + 1) / 2) + 2 * d.n_max > MACS_EMS_CAP)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS: blocks_num %d too large for the EMS list", d.n_max);
     return TAP_OK;
 }
 

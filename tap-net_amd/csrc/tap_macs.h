@@ -27,29 +27,35 @@
 
 #include "tap_place.h"
 
-constexpr int MACS_EMS_CAP = 128;  // packed EMS entries per env
-constexpr int MACS_SLOT_CAP = 256; // two walks per EMS
+// EMS entries one step can produce: (W+1)/2 free runs on each of at most W+1 distinct levels, plus at
+// most two per placed block (tools.py:2517-2555); two walks (slots) per EMS.  Even, for alignment.
+__host__ __device__ constexpr int macs_ems_cap(int W, int n_max)
+{
+    return ((W + 1) * ((W + 1) / 2) + 2 * n_max + 1) & ~1;
+}
 constexpr int MACS_MAX_H = 256;
 
-// LDS words per env group: hm | ems | slots | taken (uint16 per level) | history (x, z, bx, bz)
-__host__ __device__ constexpr int macs_group_words(int G, int H, int n_max)
+// LDS words per env group: hm | ems[cap] | slots[2 cap] | taken (uint16 per level) | history (x, z, bx, bz)
+__host__ __device__ constexpr int macs_group_words(int G, int H, int n_max, int W)
 {
-    return G + MACS_EMS_CAP + MACS_SLOT_CAP + (H + 1) / 2 + 4 * n_max;
+    return G + 3 * macs_ems_cap(W, n_max) + (H + 1) / 2 + 4 * n_max;
 }
 
 struct MacsLds {
     int *hm, *ems, *slots, *hist;
     unsigned short *taken;
+    int ems_cap;
 };
 
-__device__ __forceinline__ MacsLds macs_lds(int *base, int G, int H)
+__device__ __forceinline__ MacsLds macs_lds(int *base, int G, int H, int ems_cap)
 {
     MacsLds m;
     m.hm = base;
     m.ems = base + G;
-    m.slots = m.ems + MACS_EMS_CAP;
-    m.taken = reinterpret_cast<unsigned short *>(m.slots + MACS_SLOT_CAP);
-    m.hist = m.slots + MACS_SLOT_CAP + (H + 1) / 2;
+    m.ems_cap = ems_cap;
+    m.slots = m.ems + ems_cap;
+    m.taken = reinterpret_cast<unsigned short *>(m.slots + 2 * ems_cap);
+    m.hist = m.slots + 2 * ems_cap + (H + 1) / 2;
     return m;
 }
 
@@ -120,7 +126,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
                                            int &hm, Counters &cnt, int &err, int bx, int bz,
                                            bool do_step)
 {
-    const int W = c.W, H = c.H;
+    const int W = c.W, H = c.H, ems_cap = L.ems_cap;
     const bool incell = cell < W;
     Placement res = {0, 0, 0, 0, 0};
     if (!do_step) return res;
@@ -138,7 +144,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
     int n_ems = 0;
 #define EMS_PUSH(x1, z, x2)                                                                  \
     do {                                                                                     \
-        if (n_ems < MACS_EMS_CAP) L.ems[n_ems++] = ((x1) & 0xff) | (((x2) & 0xff) << 8) | ((z) << 16); \
+        if (n_ems < ems_cap) L.ems[n_ems++] = ((x1) & 0xff) | (((x2) & 0xff) << 8) | ((z) << 16); \
         else err |= 16;                                                                      \
     } while (0)
     // (a) per-level free runs (tools.py:2517-2529); only z = 0 and z in {hm[c]} differ from below
@@ -266,10 +272,13 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         if (!tiebreak) {
             win = group_min<G>(my_r == rmax ? my_slot : INT_MAX);
         } else {
-            int best_adj = INT_MIN, best_s = INT_MAX;
+            int best_adj = INT_MIN, best_s = INT_MAX, n_tied = 0, max_height = gmax;
             for (int s = cell; s < n_slots; s += G) {
                 int xs, Z, sum, stab;
-                if (eval_slot(s, xs, Z, sum, stab) != rmax) continue; // recomputing beats storing r
+                const double r = eval_slot(s, xs, Z, sum, stab);              // recomputing beats storing r
+                max_height = max(max_height, Z + bz);                         // :2719 np.max(heightmap_ems)
+                if (r != rmax) continue;
+                ++n_tied;
                 const int adj = macs_adj<G>(hmr, W, xs, bx, Z + bz, max(gmax, Z + bz));
                 if (adj > best_adj) { best_adj = adj; best_s = s; }
             }
@@ -279,6 +288,10 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
                 if (a2 > best_adj || (a2 == best_adj && s2 < best_s)) { best_adj = a2; best_s = s2; }
             }
             win = best_s;
+            // the reference only scores usable space when more than one entry ties (:2718), and then
+            // indexes levels up to max_height: IndexError once any settled slot reaches above H
+            const int nt = zero ? 2 * n_ems : group_sum<G>(n_tied);
+            if (nt > 1 && group_max<G>(max_height) > H) err |= 1;
         }
     }
 

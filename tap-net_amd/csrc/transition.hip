@@ -115,7 +115,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
     const int cell = tid % G, gl0 = lane - cell;
     const int env = env_base + tid / G;
     const bool ev = env < B, incell = cell < W;
-    const MacsLds L = macs_lds(macs_base + (tid / G) * macs_group_words(G, H, a.s.d.n_max), G, H);
+    const MacsLds L = macs_lds(macs_base + (tid / G) * macs_group_words(G, H, a.s.d.n_max, W), G, H, macs_ems_cap(W, a.s.d.n_max));
     int hm = 0, cv = 0, bx = 1, bz = 1;
     if (ev) {
         if (!fresh) {
@@ -224,7 +224,7 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
     const int grid = (a.s.d.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
-                       (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max) * sizeof(int);
+                       (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max, a.s.d.W) * sizeof(int);
     if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
     switch (mask_fast_path_cols(a.m)) {
     case 1: hipLaunchKernelGGL((k_transition_macs<G, 1>), dim3(grid), dim3(THREADS), lds, st, a); break;
