@@ -71,16 +71,20 @@ class HotPath(object):
     An episode is `windows` consecutive precedence windows of `nw` nodes each over ONE long-lived
     container per env (windows = 1 except for the rolling-sized config c5)."""
 
-    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None, bits=True):
+    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None, bits=True, instances=None):
         _, D, cs, n, _, reward, strategy = cfg
         self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
         self.nw = window or n
         assert n % self.nw == 0
         self.windows = n // self.nw
         f32 = dict(dtype=torch.float32, device=device)
+        self.instances = instances
         self.static, self.dynamic0, self.tape, self.cs0, self.bits0 = [], [], [], [], []
         for w in range(self.windows):
-            static, dynamic = synth.rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start)
+            if instances is not None:                               # real instances from a committed fixture, tiled
+                static, dynamic = synth.tiled_instances(instances[0], instances[1], B, start=start)
+            else:
+                static, dynamic = synth.rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start)
             tape = synth.random_feasible_tape(static, dynamic, self.nw, seed=seed + 100 * w + 1, start=start)
             self.static.append(static.to(device))
             self.dynamic0.append(dynamic.to(device))
@@ -376,7 +380,7 @@ def kernel_event_times(hp, steps, graph=None):
     return out, empty_us
 
 
-def cpu_baseline(cfg, window=None, budget_s=12.0):
+def cpu_baseline(cfg, window=None, budget_s=12.0, instances=None):
     """The oracle (C port of the reference algorithm) over the same pass, on the host cores."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
@@ -385,7 +389,10 @@ def cpu_baseline(cfg, window=None, budget_s=12.0):
     nw = window or n
     wins = []
     for w in range(n // nw):
-        static, dynamic = synth.rand_instances(B, nw, D, seed=12345 + 100 * w)
+        if instances is not None:
+            static, dynamic = synth.tiled_instances(instances[0], instances[1], B)
+        else:
+            static, dynamic = synth.rand_instances(B, nw, D, seed=12345 + 100 * w)
         tape = synth.random_feasible_tape(static, dynamic, nw, seed=12346 + 100 * w).numpy()
         wins.append((static.numpy(), dynamic.numpy(), tape))
     R = wins[0][0].shape[2] // nw
@@ -476,6 +483,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rand-blocks", action="store_true",
+                    help="c4: RAND-marginal synthetic instances instead of the reference-generated PPSG fixture tiled x128")
     ap.add_argument("--no-bits", action="store_true",
                     help="precedence update as an fp32 copy (tap_transition) instead of on the bit shadow (tap_transition_bits)")
     ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
@@ -507,7 +516,16 @@ def main():
         hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=not args.two_launch_rolling,
                             overlap=args.overlap)
     else:
-        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits)
+        instances = None
+        if args.config == "c4" and not args.rand_blocks:
+            fx = os.path.join(ROOT, "tests", "golden", "ppsg_2d.npz")
+            if os.path.exists(fx):                                  # 64 PPSG instances written by the reference
+                z = np.load(fx)                                     # (tests/golden/make_golden.py --only ppsg)
+                instances = (z["static"].astype(np.float32), z["dynamic"].astype(np.float32))
+                name = name.replace("RAND-marginal blocks", "the reference's PPSG generator: 64 instances tiled x%d" % (B // 64))
+                cfg = (name, D, cs, n, B, reward, strategy)
+        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits,
+                     instances=instances)
     use_graph = not args.no_graph
     dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
     hp.env.check()
@@ -558,7 +576,7 @@ def main():
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_rolling(cfg, WINDOW[args.config]) if rolling else cpu_baseline(cfg, WINDOW.get(args.config))
+            out["cpu_baseline"] = cpu_baseline_rolling(cfg, WINDOW[args.config]) if rolling else cpu_baseline(cfg, WINDOW.get(args.config), instances=getattr(hp, 'instances', None))
         if args.sweep:
             for b in (8192, 32768, 131072, 524288, 2097152):
                 try:

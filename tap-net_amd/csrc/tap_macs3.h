@@ -81,6 +81,19 @@ template <int G> __device__ __forceinline__ u64 group_or64(u64 v)
     return v;
 }
 
+// cell / position masks: 32-bit arithmetic when the container has at most 32 cells (variable 64-bit
+// shifts run at quarter rate), 64-bit otherwise
+template <int G> struct m3_mask { typedef u64 type; };
+template <> struct m3_mask<8> { typedef unsigned type; };
+template <> struct m3_mask<16> { typedef unsigned type; };
+template <> struct m3_mask<32> { typedef unsigned type; };
+__device__ __forceinline__ int m3_ffs(unsigned v) { return __ffs((int)v) - 1; }               // -1 if empty
+__device__ __forceinline__ int m3_ffs(u64 v) { return __ffsll((long long)v) - 1; }
+__device__ __forceinline__ int m3_fls(unsigned v) { return 31 - __clz((int)v); }
+__device__ __forceinline__ int m3_fls(u64 v) { return 63 - __clzll((long long)v); }
+__device__ __forceinline__ int m3_popc(unsigned v) { return __popc(v); }
+__device__ __forceinline__ int m3_popc(u64 v) { return __popcll(v); }
+
 __device__ __forceinline__ unsigned m3_bits(int a, int b) // bits a..b inclusive, empty when a > b
 {
     return a > b ? 0u : (((2u << (b - a)) - 1u) << a);
@@ -130,6 +143,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     if (!do_step) return res;
     const int hard = c.flags & TAP_F_HARD;
     const int vol = bx * by * bz, step = cnt.count;
+    typedef typename m3_mask<G>::type mk;                // masks over cells / positions
     const int HW = macs3_hw(H);
     const unsigned wmask = (1u << W) - 1u, lmask = (1u << L) - 1u;
     const int wl = threadIdx.x & 63;
@@ -144,12 +158,12 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         return inT ? (~occT[w] & (nb >= 64 ? ~0ull : ((1ull << nb) - 1ull))) : 0ull;
     };
     const int gmax = group_max<G>(inT ? hmT : 0);
-    u64 colsel = 0; // bit y*W for every row
-    for (int y = 0; y < L; ++y) colsel |= 1ull << (y * W);
+    mk colsel = 0; // bit y*W for every row
+    for (int y = 0; y < L; ++y) colsel |= (mk)1 << (y * W);
 
-    auto rowT = [&](u64 m, int y) -> unsigned { return (unsigned)(m >> (y * W)) & wmask; };
-    auto levelF = [&](int z) -> u64 { return ballot_g<G>((wordF(z >> 6) >> (z & 63)) & 1ull, gl0); };
-    auto levelT = [&](int z) -> u64 { return ballot_g<G>(hmT <= z, gl0); }; // container[.., z] == 0
+    auto rowT = [&](mk m, int y) -> unsigned { return (unsigned)(m >> (y * W)) & wmask; };
+    auto levelF = [&](int z) -> mk { return (mk)ballot_g<G>((wordF(z >> 6) >> (z & 63)) & 1ull, gl0); };
+    auto levelT = [&](int z) -> mk { return (mk)ballot_g<G>(hmT <= z, gl0); }; // container[.., z] == 0
 
     // ---- phase 1: EMS list (identical on every lane of the group) -------------------------------
     int n_ems = 0;
@@ -183,7 +197,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         while (chg) {
             const int z = 64 * w + __ffsll((long long)chg) - 1;
             chg &= chg - 1ull;
-            const u64 Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : 0ull, Tz = levelT(z);
+            const mk Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : (mk)0, Tz = levelT(z);
             for (int y = 0; y < L; ++y) {
                 if (y + by > L) break;                                               // :2818
                 const unsigned row = rowT(Fz, y), prow = y > 0 ? rowT(Fz, y - 1) : 0u;
@@ -221,7 +235,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         const int *hb = S.hist + bi * MACS3_HIST;
         const int x = hb[0], y = hb[1], z = hb[2], xx = hb[3], yy = hb[4], zz = hb[5];
         const int xe = x + xx - 1;
-        const u64 T = levelT(z);
+        const mk T = levelT(z);
         const unsigned spanx = m3_bits(x, xe);
         if (y + yy < L) {                                                            // :2847 beyond +y
             const unsigned r = rowT(T, y + yy);
@@ -276,7 +290,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         }
         if (z + zz < H) {                                                            // :2909 on top
             const int t = z + zz;
-            const u64 Tt = levelT(t);
+            const mk Tt = levelT(t);
             bool full = true;
             for (int j = 0; j < yy; ++j) full = full && (rowT(Tt, y + j) & spanx) == spanx;
             if (full) {                                                              // :2911-2913
@@ -293,14 +307,14 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                         t >= hk[2] && t < hk[2] + hk[5]) id = k + 1;
                 }
                 const int idl = __shfl(id, (wl + 63) & 63);                          // the cell at x-1 (same row)
-                const u64 EQ = ballot_g<G>(inT && tx > 0 && id == idl, gl0);
+                const mk EQ = (mk)ballot_g<G>(inT && tx > 0 && id == idl, gl0);
                 auto hist = [&](int i, int j) -> int {                               // :2915-2922
                     const unsigned v = (rowT(Tt, y + j) >> (x + i)) & ((1u << (xx - i)) - 1u);
                     return __ffs((int)~v) - 1;
                 };
                 auto rows_equal = [&](int i, int ja, int jb) -> bool {               // rows x+i, x+i-1 over [ja, jb)
                     bool eq = true;
-                    for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((y + j) * W + x + i)) & 1ull);
+                    for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((y + j) * W + x + i)) & 1);
                     return eq;
                 };
                 for (int i = 0; i < xx; ++i)                                         // :2924-2942
@@ -334,56 +348,56 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     }
     const bool okp = posv && (stab_p || !hard);                                      // :2963-2965
     const int X = W - bx + 1, Y = L - by + 1;
-    u64 taken = 0;
+    mk taken = 0;
     int n_slots = 0;
     S.ord[cell] = -1;
-    auto rect = [&](int xa, int xb, int ya, int yb) -> u64 { // [xa, xb) x [ya, yb), y-major
-        const u64 rows = colsel & ((yb >= L ? ~0ull : ((1ull << (yb * W)) - 1ull)) & ~((1ull << (ya * W)) - 1ull));
-        return (u64)m3_bits(xa, xb - 1) * rows;
+    auto rect = [&](int xa, int xb, int ya, int yb) -> mk { // [xa, xb) x [ya, yb), y-major
+        const mk rows = colsel & ((yb >= L ? ~(mk)0 : (((mk)1 << (yb * W)) - 1)) & ~(((mk)1 << (ya * W)) - 1));
+        return (mk)m3_bits(xa, xb - 1) * rows;
     };
-    auto fold = [&](u64 m) -> unsigned {
+    auto fold = [&](mk m) -> unsigned {
         unsigned f = 0;
         for (int y = 0; y < L; ++y) f |= rowT(m, y);
         return f;
     };
     auto settle = [&](int px, int py) {
         const int p = py * W + px;
-        taken |= 1ull << p;
+        taken |= (mk)1 << p;
         S.ord[p] = n_slots++; // same value from every lane of the group
     };
     for (int e = 0; e < n_ems; ++e) {
         const int pk = S.ems[e];
         const int X1 = pk & 15, Y1 = (pk >> 4) & 15, X2 = (pk >> 8) & 15, Y2 = (pk >> 12) & 15, Z = pk >> 16;
-        const u64 gm = ballot_g<G>(okp && mp == Z, gl0);
+        const mk gm = (mk)ballot_g<G>(okp && mp == Z, gl0);
         if (!(gm & ~taken)) continue;
         const int xr = X2 - bx + 2, yr = Y2 - by + 2;
         if (X1 < X && Y1 < Y) {                                                      // :3085 x up, then y up
-            const u64 m = gm & ~taken & rect(X1, X, Y1, Y);
+            const mk m = gm & ~taken & rect(X1, X, Y1, Y);
             if (m) {
                 const int px = __ffs((int)fold(m)) - 1;
-                const int py = (__ffsll((long long)((m >> px) & colsel)) - 1) / W;
+                const int py = m3_ffs((mk)((m >> px) & colsel)) / W;
                 settle(px, py);
             }
         }
         if (xr > 0 && Y1 < Y) {                                                      // :3093 y up, then x down
-            const u64 m = gm & ~taken & rect(0, xr, Y1, Y);
+            const mk m = gm & ~taken & rect(0, xr, Y1, Y);
             if (m) {
-                const int py = (__ffsll((long long)m) - 1) / W;
+                const int py = m3_ffs(m) / W;
                 settle(31 - __clz((int)rowT(m, py)), py);
             }
         }
         if (xr > 0 && yr > 0) {                                                      // :3101 x down, then y down
-            const u64 m = gm & ~taken & rect(0, xr, 0, yr);
+            const mk m = gm & ~taken & rect(0, xr, 0, yr);
             if (m) {
                 const int px = 31 - __clz((int)fold(m));
-                const int py = (63 - __clzll((long long)((m >> px) & colsel))) / W;
+                const int py = m3_fls((mk)((m >> px) & colsel)) / W;
                 settle(px, py);
             }
         }
         if (X1 < X && yr > 0) {                                                      // :3109 y down, then x up
-            const u64 m = gm & ~taken & rect(X1, X, 0, yr);
+            const mk m = gm & ~taken & rect(X1, X, 0, yr);
             if (m) {
-                const int py = (63 - __clzll((long long)m)) / W;
+                const int py = m3_fls(m) / W;
                 settle(__ffs((int)rowT(m, py)) - 1, py);
             }
         }
@@ -413,8 +427,8 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     for (int o = G / 2; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, G));
     int win = -1; // y-major position of the winner
     if (n_slots > 0) {
-        const u64 tied = ballot_g<G>(settled && r == rmax, gl0);
-        const int nt = zero ? 4 * n_ems : __popcll(tied); // len(best_ems_indexes), unsettled entries are 0.0
+        const mk tied = (mk)ballot_g<G>(settled && r == rmax, gl0);
+        const int nt = zero ? 4 * n_ems : m3_popc(tied); // len(best_ems_indexes), unsettled entries are 0.0
         if (!(tiebreak && nt > 1)) {                                                 // :3145-3148
             const int wo = group_min<G>((settled && r == rmax) ? ord : INT_MAX);
             win = __ffsll((long long)ballot_g<G>(settled && ord == wo, gl0)) - 1;

@@ -76,6 +76,16 @@ def rand_instances(batch, n, block_dim, seed=12345, start=0, p_move=0.22, p_side
     return torch.from_numpy(np.ascontiguousarray(static)), torch.from_numpy(np.ascontiguousarray(dynamic))
 
 
+def tiled_instances(static_fix, dynamic_fix, batch, start=0):
+    """``batch`` instances taken cyclically from a fixture of real instances (numpy or torch, PACKDataset
+    layout): env ``start + i`` gets fixture instance ``(start + i) % len(fixture)``, so shards see what
+    the single-GPU run sees."""
+    st = torch.as_tensor(np.asarray(static_fix), dtype=torch.float32)
+    dy = torch.as_tensor(np.asarray(dynamic_fix), dtype=torch.float32)
+    idx = (torch.arange(batch) + int(start)) % st.shape[0]
+    return st[idx].contiguous(), dy[idx].contiguous()
+
+
 def random_feasible_tape(static, dynamic, n, seed=1, start=0):
     """A valid action tape (batch, n) int64 for the instances: at every step a uniformly random
     selectable column (numpy re-statement of the mask rule, appendix E; host only, setup time)."""

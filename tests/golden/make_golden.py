@@ -16,6 +16,7 @@ Fixtures:
   reward_tour.npz                    pack.reward on those tours
   kat.npz                            hand-checkable known answers
   rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
+  ppsg_2d.npz                        (--only ppsg) 64 instances of the reference's PPSG generator + MACS traces over them
 """
 import argparse
 import itertools
@@ -221,6 +222,42 @@ def make_dataset(pack, D, tmp, count):
     return torch.from_numpy(static.astype(np.float32)), torch.from_numpy(dynamic.astype(np.float32))
 
 
+def make_ppsg(tools, pack, src=None):
+    """64 PPSG instances (2D, 20 blocks, initial container 7 wide) written by the reference's own
+    generator -- SURVEY 8(c)/(d): pack.create_dataset(10, 8, 10000, 2, 7, 50, 1, [1, 5], seed=12345)
+    (generate_height_prob reads its 10 000 validation samples) followed by
+    pack.create_dataset_gt(20, 8, 64, 2, 7, 50, 7, 50, 'bot', 1, [1, 5], seed=12345).  The
+    perfect-packing generator is a rejection sampler and takes the better part of an hour, so an
+    already generated directory can be passed with --ppsg-dir.  Stored: the PACKDataset tensors and the
+    MACS trace of the reference container over the blocks in file order (rotation 0)."""
+    n = 20
+    if src is None:
+        tmp = tempfile.mkdtemp()
+        cwd = os.getcwd()
+        os.chdir(tmp)
+        try:
+            pack.create_dataset(10, 8, 10000, 2, 7, 50, 1, [1, 5], seed=12345)
+            _, src = pack.create_dataset_gt(n, 8, 64, 2, 7, 50, 7, 50, "bot", 1, [1, 5], seed=12345)
+            src = os.path.abspath(src)
+        finally:
+            os.chdir(cwd)
+    src = src.rstrip("/") + "/"
+    ds = pack.PACKDataset(src, n, 64, 12345, "bot", "diff", True, 7, unit=1)
+    static = ds.static.detach().numpy().astype(np.int8)
+    dynamic = ds.dynamic.detach().numpy().astype(np.int8)
+    assert np.array_equal(static.astype(np.float32), ds.static.detach().numpy())
+    assert np.array_equal(dynamic.astype(np.float32), ds.dynamic.detach().numpy())
+    blocks = np.ascontiguousarray(static[:, 1:, :n].transpose(0, 2, 1)).astype(np.int8)   # rotation 0, file order
+    cases = []
+    for reward in ("C+P+S-mcs-soft", "C+P+S-mcs-hard"):
+        meta = dict(cs=[7, 100], n=n, reward=reward, feat="diff", strategy="MACS")
+        cases.append((meta, trace_container(tools, [7, 100], n, reward, "diff", "MACS", blocks), blocks))
+    files = {}
+    for f in ("blocks", "pos", "container", "dep_move", "dep_small", "dep_large"):
+        files["txt_" + f] = np.loadtxt(src + f + ".txt").astype(np.int8)
+    save("ppsg_2d.npz", static=static, dynamic=dynamic, **files, **pack_cases(cases))
+
+
 def make_masks(pack, D, static, dynamic):
     """Random feasible action tapes through the reference's update_dynamic / update_mask."""
     import torch
@@ -377,6 +414,7 @@ def make_rolling(tools, generate):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--ppsg-dir", default=None, help="directory create_dataset_gt already wrote (for --only ppsg)")
     args = ap.parse_args()
     mods = ref_loader.load()
     if mods is None:
@@ -389,6 +427,7 @@ def main():
     if want("lbg3d"): make_lbg3d(tools)
     if want("macs2d"): make_macs2d(tools)
     if want("macs3d"): make_macs3d(tools)
+    if args.only and "ppsg" in args.only: make_ppsg(tools, pack, args.ppsg_dir)   # slow: only on request
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)

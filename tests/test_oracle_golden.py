@@ -32,6 +32,15 @@ def test_container_traces(fixture):
     assert ncases >= 8
 
 
+def test_ppsg_instances_macs_traces():
+    """The reference's own PPSG instances (perfect-packing generator) through MACS."""
+    n = 0
+    for meta, tr in G.cases("ppsg_2d.npz"):
+        _check_trace(meta, tr)
+        n += 1
+    assert n == 2
+
+
 def test_per_step_counters_2d():
     """valid/empty after every step, via the step-wise Env API."""
     for meta, tr in G.cases("lbg2d.npz"):
