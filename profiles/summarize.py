@@ -55,7 +55,9 @@ for k, m in means.items():
 traffic.setdefault("_note", "")
 traffic["_source"] = "profiles/summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes per launch"
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
-bj = os.path.join(src, "prof_%s" % tag, "%s_bench.json" % cfg)
+# bench lines under profiles/ come from clean runs (gpurun_out/bench_<tag>/<cfg>.json), never from the
+# profiled run, whose timings the tracer perturbs
+bj = os.path.join(src, "bench_%s" % tag, "%s.json" % cfg)
 if os.path.exists(bj) and os.path.getsize(bj):
     shutil.copy(bj, os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, cfg)))
 print(json.dumps(traffic, indent=1))
