@@ -81,7 +81,10 @@ class HotPath(object):
         self.instances = instances
         self.static, self.dynamic0, self.tape, self.cs0, self.bits0 = [], [], [], [], []
         for w in range(self.windows):
-            if instances is not None:                               # real instances from a committed fixture, tiled
+            if instances == "generate":                             # RAND instances of the device-side generator (f1)
+                static, dynamic = synth.device_rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start, device=device)
+                static, dynamic = static.cpu(), dynamic.cpu()
+            elif instances is not None:                             # real instances from a committed fixture, tiled
                 static, dynamic = synth.tiled_instances(instances[0], instances[1], B, start=start)
             else:
                 static, dynamic = synth.rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start)
@@ -389,7 +392,9 @@ def cpu_baseline(cfg, window=None, budget_s=12.0, instances=None):
     nw = window or n
     wins = []
     for w in range(n // nw):
-        if instances is not None:
+        if isinstance(instances, tuple) and len(instances) == 3:     # ("given", [static per window], [dynamic per window])
+            static, dynamic = instances[1][w][:B].cpu(), instances[2][w][:B].cpu()
+        elif instances is not None:
             static, dynamic = synth.tiled_instances(instances[0], instances[1], B)
         else:
             static, dynamic = synth.rand_instances(B, nw, D, seed=12345 + 100 * w)
@@ -483,6 +488,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--synthetic-precedence", action="store_true",
+                    help="c2/c3: RAND-marginal blocks with a random precedence DAG (synth.rand_instances) instead of "
+                         "instances from the device-side RAND generator (blocks packed into the 7-wide initial container)")
     ap.add_argument("--rand-blocks", action="store_true",
                     help="c4: RAND-marginal synthetic instances instead of the reference-generated PPSG fixture tiled x128")
     ap.add_argument("--no-bits", action="store_true",
@@ -517,6 +525,8 @@ def main():
                             overlap=args.overlap)
     else:
         instances = None
+        if args.config in ("c2", "c3") and not args.synthetic_precedence:
+            instances = "generate"
         if args.config == "c4" and not args.rand_blocks:
             fx = os.path.join(ROOT, "tests", "golden", "ppsg_2d.npz")
             if os.path.exists(fx):                                  # 64 PPSG instances written by the reference
@@ -558,6 +568,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy,
+                       "instances": ("device-generated 50-block RAND instances (generate.generate_instances), initial container 7 wide"
+                                     if rolling else "RAND instances of the device-side generator (generate_blocks semantics: "
+                                     "random blocks packed into the 7-wide initial container, real precedence)"
+                                     if getattr(hp, "instances", None) == "generate" else
+                                     "fixture tiled" if getattr(hp, "instances", None) is not None else
+                                     "RAND-marginal blocks, random precedence DAG (synth.rand_instances)"),
                        "pass": (("rolling.validate's loop: (n - window) x tap_rolling_step (placement t + window t+1 in one launch), "
                                  "then window x tap_transition_bits on the last graph") if getattr(hp, "fused_rolling", False) else
                                 ("rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window), "
@@ -576,7 +592,7 @@ def main():
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_rolling(cfg, WINDOW[args.config]) if rolling else cpu_baseline(cfg, WINDOW.get(args.config), instances=getattr(hp, 'instances', None))
+            out["cpu_baseline"] = cpu_baseline_rolling(cfg, WINDOW[args.config]) if rolling else cpu_baseline(cfg, WINDOW.get(args.config), instances=("given", hp.static, hp.dynamic0) if getattr(hp, 'instances', None) == 'generate' else getattr(hp, 'instances', None))
         if args.sweep:
             for b in (8192, 32768, 131072, 524288, 2097152):
                 try:

@@ -76,6 +76,27 @@ def rand_instances(batch, n, block_dim, seed=12345, start=0, p_move=0.22, p_side
     return torch.from_numpy(np.ascontiguousarray(static)), torch.from_numpy(np.ascontiguousarray(dynamic))
 
 
+def device_rand_instances(batch, n, block_dim, seed=12345, start=0, device='cuda',
+                          initial_container_width=7, initial_container_height=50):
+    """RAND instances from the device-side generator (generate.generate_instances = the reference's
+    generate_blocks + PACKDataset layout: random blocks packed into the initial container with
+    'C+P+S-lb-hard', rejected unless all are stable, precedence extracted from the packing), drawn in
+    CHUNK-sized pieces seeded by (seed, chunk index) so any CHUNK-aligned sharding sees the same data.
+    -> (static, dynamic) on ``device``."""
+    from . import generate
+    statics, dynamics = [], []
+    e = start
+    while e < start + batch:
+        c = e // CHUNK
+        lo, hi = c * CHUNK, (c + 1) * CHUNK
+        st, dy = generate.generate_instances(CHUNK, n, block_dim, initial_container_width, initial_container_height,
+                                             1, (1, 5), seed=(int(seed) * 1000003 + c) % (2 ** 31), device=device)
+        statics.append(st[e - lo: min(hi, start + batch) - lo])
+        dynamics.append(dy[e - lo: min(hi, start + batch) - lo])
+        e = hi
+    return torch.cat(statics).contiguous(), torch.cat(dynamics).contiguous()
+
+
 def tiled_instances(static_fix, dynamic_fix, batch, start=0):
     """``batch`` instances taken cyclically from a fixture of real instances (numpy or torch, PACKDataset
     layout): env ``start + i`` gets fixture instance ``(start + i) % len(fixture)``, so shards see what
