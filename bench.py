@@ -272,13 +272,18 @@ GATHER_EVERY = 8   # passes whose (B,) reward vectors share one RCCL all-gather 
 def time_passes(hp, steps, warmup, use_graph, world):
     dev = hp.device
     handles = []
-    acc = torch.empty(GATHER_EVERY, hp.B, dtype=torch.float32, device=dev) if world > 1 else None
+    import torch.distributed as tdd
+    # TAP_BENCH_FORCE_GATHER=1 runs the N > 1 code path (accumulate + async all-gather) in a 1-rank
+    # process group: the only way to time its overhead on a 1-GPU box
+    gather = world > 1 or (os.environ.get("TAP_BENCH_FORCE_GATHER") == "1" and tdd.is_available() and tdd.is_initialized())
+    nranks = tdd.get_world_size() if gather else 1
+    acc = torch.empty(GATHER_EVERY, hp.B, dtype=torch.float32, device=dev) if gather else None
     state = {"i": 0}
 
     def flush(count):
         import torch.distributed as dist
         buf = acc[:count].clone()                              # the only exchange of the whole job
-        out = [torch.empty_like(buf) for _ in range(world)]
+        out = [torch.empty_like(buf) for _ in range(nranks)]
         handles.append((dist.all_gather(out, buf, async_op=True), out))
 
     def one_pass(g):
@@ -286,7 +291,7 @@ def time_passes(hp, steps, warmup, use_graph, world):
             g.replay()
         else:
             hp.episode()
-        if world > 1:
+        if gather:
             acc[state["i"]].copy_(hp.reward)
             state["i"] += 1
             if state["i"] == GATHER_EVERY:
@@ -294,7 +299,7 @@ def time_passes(hp, steps, warmup, use_graph, world):
                 state["i"] = 0
 
     def drain():
-        if world > 1 and state["i"]:
+        if gather and state["i"]:
             flush(state["i"])
             state["i"] = 0
         for h, _ in handles:
