@@ -36,7 +36,8 @@ class RandomFeasiblePolicy(object):
 
 def run_episode(static, dynamic, policy, container_width, container_height,
                 reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
-                input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True, bits=None):
+                input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True, bits=None,
+                container_length=None):
     """One episode for a batch (model.py:254-515 minus the network).
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
@@ -52,7 +53,9 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     block_dim = int(static.shape[1]) - 1
     n = int(dynamic.shape[-1]) // (math.factorial(block_dim) if allow_rot else 1)
     B, D = int(static.shape[0]), block_dim
-    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    # model.py:279 builds square 3D containers (L = W); container_length lifts that for callers that want it
+    cs = [container_width, container_height] if D == 2 else \
+        [container_width, container_length or container_width, container_height]
     dev = _lib.resolve_device(static.device)
     if env is None:
         env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
