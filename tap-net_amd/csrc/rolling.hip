@@ -177,9 +177,10 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
 {
     int val = -1, size = 8, fill = 0;
     u64 occ = 0;
+    const int mykey = lane < n ? (int)keys[lane] : 0;   // one LDS read; the loop then reads lanes, not memory
     for (int k = 0; k < n; ++k) {
         // the table state is wave-uniform: say so, and the probe arithmetic runs on the scalar unit
-        const int key = __builtin_amdgcn_readfirstlane((int)keys[k]);
+        const int key = __builtin_amdgcn_readlane(mykey, k);
         const int slot = pyset_probe_mask(occ, size - 1, key);
         if (lane == slot) val = key;
         occ |= 1ull << slot;
@@ -218,10 +219,26 @@ struct RollLds {          // one wavefront's scratch: 4.8 KB, so that 8 workgrou
 };
 
 // one wavefront = one instance, lane v = node v; every lane of the wave must call this
+// -DTAP_PROF: per-phase shader-clock deltas of the first 8192 instances (scratch/prof_roll.py reads them)
+#ifdef TAP_PROF
+__device__ unsigned int tap_prof_w[8192 * 8];
+extern "C" int tap_prof_read(unsigned int *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tap_prof_w), sizeof(unsigned int) * 8192 * 8);
+    return 0;
+}
+#define PROF(i) do { const long long t_ = clock64(); if (v == 0 && inst < 8192) tap_prof_w[inst * 8 + (i)] = (unsigned)(t_ - tp); tp = t_; } while (0)
+#define PROF_BEGIN long long tp = clock64()
+#else
+#define PROF(i) do { } while (0)
+#define PROF_BEGIN do { } while (0)
+#endif
+
 template <int D>
 __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
 {
     if (inst >= a.B) return;
+    PROF_BEGIN;
     const int N = a.N, child = a.child;
     constexpr int R = D == 2 ? 2 : 6;
     const int nRc = child * R;
@@ -243,6 +260,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     };
     u64 entered = uniform64(a.state[(size_t)inst * 2]), window = uniform64(a.state[(size_t)inst * 2 + 1]);
 
+    PROF(0);
     // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
     if (a.remove_ptr) {
         long slot = (long)uniform64((u64)a.remove_ptr[inst]);
@@ -272,6 +290,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     const int short_window = count != child;
     tap_wave_lds_sync();
 
+    PROF(1);
     // (3) node order of the induced sub-graphs (:1684-1688, 1758-1761)
     if (2 * child < N) {
         if (child <= 18) { if (!short_window) pyset_order_wave(S.lst, child, S.ord, v); } // wave-uniform branch
@@ -290,6 +309,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     }
     if (short_window) return;
 
+    PROF(2);
     // (4) tensors (generate.py:1778-1822).  Window-node lanes publish their five column masks (with
     //     the :1690-1705 rule: a blocker that has not entered any window yet => the side counts as
     //     self-blocked) by sub-graph index; then ALL 64 lanes write the tensors element-wise with
@@ -304,6 +324,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + __popcll(window & below)] = v;
     }
     tap_wave_lds_sync();
+    PROF(3);
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
@@ -369,6 +390,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
             }
         }
     }
+    PROF(4);
     if (!packed) return;
     tap_wave_lds_sync();
     const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
@@ -379,6 +401,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
             store_stream(&dst[(size_t)r * C4], make_float4(bit_as_float(w0, r), bit_as_float(w1, r),
                                                            bit_as_float(w2, r), bit_as_float(w3, r)));
     }
+    PROF(5);
 }
 
 
