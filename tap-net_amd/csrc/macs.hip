@@ -143,3 +143,11 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
     }
     return a.d.W <= 8 ? launch_macs<8>(ctx, a, st) : launch_macs<16>(ctx, a, st);
 }
+
+#ifdef TAP_PROF
+extern "C" int tap_prof_read_macs3(unsigned int *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tap_prof_m3), sizeof(unsigned int) * 8192 * 8);
+    return 0;
+}
+#endif

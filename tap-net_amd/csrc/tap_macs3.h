@@ -34,20 +34,22 @@
 
 constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 8x8, 40 blocks)
 constexpr int MACS3_MAX_H = 256;   // HW = ceil(H / 64) <= 4 words per cell
-constexpr int MACS3_HIST = 8;      // ints per history entry: x y z xx yy zz placed pad
+constexpr int MACS3_HIST = 2;      // ints per history entry: x | y<<4 | xx<<8 | yy<<12 | placed<<16,  z | zz<<16
 
 __host__ __device__ constexpr int macs3_hw(int H) { return (H + 63) / 64; }
 
 // LDS words per env group: occ u64[G*HW] | lvm u64[G+2] | hm[G] | ord[G] | lvh[G+2] | lvr[G+2] | ems[CAP] |
-// hist[8 n_max]   (lv*: the distinct levels of the height-map, at most cells + 1 of them)
+// lrun u8[256] | hist[2 n_max]   (lv*: the distinct levels of the height-map, at most cells + 1 of them;
+// lrun: longest run of ones of every byte)
 __host__ __device__ constexpr int macs3_group_words(int G, int n_max, int H)
 {
-    return 2 * G * macs3_hw(H) + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + MACS3_HIST * n_max;
+    return 2 * G * macs3_hw(H) + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + 64 + MACS3_HIST * n_max;
 }
 
 struct Macs3Lds {
     u64 *occ, *lvm;
     int *hm, *ord, *lvh, *lvr, *ems, *hist;
+    unsigned char *lrun;
 };
 
 __device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G, int H)
@@ -61,7 +63,8 @@ __device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G, int H)
     m.lvh = m.ord + G;
     m.lvr = m.lvh + G + 2;
     m.ems = m.lvr + G + 2;
-    m.hist = m.ems + MACS3_EMS_CAP;
+    m.lrun = reinterpret_cast<unsigned char *>(m.ems + MACS3_EMS_CAP);
+    m.hist = m.ems + MACS3_EMS_CAP + 64;
     return m;
 }
 
@@ -109,6 +112,7 @@ __device__ __forceinline__ bool m3_inlist(unsigned r, int v)
 {
     return m3_bit(r, v) && (v == 0 || !m3_bit(r, v - 1) || !m3_bit(r, v + 1));
 }
+// longest run of ones in a byte (L <= 8 columns)
 __device__ __forceinline__ int m3_longest_run(unsigned v)
 {
     int r = 0;
@@ -116,7 +120,8 @@ __device__ __forceinline__ int m3_longest_run(unsigned v)
     return r;
 }
 // largest all-free axis-aligned rectangle of an x-major W x L bit grid (bit x*L + y)
-__device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask)
+// lrun: the group's 256-entry table of m3_longest_run in LDS (one read instead of a data-dependent loop)
+__device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask, const unsigned char *lrun)
 {
     int best = 0;
     for (int i1 = 0; i1 < W; ++i1) {
@@ -124,11 +129,22 @@ __device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask)
         for (int i2 = i1; i2 < W; ++i2) {
             acc &= (unsigned)(fm >> (i2 * L)) & lmask;
             if (!acc) break;
-            best = max(best, (i2 - i1 + 1) * m3_longest_run(acc));
+            if ((i2 - i1 + 1) * __popc(acc) <= best) continue;      // cannot beat the best even if contiguous
+            best = max(best, (i2 - i1 + 1) * (int)lrun[acc]);
         }
     }
     return best;
 }
+
+// -DTAP_PROF: shader-clock deltas per phase of the group in lanes 0..G-1 of each workgroup's first wave
+#ifdef TAP_PROF
+static __device__ unsigned int tap_prof_m3[8192 * 8];
+#define M3_PROF(i) do { const long long t_ = clock64(); if (cell == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 8192) tap_prof_m3[blockIdx.x * 8 + (i)] = (unsigned)(t_ - tp_); tp_ = t_; } while (0)
+#define M3_PROF_BEGIN long long tp_ = clock64()
+#else
+#define M3_PROF(i) do { } while (0)
+#define M3_PROF_BEGIN do { } while (0)
+#endif
 
 // One placement.  Preconditions: S.hm[cell] = hm, S.occ[cell] = occ (x-major cells, 0 beyond W*L),
 // S.hist[0..8*cnt.count) filled, visible to the group (wave-level sync by the caller).  do_step is
@@ -141,6 +157,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     const int W = c.W, L = c.L, H = c.H, cells = W * L;
     Placement res = {0, 0, 0, 0, 0};
     if (!do_step) return res;
+    M3_PROF_BEGIN;
     const int hard = c.flags & TAP_F_HARD;
     const int vol = bx * by * bz, step = cnt.count;
     typedef typename m3_mask<G>::type mk;                // masks over cells / positions
@@ -229,11 +246,13 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             }
         }
     }
+    M3_PROF(0);
     // (b) spaces next to and on top of the blocks placed so far (tools.py:2843-2942); a block that
     //     could not be placed sits at (0,0,0) in `positions` and is visited all the same
     for (int bi = 0; bi < step; ++bi) {
-        const int *hb = S.hist + bi * MACS3_HIST;
-        const int x = hb[0], y = hb[1], z = hb[2], xx = hb[3], yy = hb[4], zz = hb[5];
+        const int2 hb = reinterpret_cast<const int2 *>(S.hist)[bi];                  // one 8-byte LDS read
+        const int x = hb.x & 15, y = (hb.x >> 4) & 15, xx = (hb.x >> 8) & 15, yy = (hb.x >> 12) & 15;
+        const int z = hb.y & 0xffff, zz = hb.y >> 16;
         const int xe = x + xx - 1;
         const mk T = levelT(z);
         const unsigned spanx = m3_bits(x, xe);
@@ -302,9 +321,11 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                 // voxel value at level t under this lane's (tx, ty): block index, -1 below a block, 0 free
                 int id = inT ? (hmT > t ? -1 : 0) : 0;
                 for (int k = 0; k < step; ++k) {
-                    const int *hk = S.hist + k * MACS3_HIST;
-                    if (hk[6] && tx >= hk[0] && tx < hk[0] + hk[3] && ty >= hk[1] && ty < hk[1] + hk[4] &&
-                        t >= hk[2] && t < hk[2] + hk[5]) id = k + 1;
+                    const int2 hk = reinterpret_cast<const int2 *>(S.hist)[k];
+                    const int kz = hk.y & 0xffff;
+                    if (!((hk.x >> 16) & 1) || t < kz || t >= kz + (hk.y >> 16)) continue; // group-uniform: not at level t
+                    const int kx = hk.x & 15, ky = (hk.x >> 4) & 15;
+                    if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) id = k + 1;
                 }
                 const int idl = __shfl(id, (wl + 63) & 63);                          // the cell at x-1 (same row)
                 const mk EQ = (mk)ballot_g<G>(inT && tx > 0 && id == idl, gl0);
@@ -317,26 +338,40 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                     for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((y + j) * W + x + i)) & 1);
                     return eq;
                 };
-                for (int i = 0; i < xx; ++i)                                         // :2924-2942
-                    for (int j = 0; j < yy; ++j) {
-                        const int hv = hist(i, j);
-                        if (hv == 0) continue;
-                        if (j > 0 && hv == hist(i, j - 1)) continue;
-                        if (i > 0 && rows_equal(i, j, yy)) continue;                 // :2928
+                // :2924-2942.  The reference scans the footprint cell by cell; whether cell (i, j) yields a
+                // space, and which, depends on the cell alone, so the cells are evaluated one per lane; the
+                // sequential part that remains is the order of the list (cells in (i, j) order) and its
+                // "not already in the list" test, done with a ballot and a prefix count.
+                int want = -1;
+                if (cell < xx * yy) {
+                    const int i = cell / yy, j = cell - i * yy;
+                    const int hv = hist(i, j);
+                    bool ok = hv != 0 && !(j > 0 && hv == hist(i, j - 1)) && !(i > 0 && rows_equal(i, j, yy)); // :2926-2928
+                    if (ok) {
                         const int i2 = i + hv - 1;
                         int j2, j1;
                         for (j2 = j;; ++j2) { if (j2 == yy - 1) break; if (hist(i, j2 + 1) < hv) break; }
-                        if (i > 0 && rows_equal(i, j, j2)) continue;                 // :2934 (empty range is "equal")
+                        ok = !(i > 0 && rows_equal(i, j, j2));                       // :2934 (empty range is "equal")
                         for (j1 = j;; --j1) { if (j1 == 0) break; if (hist(i, j1 - 1) < hv) break; }
-                        const int want = M3_PACK(x + i, y + j1, z, x + i2, y + j2);  // :2940 (sic: level z, not z+zz)
-                        int dup = 0;
-                        for (int k = cell; k < n_ems; k += G) dup |= S.ems[k] == want;
-                        if (!group_or<G>(dup)) M3_PUSH(x + i, y + j1, z, x + i2, y + j2);
+                        if (ok) want = M3_PACK(x + i, y + j1, z, x + i2, y + j2);    // :2940 (sic: level z, not z+zz)
                     }
+                }
+                S.ord[cell] = want;                                                  // scratch until phase 2
+                tap_wave_lds_sync();
+                bool dup = false;                                                    // no early exit: loads pipeline
+                for (int k = 0; k < n_ems; ++k) dup |= S.ems[k] == want;             // :2941 not in ems_list ...
+                for (int k = 0; k < xx * yy; ++k) dup |= k < cell && S.ord[k] == want; // ... nor added by an earlier cell
+                const bool push = want >= 0 && !dup;
+                const mk pm = (mk)ballot_g<G>(push, gl0);
+                const int at = n_ems + m3_popc((mk)(pm & (((mk)1 << cell) - 1)));
+                if (push) { if (at < MACS3_EMS_CAP) S.ems[at] = want; else err |= 16; }
+                n_ems = min(MACS3_EMS_CAP, n_ems + m3_popc(pm));
+                tap_wave_lds_sync();                                                 // entries written by other lanes
             }
         }
     }
 
+    M3_PROF(1);
     // ---- phase 2: the four corner walks of every EMS (tools.py:3080-3115) -------------------------
     // this lane's position (tx, ty): it can only settle at Z = max height under the footprint
     const bool posv = inT && tx + bx <= W && ty + by <= L;
@@ -406,6 +441,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     const int ord = S.ord[cell];
     const bool settled = ord >= 0;
 
+    M3_PROF(2);
     // ---- phase 3: score (tools.py:2973-2987), every settled position by its own lane --------------
     const int valid2 = cnt.valid + vol;
     const bool tiebreak = (c.flags & TAP_F_MCS_TIE) != 0, zero = (c.flags & TAP_F_MCS_ZERO) != 0;
@@ -426,6 +462,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, G));
     int win = -1; // y-major position of the winner
+    M3_PROF(5);
     if (n_slots > 0) {
         const mk tied = (mk)ballot_g<G>(settled && r == rmax, gl0);
         const int nt = zero ? 4 * n_ems : m3_popc(tied); // len(best_ems_indexes), unsettled entries are 0.0
@@ -451,8 +488,9 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                 if (nxt == INT_MAX) break;
                 h = nxt;
             }
-            for (int k = cell; k < nl; k += G) S.lvr[k] = m3_maxrect(S.lvm[k], W, L, lmask);
+            for (int k = cell; k < nl; k += G) S.lvr[k] = m3_maxrect(S.lvm[k], W, L, lmask, S.lrun);
             tap_wave_lds_sync();
+            M3_PROF(6);
             int adj = INT_MIN;
             if (settled && r == rmax) {
                 const int Zt = mp + bz, M = max(gmax, Zt);
@@ -466,11 +504,12 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                     const u64 fm = S.lvm[k];
                     const int a_hi = min(hi, Zt), b_lo = max(lo, Zt);
                     if (a_hi > lo)                                                   // below the block's top
-                        base += (a_hi - lo) * ((fm & footm) ? m3_maxrect(fm & ~footm, W, L, lmask) : S.lvr[k]);
+                        base += (a_hi - lo) * ((fm & footm) ? m3_maxrect(fm & ~footm, W, L, lmask, S.lrun) : S.lvr[k]);
                     if (hi > b_lo) base += (hi - b_lo) * S.lvr[k];
                 }
                 adj = base - M * cells;
             }
+            M3_PROF(7);
             int best_ord = (settled && r == rmax) ? ord : INT_MAX;
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) { // lexicographic (adj desc, order asc)
@@ -481,6 +520,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         }
     }
 
+    M3_PROF(3);
     // ---- commit (tools.py:3150-3163) -----------------------------------------------------------------
     if (win >= 0) {
         const int Z = __shfl(mp, gl0 + win), stab = __shfl(stab_p, gl0 + win), emp = __shfl(emp_p, gl0 + win);
@@ -517,6 +557,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         if (Z + bz > H) err |= 1;                                                    // level_free_space[zz] IndexError
     }
     cnt.count += 1;
+    M3_PROF(4);
 #undef M3_PACK
 #undef M3_PUSH
 #undef M3_EXT_UP
@@ -570,12 +611,15 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > Ld)) { err |= 4; do_step = false; }
 
     S.hm[cell] = hm;
-    if (ev) // one round trip for the whole placement history
-        for (int k = cell; k < cnt.count * 6 && k < a.d.n_max * 6; k += G) {
-            const int i = k / 6, f = k - i * 6;
-            const int v = (f < 3 ? a.v.pos : a.v.blk)[(size_t)(i * 3 + (f < 3 ? f : f - 3)) * B + env];
-            S.hist[i * MACS3_HIST + f] = f == 3 ? (v & 0xffff) : v;
-            if (f == 3) S.hist[i * MACS3_HIST + 6] = v >> 16; // placed flag rides on the x size
+    for (int k = cell; k < 256; k += G) S.lrun[k] = (unsigned char)m3_longest_run((unsigned)k);
+    if (ev) // one round trip for the whole placement history: lane i packs entry i
+        for (int i = cell; i < cnt.count && i < a.d.n_max; i += G) {
+            int f[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) f[q] = (q < 3 ? a.v.pos : a.v.blk)[(size_t)(i * 3 + (q < 3 ? q : q - 3)) * B + env];
+            // the placed flag rides on bit 16 of the stored x size
+            S.hist[i * MACS3_HIST] = (f[0] & 15) | ((f[1] & 15) << 4) | ((f[3] & 15) << 8) | ((f[4] & 15) << 12) | (((f[3] >> 16) & 1) << 16);
+            S.hist[i * MACS3_HIST + 1] = (f[2] & 0xffff) | (f[5] << 16);
         }
     tap_wave_lds_sync();
     const int step = cnt.count;
