@@ -175,9 +175,25 @@ __device__ __forceinline__ int pyset_probe_mask(u64 occ, int mask, int key)
 
 __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsigned char *order, int lane)
 {
+    const int mykey = lane < n ? (int)keys[lane] : 0;   // one LDS read; the loops then read lanes, not memory
+    {
+        // Fast path.  Small ints hash to themselves; a key whose home slot (key & mask) is free goes
+        // there, and a key is only ever displaced by a key that shares its home.  So when all keys
+        // have distinct homes in the FINAL table (its size depends on n alone), every key sits at its
+        // home whatever the insertion and resize history was, and the iteration order is the order of
+        // the homes.  Only sets with two keys congruent modulo the table size need the emulation.
+        int fsize = 8;
+        for (int f = 1; f <= n; ++f)
+            if (f * 5 >= (fsize - 1) * 3) { int ns = 8; while (ns <= f * 4) ns <<= 1; fsize = ns; }
+        u64 homes = 0;
+        for (int k = 0; k < n; ++k) homes |= 1ull << (__builtin_amdgcn_readlane(mykey, k) & (fsize - 1));
+        if (__popcll(homes) == n) {
+            if (lane < n) order[__popcll(homes & ((1ull << (mykey & (fsize - 1))) - 1ull))] = (unsigned char)mykey;
+            return;
+        }
+    }
     int val = -1, size = 8, fill = 0;
     u64 occ = 0;
-    const int mykey = lane < n ? (int)keys[lane] : 0;   // one LDS read; the loop then reads lanes, not memory
     for (int k = 0; k < n; ++k) {
         // the table state is wave-uniform: say so, and the probe arithmetic runs on the scalar unit
         const int key = __builtin_amdgcn_readlane(mykey, k);
