@@ -178,7 +178,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
             const int want = (x & 0xff) | (((x + xx - 1) & 0xff) << 8) | (tz << 16);
             int dup = 0;                                                      // :2538
             for (int k = cell; k < n_ems; k += G) dup |= L.ems[k] == want;
-            if (!group_or<G>(dup)) EMS_PUSH(x, tz, x + xx - 1);
+            if (!((__ballot(dup != 0) >> gl0) & gmask)) EMS_PUSH(x, tz, x + xx - 1); // one ballot, no shuffle chain
         } else {
             if (x + xx - 1 >= W) { err |= 8; continue; }                      // reference: IndexError :2550
             if (((fr >> x) & 1u) && x > 0 && ((fr >> (x - 1)) & 1u)) {        // :2543-2548 left part

@@ -316,7 +316,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                 const int want = M3_PACK(x, y, t, xe, y + yy - 1);
                 int dup = 0;
                 for (int k = cell; k < n_ems; k += G) dup |= S.ems[k] == want;
-                if (!group_or<G>(dup)) M3_PUSH(x, y, t, xe, y + yy - 1);
+                if (!ballot_g<G>(dup != 0, gl0)) M3_PUSH(x, y, t, xe, y + yy - 1);   // one ballot, no shuffle chain
             } else {
                 // voxel value at level t under this lane's (tx, ty): block index, -1 below a block, 0 free
                 int id = inT ? (hmT > t ? -1 : 0) : 0;
