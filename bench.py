@@ -611,6 +611,19 @@ def main():
                 except Exception as ex:  # out of memory at the top end is fine
                     print("sweep B=%d failed: %s" % (b, ex), file=sys.stderr)
                     break
+        cb = out.get("cpu_baseline")
+        rp = os.path.join(ROOT, "profiles", "r01d_reference_cpu.jsonl")
+        if cb and os.path.exists(rp):
+            # the reference's own Python path cannot run on the GPU box; scripts/time_reference.py measured, in
+            # the build container, how much slower it is than the oracle on the same core and the same work
+            key = {"c2": "c1/c2", "c3": "c3", "c4": "c4"}.get(args.config)
+            for line in open(rp):
+                r = json.loads(line)
+                if r.get("config") == key:
+                    cb["reference_derived"] = dict(
+                        value=cb["value"] / r["ratio_oracle_over_reference"], unit="env-steps/s", cores=1,
+                        how="this oracle figure / %.0f (reference vs oracle on one core of the build container, "
+                            "profiles/r01d_reference_cpu.jsonl); derived, not measured here" % r["ratio_oracle_over_reference"])
         print(json.dumps(out))
     tdist.barrier()
     if world > 1:
