@@ -160,6 +160,7 @@ extern "C" int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, v
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
     TAP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, tap_env_layout(d, nullptr, nullptr), (hipStream_t)stream));
     return TAP_OK;
@@ -213,6 +214,7 @@ static int step_common(tap_ctx *ctx, const tap_env_desc *d, void *state, StepArg
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
     a.d = *d;
     tap_env_layout(d, state, &a.v);
@@ -226,6 +228,7 @@ extern "C" int tap_env_step(tap_ctx *ctx, const tap_env_desc *d, void *state, co
                             int blocks_dtype, const uint8_t *active, float *feature_out,
                             void *stream)
 {
+    if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     if (!blocks) return tap_fail(ctx, TAP_E_INVALID, "null blocks");
     if (blocks_dtype != TAP_DT_F32 && blocks_dtype != TAP_DT_I32)
         return tap_fail(ctx, TAP_E_INVALID, "bad blocks_dtype %d", blocks_dtype);
@@ -239,6 +242,7 @@ extern "C" int tap_env_step_gather(tap_ctx *ctx, const tap_env_desc *d, void *st
                                    const int64_t *ptr, const uint8_t *active, float *feature_out,
                                    void *stream)
 {
+    if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     if (!static_ || !ptr || !d || static_rows < 1 + d->D || nR < 1)
         return tap_fail(ctx, TAP_E_INVALID, "bad gather arguments");
     StepArgs a = {};
@@ -285,6 +289,7 @@ extern "C" int tap_env_feature(tap_ctx *ctx, const tap_env_desc *d, const void *
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state || !feature_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
@@ -319,6 +324,7 @@ extern "C" int tap_env_ratio(tap_ctx *ctx, const tap_env_desc *d, const void *st
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
@@ -350,6 +356,7 @@ extern "C" int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *s
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
@@ -366,6 +373,7 @@ extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *st
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
@@ -472,6 +480,7 @@ extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, in
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (B == 0) return TAP_OK; // an empty batch has no buffers to check (d->B is ignored here)
     if (d->strategy != TAP_LB_GREEDY)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
     if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
@@ -486,6 +495,7 @@ extern "C" int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (B == 0) return TAP_OK; // an empty batch has no buffers to check (d->B is ignored here)
     if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY only");
     if (!blocks || B < 0 || n < 1) return tap_fail(ctx, TAP_E_INVALID, "bad pack_blocks arguments");
     EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, score64_out};

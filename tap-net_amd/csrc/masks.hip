@@ -116,6 +116,7 @@ extern "C" int tap_dyn_colsum(tap_ctx *ctx, int B, int n, int nR, int rows, cons
 {
     int rc = check_shape(ctx, B, n, nR, rows);
     if (rc) return rc;
+    if (B == 0) return TAP_OK;
     if (!dynamic || !colsum_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     const int grid = (B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
@@ -129,6 +130,7 @@ extern "C" int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *
                             unsigned long long *bits_out, int32_t *nonbinary_out, void *stream)
 {
     if (B < 0 || nR < 1 || rows < 1) return tap_fail(ctx, TAP_E_INVALID, "bad shape B=%d nR=%d rows=%d", B, nR, rows);
+    if (B == 0) return TAP_OK;
     if (rows > 64) return tap_fail(ctx, TAP_E_UNSUPPORTED, "the bit shadow holds at most 64 rows (rows=%d)", rows);
     if (!dynamic || !bits_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     const int grid = (B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
@@ -146,6 +148,7 @@ extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, i
 {
     int rc = check_shape(ctx, B, n, n * R, rows);
     if (rc) return rc;
+    if (B == 0) return TAP_OK;
     if (!bits_in || !static_ || !ptr || static_rows < 1 || update_rows < 0 || update_rows > 3 ||
         bits_in == bits_out || (!bits_out && !dyn_out && !current_out && !mask_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_bits arguments");
@@ -163,6 +166,7 @@ extern "C" int tap_update_dynamic(tap_ctx *ctx, int B, int n, int nR, int rows, 
 {
     int rc = check_shape(ctx, B, n, nR, rows);
     if (rc) return rc;
+    if (B == 0) return TAP_OK;
     if (!dyn_in || !static_ || !ptr || !dyn_out || static_rows < 1 || update_rows < 0 || update_rows > 3)
         return tap_fail(ctx, TAP_E_INVALID, "bad update_dynamic arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "update_dynamic is out of place (pack.py:370)");
@@ -178,6 +182,7 @@ extern "C" int tap_update_mask(tap_ctx *ctx, int B, int n, int R, const float *m
                                float *mask_out, void *stream)
 {
     if (B < 0 || n < 1 || R < 1) return tap_fail(ctx, TAP_E_INVALID, "bad mask shape");
+    if (B == 0) return TAP_OK;
     if (!colsum || (!current_out && !mask_out)) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     if (ptr && !mask_in) return tap_fail(ctx, TAP_E_INVALID, "update_mask needs mask_in");
     MaskArgs a = {B, n, R, n * R, 3 * n, 0, 0, nullptr, nullptr, nullptr, ptr, mask_in, colsum,
@@ -193,6 +198,7 @@ extern "C" int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int up
 {
     int rc = check_shape(ctx, B, n, n * R, rows);
     if (rc) return rc;
+    if (B == 0) return TAP_OK;
     if (!dyn_in || !static_ || !ptr || !mask_in || !colsum_in || !dyn_out || !colsum_out ||
         !current_out || !mask_out || static_rows < 1 || update_rows < 0 || update_rows > 3)
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step arguments");

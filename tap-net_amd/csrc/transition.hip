@@ -267,6 +267,7 @@ static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, i
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
     if (!state || !static_ || !ptr || !mask_in || !current_out || !mask_out || n < 1 || R < 1 || rows < 1 ||
         static_rows < 1 + d->D || update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
@@ -288,6 +289,7 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
                               float *current_out, float *mask_out, float *feature_out,
                               float *ratio_out, int flags, void *stream)
 {
+    if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     TransArgs a = {};
     int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
                                current_out, mask_out, feature_out, ratio_out, flags, a);
@@ -307,6 +309,7 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
                                    float *mask_out, float *feature_out, float *ratio_out, int flags,
                                    void *stream)
 {
+    if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     TransArgs a = {};
     int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
                                current_out, mask_out, feature_out, ratio_out, flags, a);
