@@ -390,7 +390,7 @@ extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *st
     if (n_bad_out) *n_bad_out = bad;
     if (bits & 1) return tap_fail(ctx, TAP_E_OVERFLOW, "%d container(s) exceeded height H=%d", bad, d->H);
     if (bits & 2) return tap_fail(ctx, TAP_E_STEPS, "%d container(s) stepped more than blocks_num=%d times", bad, d->n_max);
-    if (bits & 4) return tap_fail(ctx, TAP_E_INVALID, "%d container(s) were given a block side < 1", bad);
+    if (bits & 4) return tap_fail(ctx, TAP_E_INVALID, "%d container(s) were given a block side < 1 or a column index outside [0, nR)", bad);
     return TAP_OK;
 }
 
@@ -426,9 +426,13 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
     for (int t = 0; t < n; ++t) {
         int dims[3] = {1, 1, 1};
         if (ev && a.static_) { // pack.py:441-444 gather by tour, :454-455 rows 1..D, tools.py:2415 astype('int')
-            const long p = (long)a.tour[(size_t)env * n + t];
-            for (int k = 0; k < D; ++k)
-                dims[k] = (int)a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
+            bool badp;
+            const long p = tap_col((long)a.tour[(size_t)env * n + t], a.nR, badp);
+            if (badp) err |= 4;                                   // the reference's gather raises
+            for (int k = 0; k < D; ++k) {
+                const float v = a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
+                dims[k] = badp ? 0 : (int)v;
+            }
         } else if (ev) {
             for (int k = 0; k < D; ++k) dims[k] = a.blocks[((size_t)env * n + t) * D + k];
         }

@@ -22,9 +22,12 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_step(StepArgs a)
     bool act = ev;
     if (ev) {
         if (a.static_) {
-            const long p = (long)a.ptr[env];
-            bx = (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
-            bz = (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+            bool badp;
+            const long p = tap_col((long)a.ptr[env], a.nR, badp);
+            const float vx = a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+            const float vz = a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+            bx = badp ? 0 : (int)vx;
+            bz = badp ? 0 : (int)vz;
         } else if (a.blocks_dtype == TAP_DT_F32) {
             bx = (int)((const float *)a.blocks)[(size_t)env * 2];
             bz = (int)((const float *)a.blocks)[(size_t)env * 2 + 1];

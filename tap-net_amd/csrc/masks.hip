@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     }
     const int nR = a.nR;
     const size_t slab = (size_t)a.rows * nR;
-    const long p = a.ptr ? (long)a.ptr[env] : 0;
+    bool badp = false;
+    const long p = a.ptr ? tap_col((long)a.ptr[env], nR, badp) : 0;
     // pack.py:339: block id read from row 0 of `static` as float -> long
     const long real = (a.ptr && a.static_) ? (long)a.static_[(size_t)env * a.static_rows * nR + p] : -1;
     if (a.dyn_out) {

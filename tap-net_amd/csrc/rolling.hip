@@ -280,7 +280,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
     if (a.remove_ptr) {
         long slot = (long)uniform64((u64)a.remove_ptr[inst]);
-        while (slot >= child) slot -= child;
+        slot = tap_mod_col(slot, child, nRc);                        // rolling.py:632-633
         const bool hit = (window & bit) && __popcll(window & below) == slot;
         window &= ~__ballot(hit);
     }

@@ -45,6 +45,16 @@ inline int tap_fail(tap_ctx *ctx, int code, const char *fmt, ...)
 
 constexpr int TAP_BLOCK = 256; // threads per workgroup (4 wave64)
 
+// A column index handed in by the caller (ptr / tour).  The reference raises IndexError for a value
+// outside [0, nR); here it must never become an out-of-bounds read: the index is replaced by column 0
+// and `bad` makes the caller flag the step (error bit 4, "bad block").
+__device__ __forceinline__ long tap_col(long p, int nR, bool &bad)
+{
+    bad = p < 0 || p >= nR;
+    return bad ? 0 : p;
+}
+
+
 // ---- state blob layout -------------------------------------------------------------------
 // hm      int32 [B][cells]        height-map, env-major (a lane group reads one env's row)
 // cnt     int32 [B][4]            valid_size, empty_size, sum(stable), current_blocks_num

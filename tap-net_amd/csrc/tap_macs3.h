@@ -590,10 +590,14 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     bool act = ev;
     if (ev) {
         if (a.static_) {
-            const long p = (long)a.ptr[env];
-            bx = (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
-            by = (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
-            bz = (int)a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
+            bool badp;
+            const long p = tap_col((long)a.ptr[env], a.nR, badp);
+            const float vx = a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+            const float vy = a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+            const float vz = a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
+            bx = badp ? 0 : (int)vx;
+            by = badp ? 0 : (int)vy;
+            bz = badp ? 0 : (int)vz;
         } else if (a.blocks_dtype == TAP_DT_F32) {
             const float *b = (const float *)a.blocks + (size_t)env * 3;
             bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];

@@ -38,6 +38,16 @@ __device__ __forceinline__ float bit_as_float(unsigned long long w, int r)
     return (float)((half >> (r & 31)) & 1u);
 }
 
+// `while ptr >= n: ptr -= n` (pack.py:314-316) for a caller-provided column index: a valid index
+// (< nR = n*R) needs at most R - 1 subtractions; an invalid one (the reference raises) is mapped to
+// column 0 first instead of looping 2^60 times
+__device__ __forceinline__ long tap_mod_col(long p, int n, int nR)
+{
+    if ((unsigned long)p >= (unsigned long)nR) p = 0;
+    while (p >= n) p -= n;
+    return p;
+}
+
 // mask math for one column: pack.py:318-329
 __device__ __forceinline__ void mask_column(const MaskArgs &a, int env, int j, long real_m,
                                             float move, float small, float large)
@@ -80,7 +90,7 @@ __device__ __forceinline__ void mask_env(const MaskArgs &a, int env, int lane, l
     const int nR = a.nR;
     const size_t slab = (size_t)a.rows * nR;
     long real_m = p;
-    while (real_m >= a.n) real_m -= a.n;                          // pack.py:314-316
+    real_m = tap_mod_col(real_m, a.n, a.nR);                       // pack.py:314-316
     for (int j = lane; j < nR; j += 64) {
         float sum[3], row[3];
 #pragma unroll
@@ -186,7 +196,7 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
         if (!on[k]) continue;
         const int env = senv0 + k;
         long real_m = p[k];
-        while (real_m >= a.n) real_m -= a.n;                                  // pack.py:314-316
+        real_m = tap_mod_col(real_m, a.n, a.nR);                               // pack.py:314-316
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
@@ -278,7 +288,7 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
             }
         }
         long real_m = p[k];
-        while (real_m >= a.n) real_m -= a.n;                                  // pack.py:314-316
+        real_m = tap_mod_col(real_m, a.n, a.nR);                               // pack.py:314-316
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;

@@ -25,9 +25,12 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
             if (cell < 4) cv = s.v.cnt[(size_t)env * 4 + cell];
         }
         if (s.static_) { // gather of model.py:404-412
-            const long p = (long)s.ptr[env];
-            for (int k = 0; k < D; ++k)
-                dims[k] = (int)s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
+            bool badp;
+            const long p = tap_col((long)s.ptr[env], s.nR, badp);
+            for (int k = 0; k < D; ++k) { // unconditional load of a valid column, then the select
+                const float v = s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
+                dims[k] = badp ? 0 : (int)v;
+            }
         } else if (s.blocks_dtype == TAP_DT_F32) { // block.astype(int), tools.py:3689
             for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)s.blocks)[(size_t)env * D + k];
         } else {

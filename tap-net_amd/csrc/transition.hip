@@ -48,7 +48,8 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
     for (int k = 0; k < SPW; ++k) {
         if (!on[k]) continue;
         const int senv = senv0 + k;
-        const long p = (long)m.ptr[senv];
+        bool badp;
+        const long p = tap_col((long)m.ptr[senv], m.nR, badp);
         const long real = (long)m.static_[(size_t)senv * m.static_rows * m.nR + p]; // pack.py:339
         const ClearRanges cr = clear_ranges(m, real);
         const float *src = m.dyn_in + (size_t)senv * slab;
@@ -122,9 +123,12 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
             if (incell) hm = a.s.v.hm[(size_t)env * W + cell];
             if (cell < 4) cv = a.s.v.cnt[(size_t)env * 4 + cell];
         }
-        const long p = (long)a.s.ptr[env];
-        bx = (int)a.s.static_[((size_t)env * a.s.static_rows + 1) * a.s.nR + p];
-        bz = (int)a.s.static_[((size_t)env * a.s.static_rows + 2) * a.s.nR + p];
+        bool badp;
+        const long p = tap_col((long)a.s.ptr[env], a.s.nR, badp);
+        const float vx = a.s.static_[((size_t)env * a.s.static_rows + 1) * a.s.nR + p];
+        const float vz = a.s.static_[((size_t)env * a.s.static_rows + 2) * a.s.nR + p];
+        bx = badp ? 0 : (int)vx;
+        bz = badp ? 0 : (int)vz;
     }
     Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
     int err = 0;
