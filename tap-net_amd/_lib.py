@@ -140,7 +140,13 @@ def stream_of(device):
 
 
 def ptr(t):
-    return None if t is None else _vp(t.data_ptr())
+    """Device pointer of a tensor for the C ABI.  A host tensor here would hand the kernels a host
+    address (a GPU memory fault, not an exception), so it is refused loudly instead."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise TapError(TAP_E_INVALID, "tensor on %s passed to a device entry point (move it to the GPU first)" % (t.device,))
+    return _vp(t.data_ptr())
 
 
 def make_desc(batch_size, container_size, blocks_num, reward_type, heightmap_type, packing_strategy):
