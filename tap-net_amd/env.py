@@ -67,6 +67,8 @@ class BatchedContainer(object):
         if active is None:
             return None
         a = torch.as_tensor(active, device=self.device)
+        if a.numel() != self.batch_size:
+            raise ValueError("active must have %d entries, got %s" % (self.batch_size, tuple(a.shape)))
         return a.to(torch.uint8).contiguous()
 
     # ---- tools.Container surface, batched ---------------------------------------------------
@@ -102,8 +104,14 @@ class BatchedContainer(object):
         if static.dtype != torch.float32 or not static.is_contiguous() or static.device != self.device:
             static = static.to(device=self.device, dtype=torch.float32).contiguous()
         ptr = ptr.to(device=self.device, dtype=torch.int64).contiguous()
+        if static.dim() != 3 or static.shape[0] != self.batch_size or static.shape[1] < 1 + self.block_dim:
+            raise ValueError("static must be (%d, >= %d, nR), got %s" % (self.batch_size, 1 + self.block_dim, tuple(static.shape)))
+        if tuple(ptr.shape) != (self.batch_size,):
+            raise ValueError("ptr must be (%d,), got %s" % (self.batch_size, tuple(ptr.shape)))
         act = self._as_active(active)
         feat = out if out is not None else (self._new_feature() if want_feature else None)
+        if feat is not None and (tuple(feat.shape) != self._feature_shape() or feat.dtype != torch.float32 or not feat.is_contiguous()):
+            raise ValueError("out must be a contiguous float32 tensor of shape %s" % (self._feature_shape(),))
         self._call(_lib.lib().tap_env_step_gather, _lib.ptr(self._state), _lib.ptr(static),
                    static.shape[1], static.shape[2], _lib.ptr(ptr), _lib.ptr(act), _lib.ptr(feat))
         return feat

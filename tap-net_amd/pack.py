@@ -227,9 +227,17 @@ class MaskStepper(object):
             raise ValueError("dynamic cannot be carried as a bit shadow (needs rows <= 64, nR % 4 == 0, "
                              "nR <= 256 and only 0/1 values)")
 
+    def _check_step_args(self, ptr, dyn_out):
+        if tuple(ptr.shape) != (self.B,):
+            raise ValueError("ptr must be (%d,), got %s" % (self.B, tuple(ptr.shape)))
+        if dyn_out is not None and (dyn_out.shape != self.dynamic.shape or dyn_out.dtype != torch.float32 or
+                                    not dyn_out.is_contiguous() or dyn_out.data_ptr() == self.dynamic.data_ptr()):
+            raise ValueError("dyn_out must be a distinct contiguous float32 tensor of shape %s" % (tuple(self.dynamic.shape),))
+
     def step(self, ptr, dyn_out=None):
         """-> (new_dynamic, current_mask, mask).  ``dyn_out`` lets a caller recycle buffers."""
-        ptr = ptr.to(torch.int64).contiguous()
+        ptr = ptr.to(device=self.dynamic.device, dtype=torch.int64).contiguous()
+        self._check_step_args(ptr, dyn_out)
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
@@ -268,7 +276,8 @@ class EnvTransition(MaskStepper):
     def step(self, ptr, fresh=False, want_ratio=False, want_feature=True, dyn_out=None):
         """-> (new_dynamic, current_mask, mask, feature, ratio)."""
         import ctypes as C
-        ptr = ptr.to(torch.int64).contiguous()
+        ptr = ptr.to(device=self.dynamic.device, dtype=torch.int64).contiguous()
+        self._check_step_args(ptr, dyn_out)
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
