@@ -441,7 +441,7 @@ struct RollStepArgs {
 };
 
 template <int D, int G>
-__global__ void __launch_bounds__((64 * (4 + 4 * G / 64 + (4 * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__((64 * (4 + 4 * G / 64 + (4 * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_rolling_step(RollStepArgs a)
 {
     constexpr int EPB = 4;                                  // instances per workgroup

@@ -170,6 +170,22 @@ __device__ __forceinline__ void tap_scan(const int *s, int L, int x, int y, int 
             if (h > mx) { mx = h; eq = 1ull << i; }
             else if (h == mx) eq |= 1ull << i;
         }
+    } else if (bx <= 4 && by <= 4) {
+        // every RAND block: all (at most 16) LDS reads are issued before the first is used -- the
+        // general loop below waits for each read in turn, which was half of a 3D placement's time
+        int h[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[i][j] = (i < bx && j < by) ? s[(x + i) * L + y + j] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mx = max(mx, h[i][j]); sum += max(h[i][j], 0); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) eq |= (u64)(h[i][j] == mx && i < bx && j < by) << (i * 8 + j);
     } else {
         for (int i = 0; i < bx; ++i)
             for (int j = 0; j < by; ++j) {
