@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the batched Transport-and-Pack environment hot path on MI355X.
 
-One "step" = one full pass of the hot path over one batch of synthetic instances:
-    reset -> n x [ update_dynamic + update_mask (one launch) ; add_new_block (one launch) ]
-          -> calc_ratio (one launch) [-> when N > 1, the (B,) reward vectors of 8 consecutive passes
-             are all-gathered with one RCCL call]
-i.e. what DRL.forward does around its policy network for one batch (model.py:294-515), with the
-actions replayed from a pre-computed feasible tape.  value = env-steps/s = (placements in all
-envs on all ranks) / wall time, inputs resident in HBM before the timed region.
+One "step" = one full pass of the hot path over one batch of synthetic instances, i.e. what
+DRL.forward does around its policy network for one batch (model.py:294-515), with the actions
+replayed from a pre-computed feasible tape:
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5] [--batch B]
-                    [--no-graph] [--no-cpu-baseline] [--sweep]
+    tap_dyn_bits (bit shadow of the instance batch's fp32 `dynamic`, built INSIDE the pass)
+    -> n x tap_transition_bits (update_dynamic + update_mask + gather + add_new_block in one launch;
+       the first starts a fresh container, the last emits calc_ratio)
+    [-> when N > 1, the (B,) reward vectors of 8 consecutive passes are all-gathered with one RCCL call]
 
-For N > 1 launch with torch.distributed.run (one rank per GPU, RCCL); rank 0 prints ONE JSON line.
+value = env-steps/s = (placements in all envs on all ranks) / wall time, inputs resident in HBM before
+the timed region.  After the timed region (outside it) the outputs of the LAST replayed pass are
+compared with the CPU oracle on a slice of the batch ("verified"); a mismatch exits non-zero.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c2|c3|c4|c5|c6|k6] [--batch B]
+                    [--no-graph] [--no-cpu-baseline] [--no-variants] [--sweep [--sweep-out FILE]]
+
+--gpus N > 1: launched by torch.distributed.run (one rank per GPU, RCCL) the ranks find each other
+through RANK / WORLD_SIZE / MASTER_*; launched as plain `python bench.py --gpus N` the script spawns the N
+ranks itself (torch.multiprocessing).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -31,11 +39,12 @@ from tap_net_amd import _lib, synth         # noqa: E402
 from tap_net_amd import dist as tdist       # noqa: E402
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+VERIFY_ENVS = 512        # envs of the last replayed pass compared with the oracle after the timed region
 
 # nodes of one precedence window (rolling.py feeds the actor 10-node sub-graphs)
 WINDOW = {"c5": 10}
 # configs whose pass is rolling.validate's loop: N - 10 one-step windows re-cut from the precedence DAG
-# after every placement (tap_rolling_window + tap_env_step_gather), then a full episode on the last one
+# after every placement, then a full episode on the last one
 ROLLING = {"c5"}
 
 CONFIGS = {
@@ -46,11 +55,14 @@ CONFIGS = {
            3, [5, 5, 50], 10, 4096, "C+P+S-lb-soft", "LB_GREEDY"),
     "c4": ("2D nodes=20 container_width=7 MACS batch=8192 on 1xMI355X (BASELINE configs[3], RAND-marginal blocks)",
            2, [7, 100], 20, 8192, "C+P+S-mcs-soft", "MACS"),
-    "c5": ("3D nodes=50 (5 consecutive 10-node precedence windows) container_width=5x5 H=250 LB_GREEDY "
+    "c5": ("3D MIX nodes=50 (rolling 10-node windows) container_width=5x5 H=250 LB_GREEDY "
            "batch=8192 per GPU (BASELINE configs[4] shard)",
            3, [5, 5, 250], 50, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
     "c6": ("3D RAND nodes=10 container_width=5x5 MACS batch=4096 on 1xMI355X (not a BASELINE config: SURVEY 8(f) f3)",
            3, [5, 5, 50], 10, 4096, "C+P+S-mcs-soft", "MACS"),
+    "k6": ("2D RAND nodes=10 container_width=5 LB_GREEDY batch=8192: whole episode per launch "
+           "(pack.reward / calc_positions_lb_greedy, SURVEY K6; not a BASELINE config)",
+           2, [5, 50], 10, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
 }
 
 
@@ -65,21 +77,32 @@ def algorithmic_bytes(D, cs, n):
     return env, mask
 
 
+def episode_bytes(D, n):
+    """SURVEY.md 8(d), fused full episode (K6): blocks n*D*4 (+ tour n*8) read, pos n*D*4 + stable n + reward 4
+    written -- 254 B per 2D n=10 episode."""
+    return n * D * 4 + n * 8 + n * D * 4 + n + 4
+
+
 class HotPath(object):
     """Pre-allocated buffers + direct C-ABI calls for one rank's share of the batch.
 
     An episode is `windows` consecutive precedence windows of `nw` nodes each over ONE long-lived
-    container per env (windows = 1 except for the rolling-sized config c5)."""
+    container per env (windows = 1 except for --approx-windows)."""
+
+    rolling = False
+    kind = "transition"
 
     def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None, bits=True, instances=None):
         _, D, cs, n, _, reward, strategy = cfg
+        self.cfg = cfg
         self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
+        self.reward_type, self.strategy = reward, strategy
         self.nw = window or n
         assert n % self.nw == 0
         self.windows = n // self.nw
         f32 = dict(dtype=torch.float32, device=device)
         self.instances = instances
-        self.static, self.dynamic0, self.tape, self.cs0, self.bits0 = [], [], [], [], []
+        self.static, self.dynamic0, self.tape, self.cs0 = [], [], [], []
         for w in range(self.windows):
             if instances == "generate":                             # RAND instances of the device-side generator (f1)
                 static, dynamic = synth.device_rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start, device=device)
@@ -92,19 +115,22 @@ class HotPath(object):
             self.static.append(static.to(device))
             self.dynamic0.append(dynamic.to(device))
             self.tape.append(tape.t().contiguous().to(device))  # (nw, B): one contiguous ptr row per step
-            self.cs0.append(T.pack.dynamic_colsum(self.dynamic0[-1], self.nw).clone())
-            # the instance's bit shadow, like its column sums, is dataset-time data (built once per
-            # instance, not per pass); only valid for 0/1 tensors of a supported shape
-            ok = bits and T.pack.bits_supported(self.dynamic0[-1].shape[1], self.dynamic0[-1].shape[2])
-            shadow, bad = T.pack.dynamic_bits(self.dynamic0[-1]) if ok else (None, None)
-            self.bits0.append(shadow if ok and int(bad.item()) == 0 else None)
-        self.bits = all(b is not None for b in self.bits0)
+            self.cs0.append(T.pack.dynamic_colsum(self.dynamic0[-1], self.nw).clone() if not bits else None)
         self.R = self.static[0].shape[2] // self.nw
         self.nR, self.rows = self.static[0].shape[2], self.dynamic0[0].shape[1]
+        # the bit shadow is only valid for 0/1 tensors of a supported shape: checked once here (setup), the
+        # shadow itself is rebuilt from the fp32 tensor inside every pass (episode())
+        self.bits = bool(bits and T.pack.bits_supported(self.rows, self.nR))
+        if self.bits:
+            self.bits = all(int(T.pack.dynamic_bits(d)[1].item()) == 0 for d in self.dynamic0)
+        if not self.bits and self.cs0[0] is None:
+            self.cs0 = [T.pack.dynamic_colsum(d, self.nw).clone() for d in self.dynamic0]
         self.env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=device)
         self.dyn = [torch.empty_like(self.dynamic0[0]), torch.empty_like(self.dynamic0[0])]
-        self.csb = [torch.empty_like(self.cs0[0]), torch.empty_like(self.cs0[0])]
-        self.bitb = [torch.empty_like(self.bits0[0]), torch.empty_like(self.bits0[0])] if self.bits else None
+        self.csb = [torch.empty(B, 3, self.nR, **f32), torch.empty(B, 3, self.nR, **f32)] if not self.bits else [None, None]
+        i64 = dict(dtype=torch.int64, device=device)
+        self.bitb = [torch.empty(B, self.nR, **i64) for _ in range(3)] if self.bits else None
+        self.nonbin = torch.zeros(1, dtype=torch.int32, device=device)
         self.mask0 = torch.ones(B, self.nR, **f32)
         self.maskb = [torch.empty(B, self.nR, **f32), torch.empty(B, self.nR, **f32)]
         self.cur = torch.empty(B, self.nR, **f32)
@@ -122,8 +148,12 @@ class HotPath(object):
         else:
             _lib.check(fn(*args, stream), self.ctx)
 
+    def launches_per_pass(self):
+        per = 1 if self.fused else 2
+        return self.n * per + (self.windows if self.bits else 0) + (0 if self.fused else 2)
+
     def episode(self):
-        """fused: n launches of tap_transition (first FRESH, last emits calc_ratio);
+        """fused: [tap_dyn_bits +] n launches of tap_transition (first FRESH, last emits calc_ratio);
         otherwise reset + n x (tap_mask_step, tap_env_step_gather) + tap_env_ratio."""
         L, P, e = self.lib, _lib.ptr, self.env
         d = C.byref(e.desc)
@@ -133,7 +163,12 @@ class HotPath(object):
         for w in range(self.windows):
             st = self.static[w]
             dyn_in, cs_in, mask_in = self.dynamic0[w], self.cs0[w], self.mask0
-            bits_in = self.bits0[w]
+            bits_in = None
+            if self.bits:
+                # a trainer sees fresh fp32 instances every batch (PACKDataset -> DataLoader): the shadow is
+                # built from the tensor inside the pass (reads rows*nR*4 B per env once per window)
+                bits_in = self.bitb[2]
+                self._k("dyn_bits", L.tap_dyn_bits, self.ctx, self.B, self.nR, self.rows, P(dyn_in), P(bits_in), P(self.nonbin))
             for t in range(self.nw):
                 ptr = self.tape[w][t]
                 o = t & 1
@@ -165,25 +200,125 @@ class HotPath(object):
         if not self.fused:
             self._k("ratio", L.tap_env_ratio, self.ctx, d, P(e._state), P(self.reward), None, None)
 
+    # ---- after the timed region: the state the LAST pass left behind, against the oracle ---------------
+    def verify(self, nenv=VERIFY_ENVS):
+        import oracle_lib as O
+        V = min(nenv, self.B)
+        self.env.check()
+        if self.bits and int(self.nonbin.item()) != 0:
+            return dict(verified=False, why="tap_dyn_bits counted non-binary elements")
+        st = [s[:V].cpu().numpy() for s in self.static]
+        tp = [t[:, :V].t().cpu().numpy() for t in self.tape]       # (V, nw)
+        ar = np.arange(V)
+        blocks = np.concatenate([np.stack([s[ar, 1:, t[:, k]] for k in range(self.nw)], axis=1)
+                                 for s, t in zip(st, tp)], axis=1).astype(np.int32)
+        ref = O.run_episodes(O.make_desc(self.cs, self.n, self.reward_type, "diff", self.strategy), blocks,
+                             nthreads=os.cpu_count() or 1, want_heightmaps=True)
+        if ref["nerr"]:
+            return dict(verified=False, why="the oracle flags %d envs of the slice" % ref["nerr"])
+        bad = []
+        if not np.array_equal(self.reward[:V].cpu().numpy(), ref["ratio"].astype(np.float32)):
+            bad.append("calc_ratio")
+        if not np.array_equal(self.env.positions[:V].cpu().numpy(), ref["positions"]):
+            bad.append("positions")
+        if not np.array_equal(self.env.stable[:V].cpu().numpy().astype(np.uint8), ref["stable"]):
+            bad.append("stable")
+        if not np.array_equal(self.env.heightmap[:V].cpu().numpy().reshape(V, -1), ref["heightmaps"][:, -1]):
+            bad.append("heightmap")
+        if not np.array_equal(self.feat[:V].cpu().numpy().reshape(V, -1).astype(np.int64), ref["features"][:, -1]):
+            bad.append("feature")
+        # precedence tensors of the last window after its last step
+        dyn = self.dynamic0[-1][:V].cpu().numpy()
+        mask = np.ones((V, self.nR), np.float32)
+        cur = None
+        for k in range(self.nw):
+            dyn = O.update_dynamic(dyn, st[-1], tp[-1][:, k], self.nw, 3)
+            cur, mask = O.update_mask(mask, dyn, tp[-1][:, k], self.nw, self.R)
+        o = (self.nw - 1) & 1
+        if not np.array_equal(self.dyn[o][:V].cpu().numpy(), dyn):
+            bad.append("dynamic")
+        if not np.array_equal(self.cur[:V].cpu().numpy(), cur) or not np.array_equal(self.maskb[o][:V].cpu().numpy(), mask):
+            bad.append("masks")
+        out = dict(verified=not bad, envs_checked=V,
+                   what="last replayed pass vs oracle: calc_ratio (fp32, exact), positions, stable, height-map, last "
+                        "feature, final dynamic tensor and both masks")
+        if bad:
+            out["mismatch"] = bad
+        return out
+
+
+class EpisodeHotPath(HotPath):
+    """k6: pack.reward / tools.calc_positions_lb_greedy (pack.py:378-473, tools.py:2393-2449) -- the whole
+    episode of every env in ONE launch (tap_episode_reward), the generators' and the reward seam's shape."""
+
+    kind = "episode"
+
+    def __init__(self, cfg, B, start, device, seed=12345):
+        HotPath.__init__(self, cfg, B, start, device, seed=seed, instances="generate")
+        self.tour = self.tape[0].t().contiguous()             # (B, n)
+        self.pos = torch.empty(B, self.n, self.D, dtype=torch.int32, device=device)
+        self.stab = torch.empty(B, self.n, dtype=torch.uint8, device=device)
+        self.desc = _lib.make_desc(B, self.cs, self.n, self.reward_type, "full", "LB_GREEDY")
+
+    def launches_per_pass(self):
+        return 1
+
+    def episode(self):
+        P, st = _lib.ptr, self.static[0]
+        self._k("episode", self.lib.tap_episode_reward, self.ctx, C.byref(self.desc), self.B, self.n, P(st),
+                st.shape[1], self.nR, P(self.tour), P(self.reward), P(self.pos), P(self.stab))
+
+    def verify(self, nenv=VERIFY_ENVS):
+        import oracle_lib as O
+        V = min(nenv, self.B)
+        st, tour = self.static[0][:V].cpu().numpy(), self.tour[:V].cpu().numpy()
+        nerr, want = O.reward(st, tour, self.reward_type, self.cs[0], self.cs[-1], nthreads=os.cpu_count() or 1)
+        ar = np.arange(V)
+        blocks = np.stack([st[ar, 1:, tour[:, k]] for k in range(self.n)], axis=1).astype(np.int32)
+        ref = O.run_episodes(O.make_desc(self.cs, self.n, self.reward_type, "full", "LB_GREEDY"), blocks,
+                             nthreads=os.cpu_count() or 1, want_heightmaps=False)
+        bad = []
+        if nerr or not np.array_equal(self.reward[:V].cpu().numpy(), want):
+            bad.append("reward")
+        if not np.array_equal(self.pos[:V].cpu().numpy(), ref["positions"]):
+            bad.append("positions")
+        if not np.array_equal(self.stab[:V].cpu().numpy(), ref["stable"]):
+            bad.append("stable")
+        out = dict(verified=not bad, envs_checked=V, what="last pass vs oracle: -(C+P+S) fp32 exact, positions, stable")
+        if bad:
+            out["mismatch"] = bad
+        return out
+
 
 class RollingHotPath(HotPath):
     """c5: true rolling windows over device-generated 50-block instances (initial container
     7x7x250 as scripts/rolling.sh); actions replayed from a tape recorded with a random feasible
     policy."""
 
-    def __init__(self, cfg, B, start, device, seed=12345, window=10, fused_rolling=False, overlap=False):
+    rolling = True
+    kind = "rolling"
+
+    def __init__(self, cfg, B, start, device, seed=12345, window=10, fused_rolling=False, overlap=False, mix=True):
         _, D, cs, n, _, reward, strategy = cfg
+        self.cfg = cfg
         self.overlap = overlap
         self.side = torch.cuda.Stream(device=device)
         self.D, self.cs, self.n, self.B, self.device, self.nw = D, cs, n, B, device, window
-        self.fused, self.hook, self.rolling, self.fused_rolling = True, None, True, fused_rolling
+        self.reward_type, self.strategy = reward, strategy
+        self.fused, self.hook, self.fused_rolling = True, None, fused_rolling
         self.lib, self.ctx = _lib.lib(), _lib.ctx(device)
-        init = [7, 250] if D == 2 else [7, 7, 250]
-        _, _, blocks, positions = T.generate.generate_instances(B, n, D, init[0], init[-1], 1, (1, 5),
-                                                                seed=seed + start, device=device, return_aux=True)
+        self.init = [7, 250] if D == 2 else [7, 7, 250]
+        self.mix = bool(mix and hasattr(T.generate, "generate_mix_instances"))
+        if self.mix:
+            blocks, positions = T.generate.generate_mix_instances(B, n, D, self.init[0], self.init[-1], seed=seed + start,
+                                                                   start=start, device=device)
+        else:
+            _, _, blocks, positions = T.generate.generate_instances(B, n, D, self.init[0], self.init[-1], 1, (1, 5),
+                                                                    seed=seed + start, device=device, return_aux=True)
+        self.blocks_h, self.positions_h = blocks.cpu().numpy(), positions.cpu().numpy()
         g = torch.Generator(device=device)
         g.manual_seed(seed + 1 + start)
-        rec = T.run_rolling_episode(blocks, positions, init,
+        rec = T.run_rolling_episode(blocks, positions, self.init,
                                     lambda current_mask, **_: torch.multinomial(current_mask, 1, generator=g).squeeze(1),
                                     cs[0], cs[-1], child_graph_size=window, reward_type=reward)
         rec["env"].check()
@@ -205,7 +340,11 @@ class RollingHotPath(HotPath):
         self.state = torch.zeros(B, 2, dtype=torch.int64, device=device)
         self.bits = T.pack.bits_supported(self.rows, self.nR)    # the windows' bit shadow (tap_rolling_window emits it)
         self.bitb = [torch.empty(B, self.nR, dtype=torch.int64, device=device) for _ in range(3)] if self.bits else [None] * 3
-        self.want = rec["reward"].clone()
+        self.want = rec["reward"].clone()                        # -calc_ratio of the eager, unfused recording run
+
+    def launches_per_pass(self):
+        per = 1 if self.fused_rolling else 2
+        return 2 + (self.n - self.nw) * per + self.nw
 
     def episode(self):
         L, P, e, rw = self.lib, _lib.ptr, self.env, self.rw
@@ -231,10 +370,7 @@ class RollingHotPath(HotPath):
                         P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
                         P(cs2), P(self.bitb[2]), P(self.cur), None, None)
             else:
-                # placement t (reads window t's static, owns the container state) and window t+1 (owns
-                # the window state, writes the OTHER static buffer) both depend only on the pick of step
-                # t: two HIP streams, so the latency-bound placement runs under the write-bound window
-                # kernel.  window t+1 overwrites the static buffer placement t-1 read: wait for that one.
+                # placement t and window t+1 on two HIP streams (measured slower, kept as an option)
                 main = torch.cuda.current_stream(self.device)
                 self.side.wait_stream(main)
                 with torch.cuda.stream(self.side):
@@ -265,11 +401,58 @@ class RollingHotPath(HotPath):
                         P(self.dyn[o]), P(self.csb[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
             dyn_in, cs_in, mask_in, bits_in = self.dyn[o], self.csb[o], self.maskb[o], self.bitb[o]
 
+    def verify(self, nenv=VERIFY_ENVS):
+        """(1) every env's calc_ratio against the eager two-launch recording run; (2) a slice against the
+        oracle's InitialContainer + Container driven by the same tape: reward, positions, last masks."""
+        import oracle_lib as O
+        self.env.check()
+        bad = []
+        if not torch.equal(self.reward, -self.want):
+            bad.append("calc_ratio vs the eager recording run (%d envs differ)" % int((self.reward != -self.want).sum().item()))
+        V = min(nenv, self.B)
+        tape = self.tape[:, :V].cpu().numpy()                     # (n, V)
+        n, win, R = self.n, self.nw, self.R
+        got_r = self.reward[:V].cpu().numpy()
+        got_pos = self.env.positions[:V].cpu().numpy()
+        got_cur = self.cur[:V].cpu().numpy()
+        got_dyn = self.dyn[(win - 1) & 1][:V].cpu().numpy()
+        nbad = 0
+        for b in range(V):
+            ro = O.Rolling(self.blocks_h[b], self.positions_h[b], self.init, win)
+            e = O.Env(self.cs, n, self.reward_type, "diff", self.strategy)
+            for t in range(n - win):
+                rc, st, dy, _ = ro.convert_to_input()
+                p = int(tape[t, b])
+                e.add_new_block(st[1:, p])
+                ro.remove(p % win)
+            rc, st, dy, _ = ro.convert_to_input()
+            mask, dyn, cur = np.ones((1, win * R), np.float32), dy[None], None
+            for t in range(win):
+                p = np.array([tape[n - win + t, b]], dtype=np.int64)
+                e.add_new_block(st[1:, int(p[0])])
+                dyn = O.update_dynamic(dyn, st[None], p, win, 3)
+                cur, mask = O.update_mask(mask, dyn, p, win, R)
+            ok = (np.float32(e.calc_ratio()) == got_r[b] and np.array_equal(e.positions, got_pos[b]) and
+                  np.array_equal(cur[0], got_cur[b]) and np.array_equal(dyn[0], got_dyn[b]) and e.error == 0)
+            nbad += not ok
+        if nbad:
+            bad.append("%d of %d envs differ from the oracle" % (nbad, V))
+        out = dict(verified=not bad, envs_checked=V, envs_checked_vs_eager=self.B,
+                   what="last replayed pass: calc_ratio of all envs vs the eager unfused run; slice vs the oracle "
+                        "(InitialContainer windows + Container, same tape): calc_ratio, positions, last dynamic and mask")
+        if bad:
+            out["mismatch"] = bad
+        return out
+
 
 GATHER_EVERY = 8   # passes whose (B,) reward vectors share one RCCL all-gather (fewer, larger collectives)
 
 
-def time_passes(hp, steps, warmup, use_graph, world):
+def time_passes(hps, steps, warmup, use_graph, world):
+    """Time `steps` passes, pass i on slot i % len(hps) (one slot = the headline; several = the cold variant)."""
+    if not isinstance(hps, (list, tuple)):
+        hps = [hps]
+    hp = hps[0]
     dev = hp.device
     handles = []
     import torch.distributed as tdd
@@ -278,7 +461,7 @@ def time_passes(hp, steps, warmup, use_graph, world):
     gather = world > 1 or (os.environ.get("TAP_BENCH_FORCE_GATHER") == "1" and tdd.is_available() and tdd.is_initialized())
     nranks = tdd.get_world_size() if gather else 1
     acc = torch.empty(GATHER_EVERY, hp.B, dtype=torch.float32, device=dev) if gather else None
-    state = {"i": 0}
+    state = {"i": 0, "pass": 0}
 
     def flush(count):
         import torch.distributed as dist
@@ -286,13 +469,15 @@ def time_passes(hp, steps, warmup, use_graph, world):
         out = [torch.empty_like(buf) for _ in range(nranks)]
         handles.append((dist.all_gather(out, buf, async_op=True), out))
 
-    def one_pass(g):
-        if g is not None:
-            g.replay()
+    def one_pass(graphs):
+        k = state["pass"] % len(hps)
+        state["pass"] += 1
+        if graphs is not None:
+            graphs[k].replay()
         else:
-            hp.episode()
+            hps[k].episode()
         if gather:
-            acc[state["i"]].copy_(hp.reward)
+            acc[state["i"]].copy_(hps[k].reward)
             state["i"] += 1
             if state["i"] == GATHER_EVERY:
                 flush(GATHER_EVERY)
@@ -306,35 +491,39 @@ def time_passes(hp, steps, warmup, use_graph, world):
             h.wait()
         handles.clear()
 
-    graph = None
+    graphs = None
     if use_graph:
-        s = torch.cuda.Stream(device=dev)
-        s.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(s):
-            hp.episode()                                        # warm the allocator / lazy init
-        torch.cuda.current_stream(dev).wait_stream(s)
-        torch.cuda.synchronize(dev)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            hp.episode()
+        graphs = []
+        for h in hps:
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                h.episode()                                     # warm the allocator / lazy init
+            torch.cuda.current_stream(dev).wait_stream(s)
+            torch.cuda.synchronize(dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                h.episode()
+            graphs.append(g)
     for _ in range(warmup):
-        one_pass(graph)
+        one_pass(graphs)
     drain()
     tdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(steps):
-        one_pass(graph)
+        one_pass(graphs)
     drain()
     torch.cuda.synchronize(dev)
     tdist.barrier()
     dt = time.perf_counter() - t0
-    return tdist.max_over_ranks(dt, dev), graph
+    return tdist.max_over_ranks(dt, dev), graphs
 
 
 def kernel_event_times(hp, steps, graph=None):
     """Per-launch durations with HIP events on the launch stream (torch.cuda.Event on torch's
-    current stream == the stream the kernels are enqueued on), over `steps` eager passes."""
+    current stream == the stream the kernels are enqueued on), over `steps` eager passes.  Every launch
+    is bracketed by its own event pair; the cost of an empty pair is measured next to it."""
     recs = {}
 
     def hook(name, launch):
@@ -346,30 +535,26 @@ def kernel_event_times(hp, steps, graph=None):
         recs.setdefault(name, []).append((a, b))
 
     pass_pairs = []
-    pure = hp.fused and not getattr(hp, 'rolling', False)
-    hp.hook = None if pure else hook
+    hp.hook = hook
     try:
         for _ in range(steps):
-            if pure:
-                # the pass is n back-to-back launches of ONE kernel: bracket the pass and divide, so the
-                # event overhead is amortised and the figure is comparable with rocprofv3's average
-                a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
-                a.record()
-                if graph is not None:
-                    graph.replay()
-                else:
-                    hp.episode()
-                b.record()
-                pass_pairs.append((a, b))
+            hp.episode()
+        torch.cuda.synchronize(hp.device)
+        # whole passes without per-launch events: (pass time) / launches = per-launch time incl. the
+        # inter-kernel gap, free of the event-pair overhead
+        hp.hook = None
+        for _ in range(steps):
+            a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+            a.record()
+            if graph is not None:
+                graph.replay()
             else:
                 hp.episode()
+            b.record()
+            pass_pairs.append((a, b))
         torch.cuda.synchronize(hp.device)
     finally:
         hp.hook = None
-    if pure:
-        us = np.array([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3 / hp.n
-        recs = None
-    # cost of an empty event pair, to show how much of a short kernel's figure is event overhead
     pairs = []
     for _ in range(64):
         a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
@@ -377,110 +562,282 @@ def kernel_event_times(hp, steps, graph=None):
     torch.cuda.synchronize(hp.device)
     empty_us = float(np.median([a.elapsed_time(b) for a, b in pairs]) * 1e3)
     out = {}
-    if recs is None:
-        out["transition"] = dict(launches=len(us) * hp.n, avg_us=float(us.mean()), med_us=float(np.median(us)),
-                                 total_us=float(us.sum() * hp.n))
-        return out, empty_us
     for name, evs in recs.items():
         us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
         out[name] = dict(launches=len(us), avg_us=float(us.mean()), med_us=float(np.median(us)),
                          total_us=float(us.sum()))
-    return out, empty_us
+    pass_us = float(np.median([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3)
+    return out, empty_us, pass_us
 
 
-def cpu_baseline(cfg, window=None, budget_s=12.0, instances=None):
-    """The oracle (C port of the reference algorithm) over the same pass, on the host cores."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
-    _, D, cs, n, B, reward, strategy = cfg
-    B = min(B, 4096)
-    nw = window or n
-    wins = []
-    for w in range(n // nw):
-        if isinstance(instances, tuple) and len(instances) == 3:     # ("given", [static per window], [dynamic per window])
-            static, dynamic = instances[1][w][:B].cpu(), instances[2][w][:B].cpu()
-        elif instances is not None:
-            static, dynamic = synth.tiled_instances(instances[0], instances[1], B)
-        else:
-            static, dynamic = synth.rand_instances(B, nw, D, seed=12345 + 100 * w)
-        tape = synth.random_feasible_tape(static, dynamic, nw, seed=12346 + 100 * w).numpy()
-        wins.append((static.numpy(), dynamic.numpy(), tape))
-    R = wins[0][0].shape[2] // nw
-    blocks = np.concatenate([np.stack([st[np.arange(B), 1:, tape[:, t]] for t in range(nw)], axis=1)
-                             for st, _, tape in wins], axis=1).astype(np.int32)
-    desc = O.make_desc(cs, n, reward, "diff", strategy)
-    O.lib()
+def cpu_info():
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    return model, os.cpu_count() or 1, avail
+
+
+def _timed_loop(fn, budget_s):
     done, t0 = 0, time.perf_counter()
     while True:
+        done += fn()
+        el = time.perf_counter() - t0
+        if el > budget_s:
+            return done, el
+
+
+def cpu_baseline(hp, budget_s=10.0):
+    """The oracle (C port of the reference algorithm) over the same pass -- masks + placements + ratio of the
+    first <= 4096 instances of THIS run -- on one host core, then on all of them (OpenMP over envs)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    B = min(hp.B, 4096)
+    nw, n = hp.nw, hp.n
+    wins = [(s[:B].cpu().numpy(), d[:B].cpu().numpy(), t[:, :B].t().cpu().numpy())
+            for s, d, t in zip(hp.static, hp.dynamic0, hp.tape)]
+    R = hp.R
+    ar = np.arange(B)
+    blocks = np.concatenate([np.stack([st[ar, 1:, tape[:, t]] for t in range(nw)], axis=1)
+                             for st, _, tape in wins], axis=1).astype(np.int32)
+    desc = O.make_desc(hp.cs, n, hp.reward_type, "diff", hp.strategy)
+    O.lib()
+
+    def one(threads):
+        if hp.kind == "episode":
+            nerr, _ = O.reward(wins[0][0], wins[0][2], hp.reward_type, hp.cs[0], hp.cs[-1], nthreads=threads)
+            assert nerr == 0
+            return B * n
         for st, dyn0, tape in wins:
             dyn, mask = dyn0, np.ones((B, st.shape[2]), np.float32)
             O.initial_mask(dyn, nw)
             for t in range(nw):
                 dyn = O.update_dynamic(dyn, st, tape[:, t], nw, 3)
                 _, mask = O.update_mask(mask, dyn, tape[:, t], nw, R)
-        r = O.run_episodes(desc, blocks, nthreads=1, want_heightmaps=False)
+        r = O.run_episodes(desc, blocks, nthreads=threads, want_heightmaps=False)
         assert r["nerr"] == 0
-        done += B * n
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return dict(value=done / el, unit="env-steps/s", cores=1, kind="port",
-                sample="%d passes of B=%d envs x n=%d (masks + placements + ratio), %.1f s, "
-                       "oracle/libtap_oracle.so single thread" % (done // (B * n), B, n, el))
+        return B * n
+
+    model, ncpu, avail = cpu_info()
+    O.set_threads(1)
+    done1, el1 = _timed_loop(lambda: one(1), budget_s)
+    O.set_threads(avail)
+    doneN, elN = _timed_loop(lambda: one(avail), budget_s / 2)
+    O.set_threads(1)
+    what = "whole episodes (pack.reward)" if hp.kind == "episode" else "masks + placements + ratio"
+    return dict(value=done1 / el1, unit="env-steps/s", cores=1, kind="port",
+                sample="%d passes of B=%d envs x n=%d (%s) of this run's instances, %.1f s, "
+                       "oracle/libtap_oracle.so single thread" % (done1 // (B * n), B, n, what, el1),
+                all_cores=dict(value=doneN / elN, cores=avail,
+                               sample="%d passes, %.1f s, OpenMP over envs, %d threads" % (doneN // (B * n), elN, avail)),
+                cpu_model=model, cpu_count=ncpu)
 
 
-def cpu_baseline_rolling(cfg, window, budget_s=12.0):
-    """The oracle over rolling.validate's loop (windows re-cut after every placement), one host core."""
+def cpu_baseline_rolling(hp, budget_s=10.0):
+    """The oracle over rolling.validate's loop (windows re-cut after every placement) on this run's instances
+    and tape: one host core (driven per step from Python), then one process per core."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    _, D, cs, n, B, reward, strategy = cfg
-    init = [7, 250] if D == 2 else [7, 7, 250]
-    rng = np.random.RandomState(1)
-    blocks = synth.rand_blocks(64, n, D, seed=777)
-    inst = []
-    for b in range(64):                      # instances = blocks the oracle's generator restatement accepts
-        rc, pos, _, _ = O.instance_from_blocks(blocks[b], init, 1)
-        if rc == 1:
-            inst.append((blocks[b], pos))
-    done, t0 = 0, time.perf_counter()
-    while True:
-        for bl, pos in inst:
-            ro = O.Rolling(bl, pos, init, window)
-            e = O.Env(cs, n, reward, "diff", strategy)
-            for t in range(n - window + 1):
-                rc, st, dy, nodes = ro.convert_to_input()
-                cur = O.initial_mask(dy[None], window)[0]
-                if t == n - window:
-                    break
-                p = int(rng.choice(np.flatnonzero(cur)))
+    n, win, R = hp.n, hp.nw, hp.R
+    V = min(hp.B, 256)
+    tape = hp.tape[:, :V].cpu().numpy()
+    O.lib()
+
+    def episodes(lo, hi):
+        for b in range(lo, hi):
+            ro = O.Rolling(hp.blocks_h[b], hp.positions_h[b], hp.init, win)
+            e = O.Env(hp.cs, n, hp.reward_type, "diff", hp.strategy)
+            for t in range(n - win):
+                rc, st, dy, _ = ro.convert_to_input()
+                O.initial_mask(dy[None], win)
+                p = int(tape[t, b])
                 e.add_new_block(st[1:, p])
-                ro.remove(p % window)
-            mask = np.ones((1, st.shape[1]), np.float32)
-            dyn = dy[None]
-            for t in range(window):
-                p = np.array([rng.choice(np.flatnonzero(cur))], dtype=np.int64)
+                ro.remove(p % win)
+            rc, st, dy, _ = ro.convert_to_input()
+            mask, dyn = np.ones((1, win * R), np.float32), dy[None]
+            for t in range(win):
+                p = np.array([tape[n - win + t, b]], dtype=np.int64)
                 e.add_new_block(st[1:, int(p[0])])
-                dyn = O.update_dynamic(dyn, st[None], p, window, 3)
-                c2, mask = O.update_mask(mask, dyn, p, window, st.shape[1] // window)
-                cur = c2[0]
+                dyn = O.update_dynamic(dyn, st[None], p, win, 3)
+                _, mask = O.update_mask(mask, dyn, p, win, R)
             e.calc_ratio()
-            done += n
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return dict(value=done / el, unit="env-steps/s", cores=1, kind="port",
-                sample="%d rolling episodes of %d placements (window %d) over %d oracle-generated instances, %.1f s, "
-                       "oracle/libtap_oracle.so single thread driven per step from Python" % (done // n, n, window, len(inst), el))
+        return (hi - lo) * n
+
+    model, ncpu, avail = cpu_info()
+    O.set_threads(1)
+    done1, el1 = _timed_loop(lambda: episodes(0, V), budget_s)
+    # all cores: the per-step driver is Python, so one forked process per core over disjoint slices
+    import multiprocessing as mp
+    t0 = time.perf_counter()
+    per = max(1, V // avail)
+    procs = []
+    ctxm = mp.get_context("fork")
+    for k in range(avail):
+        lo, hi = k * per, min(V, (k + 1) * per)
+        if lo < hi:
+            pr = ctxm.Process(target=episodes, args=(lo, hi))
+            pr.start()
+            procs.append((pr, hi - lo))
+    for pr, _ in procs:
+        pr.join()
+    elN = time.perf_counter() - t0
+    doneN = sum(c for _, c in procs) * n
+    return dict(value=done1 / el1, unit="env-steps/s", cores=1, kind="port",
+                sample="%d rolling episodes of %d placements (window %d) over this run's instances and tape, %.1f s, "
+                       "oracle/libtap_oracle.so single thread driven per step from Python" % (done1 // n, n, win, el1),
+                all_cores=dict(value=doneN / elN, cores=len(procs),
+                               sample="%d episodes, %.1f s, one forked process per core" % (doneN // n, elN)),
+                cpu_model=model, cpu_count=ncpu)
 
 
-def load_traffic(name):
+def attach_reference_cpu(cb, config):
+    """The reference's own Python path cannot run on the GPU box; scripts/time_reference.py measured it in the
+    build container (1 process and 8 processes) next to the oracle on the same work.  First-class fields:
+    reference_value = this box's oracle figure / that ratio (derived), reference_measured = the build
+    container's own figure (measured there)."""
+    for name in ("r02_reference_cpu.jsonl", "r01d_reference_cpu.jsonl"):
+        rp = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(rp):
+            continue
+        key = {"c2": "c1/c2", "k6": "c1/c2", "c3": "c3", "c4": "c4", "c5": "c5"}.get(config)
+        for line in open(rp):
+            r = json.loads(line)
+            if r.get("config") != key or config == "k6":
+                continue
+            ratio = r["ratio_oracle_over_reference"]
+            cb["reference_value"] = cb["value"] / ratio
+            cb["reference_cores"] = 1
+            cb["reference_how"] = ("derived: this box's 1-core oracle figure / %.0f (reference vs oracle on one core of the "
+                                   "build container, profiles/%s)" % (ratio, name))
+            cb["reference_measured"] = dict(
+                where="build container (the only place /root/reference exists)",
+                one_process=r.get("reference_env_steps_per_s"),
+                all_processes=r.get("reference_env_steps_per_s_procs"), processes=r.get("procs"),
+                cpu_model=r.get("cpu_model"), source="profiles/" + name)
+            return
+
+
+def load_traffic(key):
+    """HBM bytes per launch from the PMC passes of the profile set named in the entry (profiles/README.md:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, (2*FETCH + WRITE)*1024)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(p):
         try:
-            return json.load(open(p)).get(name)
+            t = json.load(open(p)).get(key)
         except Exception:
             return None
+        if isinstance(t, dict):
+            return t
+        if t is not None:
+            return dict(bytes=t, profile="r01d (round 1)")
     return None
+
+
+def variants(cfg, args, hp, rank, world, dev, use_graph):
+    """Two more readings of the same workload (single GPU, rank 0's line only)."""
+    name, D, cs, n, B, reward, strategy = cfg
+    out = {}
+    if hp.kind != "transition" or world != 1:
+        return out
+    # (a) cold: rotate over enough instance batches (inputs AND output buffers per slot) that the working set
+    #     exceeds the 256 MB Infinity Cache several times over -- nothing a pass reads is cache-resident
+    per_slot = sum(t.numel() * t.element_size() for t in (hp.dynamic0 + hp.static + hp.dyn + [hp.cur] + hp.maskb))
+    slots = max(3, int(np.ceil(1.2e9 / per_slot)))
+    slots = min(slots, 40)
+    try:
+        hps = [hp] + [HotPath(cfg, B, 0, dev, seed=777 + 1000 * k, fused=hp.fused, window=hp.nw if hp.windows > 1 else None,
+                              bits=hp.bits, instances=hp.instances) for k in range(1, slots)]
+        steps = max(slots * 4, 40)
+        dt, _ = time_passes(hps, steps, slots, use_graph, 1)
+        for h in hps:
+            h.env.check()
+        out["cold"] = dict(value=B * n * steps / dt, unit="env-steps/s", slots=slots,
+                           working_set_MB=round(per_slot * slots / 1e6, 1), steps=steps,
+                           what="pass i runs on instance batch i %% %d, each with its own input and output buffers; the "
+                                "working set is several times the 256 MB Infinity Cache" % slots)
+        del hps
+    except Exception as ex:                                  # pragma: no cover
+        out["cold"] = dict(error=str(ex))
+    # (b) a policy between the steps: rollout.run_episode with RandomFeasiblePolicy (torch.multinomial on
+    #     current_mask), eager launches, fresh output tensors every step -- the loop a trainer would run
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(4242)
+        pol = T.RandomFeasiblePolicy(g)
+        st, dy = hp.static[0], hp.dynamic0[0]
+        cw, ch = cs[0], cs[-1]
+
+        def run():
+            return T.run_episode(st, dy, pol, cw, ch, reward_type=reward, packing_strategy=strategy)
+        for _ in range(3):
+            r = run()
+        torch.cuda.synchronize(dev)
+        steps = 30
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = run()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        r["env"].check()
+        out["policy_in_loop"] = dict(value=B * hp.nw * steps / dt, unit="env-steps/s", steps=steps,
+                                     what="rollout.run_episode, RandomFeasiblePolicy (torch.multinomial on current_mask) "
+                                          "between the fused steps, eager launches, bit shadow built per episode")
+    except Exception as ex:                                  # pragma: no cover
+        out["policy_in_loop"] = dict(error=str(ex))
+    return out
+
+
+def run_sweep(cfg, hp, dev, use_graph, path):
+    name, D, cs, n, B, reward, strategy = cfg
+    env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
+    lines = []
+    for b in (8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304):
+        try:
+            h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev, fused=hp.fused, bits=hp.bits,
+                         instances=None)                 # host-generated synthetic precedence: setup time stays bounded
+            steps = 20 if b <= 131072 else 6
+            d2, g2 = time_passes(h2, steps, 2, use_graph, 1)
+            k2, _, pass_us = kernel_event_times(h2, 3, g2[0] if g2 else None)
+            rec = dict(config=name.split(" on ")[0], batch=b, env_steps_per_s=b * n * steps / d2,
+                       pass_us=pass_us, transition_us=k2["transition"]["avg_us"],
+                       alg_GBps=(env_b + mask_b) * b / (k2["transition"]["avg_us"] * 1e-6) / 1e9,
+                       dynamic_MB=round(h2.dynamic0[0].numel() * 4 / 1e6, 1), bits=bool(h2.bits))
+            lines.append(rec)
+            print("sweep " + json.dumps(rec), file=sys.stderr)
+            del h2, g2
+            torch.cuda.empty_cache()
+        except Exception as ex:  # out of memory at the top end is fine
+            print("sweep B=%d stopped: %s" % (b, ex), file=sys.stderr)
+            break
+    if path:
+        with open(path, "a") as f:
+            for rec in lines:
+                f.write(json.dumps(rec) + "\n")
+    return lines
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawned_rank(rank, argv, world, port):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), TAP_BENCH_SPAWNED="1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.argv = [sys.argv[0]] + list(argv)
+    main()
 
 
 def main():
@@ -493,6 +850,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the cold and policy-in-loop readings")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison after the timed region")
     ap.add_argument("--synthetic-precedence", action="store_true",
                     help="c2/c3: RAND-marginal blocks with a random precedence DAG (synth.rand_instances) instead of "
                          "instances from the device-side RAND generator (blocks packed into the 7-wide initial container)")
@@ -500,20 +859,34 @@ def main():
                     help="c4: RAND-marginal synthetic instances instead of the reference-generated PPSG fixture tiled x128")
     ap.add_argument("--no-bits", action="store_true",
                     help="precedence update as an fp32 copy (tap_transition) instead of on the bit shadow (tap_transition_bits)")
-    ap.add_argument("--sweep", action="store_true", help="also print a batch sweep to stderr")
+    ap.add_argument("--sweep", action="store_true", help="also run a batch sweep (stderr; --sweep-out appends JSON lines)")
+    ap.add_argument("--sweep-out", default=None)
     ap.add_argument("--two-launch-rolling", action="store_true",
                     help="c5: tap_env_step_gather + tap_rolling_window per step instead of the fused tap_rolling_step")
     ap.add_argument("--overlap", action="store_true",
-                    help="c5: placement t and window t+1 on two HIP streams (measured slower on this stack: "
-                         "285 vs 297 M env-steps/s in a graph, 251 vs 299 eager -- the cross-stream waits cost more "
-                         "than the 8.6 us placement they hide)")
+                    help="c5: placement t and window t+1 on two HIP streams (measured slower)")
     ap.add_argument("--approx-windows", action="store_true",
                     help="c5: consecutive independent 10-node windows instead of true rolling windows")
+    ap.add_argument("--rand-only", action="store_true", help="c5: RAND instances only instead of the MIX series")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched as plain `python bench.py --gpus N`: spawn the N ranks here (one process per GPU)
+        shared = os.environ.get("TAP_DIST_BACKEND") == "gloo"    # self-test: ranks may share a GPU
+        have = torch.cuda.device_count()
+        if have < args.gpus and not shared:
+            sys.exit("bench.py --gpus %d: only %d GPU(s) visible (set TAP_DIST_BACKEND=gloo to let ranks share one "
+                     "for a self-test)" % (args.gpus, have))
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned_rank, args=(sys.argv[1:], args.gpus, _free_port()), nprocs=args.gpus, join=True)
+        return
+
     rank, world, local = tdist.init_from_env()
-    if world != args.gpus and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; refusing to report a line for a different job size"
+                  % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libtapenv has no CPU path")
     local = local % torch.cuda.device_count()   # > 1 rank per GPU only happens in the gloo self-test
@@ -527,7 +900,12 @@ def main():
     rolling = args.config in ROLLING and not args.approx_windows
     if rolling:
         hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=not args.two_launch_rolling,
-                            overlap=args.overlap)
+                            overlap=args.overlap, mix=not args.rand_only)
+        if not hp.mix:
+            name = name.replace("3D MIX", "3D RAND")
+            cfg = (name, D, cs, n, B, reward, strategy)
+    elif args.config == "k6":
+        hp = EpisodeHotPath(cfg, B, rank * B, dev)
     else:
         instances = None
         if args.config in ("c2", "c3") and not args.synthetic_precedence:
@@ -542,93 +920,118 @@ def main():
         hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits,
                      instances=instances)
     use_graph = not args.no_graph
-    dt, graph = time_passes(hp, args.steps, args.warmup, use_graph, world)
+    dt, graphs = time_passes(hp, args.steps, args.warmup, use_graph, world)
     hp.env.check()
     total_steps = B * world * n * args.steps
     value = total_steps / dt
+    # every rank checks its own last pass against the oracle; the line says "verified" only if all did
+    ver = dict(verified=None, why="--no-verify") if args.no_verify else hp.verify()
+    ok_all = tdist.max_over_ranks(0.0 if ver.get("verified") in (True, None) else 1.0, dev) == 0.0
 
     out = None
     if rank == 0:
-        kt, empty_us = kernel_event_times(hp, max(3, min(args.steps, 20)), graph if (hp.fused and not rolling) else None)
+        npass = max(3, min(args.steps, 20))
+        kt, empty_us, pass_us = kernel_event_times(hp, npass, graphs[0] if graphs else None)
         env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
         R_ = 2 if D == 2 else 6
         win_b = (1 + D) * hp.nw * R_ * 4 + 3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 4 + 32   # static + dynamic + mask + state
         per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B,
-                      "rolling_window": win_b * B, "rolling_step": (win_b + env_b) * B}
-        names = [k for k in ("transition", "rolling_step", "rolling_window", "mask_step", "env_step", "ratio", "reset") if k in kt]
+                      "rolling_window": win_b * B, "rolling_step": (win_b + env_b) * B,
+                      "episode": episode_bytes(D, n) * B,
+                      "dyn_bits": (3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 8) * B}
+        names = [k for k in ("transition", "rolling_step", "rolling_window", "episode", "mask_step", "env_step", "dyn_bits",
+                             "ratio", "reset") if k in kt]
         dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
-        ach = per_launch[dom] / (kt[dom]["avg_us"] * 1e-6) / 1e9
-        npass = max(3, min(args.steps, 20))
+        # the dominant kernel's duration: (event-bracketed launch) - (an empty event pair); for a pass that is
+        # nothing but that kernel the graph-replayed pass / launches is the cleaner figure (it includes the gap)
+        launches = hp.launches_per_pass()
+        if hp.kind == "transition" and hp.fused:
+            other = sum(max(kt[k]["avg_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
+            dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
+            how = "(graph-replayed pass - the other kernels' event time) / launches; includes the inter-kernel gap"
+        elif hp.kind == "episode":
+            dom_us, how = pass_us, "event-bracketed pass (one launch)"
+        else:
+            dom_us = max(kt[dom]["avg_us"] - empty_us, 1e-3)
+            how = "event-bracketed launch minus an empty event pair"
+        ach = per_launch[dom] / (dom_us * 1e-6) / 1e9
         kernels = {}
         for k in names:
-            kernels[k] = dict(avg_us=round(kt[k]["avg_us"], 3), launches_per_pass=kt[k]["launches"] // npass)
+            kernels[k] = dict(avg_us_event_pair=round(kt[k]["avg_us"], 3), launches_per_pass=kt[k]["launches"] // npass)
             if k in per_launch:
                 kernels[k]["alg_bytes_per_launch"] = per_launch[k]
-                kernels[k]["alg_GBps"] = round(per_launch[k] / (kt[k]["avg_us"] * 1e-6) / 1e9, 2)
+        tkey = args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")
+        tr = load_traffic(tkey)
+        traffic = tr["bytes"] if tr else None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "frac_alg": ach / HBM_PEAK_GBS,
+                "frac_hbm": (traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "traffic": traffic,
+                "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profile set %s "
+                                   "(profiles/%s_%s_pmc_summary.csv); not re-measured in this run"
+                                   % (tr["profile"], tr["profile"].split()[0], args.config)) if tr else None,
+                "alg_bytes_per_env_step": per_launch[dom] // B, "units_per_launch": B,
+                "kernel_us": dom_us, "kernel_us_how": how, "kernel_us_rocprof": tr.get("kernel_us") if tr else None,
+                "pass_us": pass_us, "launches_per_pass": launches, "event_pair_overhead_us": empty_us}
+        if rolling:
+            inst = ("MIX (pack.py:67-97): envs [0,B/2) PPSG-like guillotine instances (BPP_Generator_3D semantics), "
+                    "[B/2,B) RAND; device-generated, initial container 7 wide" if hp.mix else
+                    "device-generated 50-block RAND instances (generate.generate_instances), initial container 7 wide")
+        elif getattr(hp, "instances", None) == "generate":
+            inst = ("RAND instances of the device-side generator (generate_blocks semantics: random blocks packed into "
+                    "the 7-wide initial container, real precedence)")
+        elif getattr(hp, "instances", None) is not None:
+            inst = "fixture tiled"
+        else:
+            inst = "RAND-marginal blocks, random precedence DAG (synth.rand_instances)"
+        if rolling:
+            pas = ("rolling.validate's loop: reset + first window + (n - window) x tap_rolling_step (placement t + window "
+                   "t+1 in one launch), then window x tap_transition_bits on the last graph" if hp.fused_rolling else
+                   "rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window), then window x "
+                   "tap_transition_bits on the last graph")
+        elif hp.kind == "episode":
+            pas = "ONE launch of tap_episode_reward: gather by tour + n placements + C+P+S per env (pack.reward)"
+        elif hp.fused:
+            pas = ("%sn x tap_transition%s (update_dynamic+update_mask+gather+add_new_block in one launch; first starts a "
+                   "fresh container, last emits calc_ratio)%s" %
+                   (("tap_dyn_bits (shadow built from the fp32 instance tensor inside the pass) + ", "_bits",
+                     "; dynamic carried between steps as a bit shadow, the fp32 tensor is written every step but not "
+                     "re-read") if hp.bits else ("", "", "")))
+        else:
+            pas = "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio"
         out = {
             "metric": "env-steps/s (batch placements) 2D n=10 LB_GREEDY; 1/2/4/8 GPU + CPU ref",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "i32 height-maps / f64 candidate scores / f32 masks",
             "data": "synthetic",
+            "verified": bool(ver.get("verified")) and ok_all if ver.get("verified") is not None else None,
+            "verification": ver,
+            "ranks": dict(world_size=world, backend=(torch.distributed.get_backend() if world > 1 else None),
+                          rccl_ranks=(torch.distributed.get_world_size() if world > 1 and
+                                      torch.distributed.get_backend() == "nccl" else (1 if world == 1 else 0)),
+                          spawned_by_bench=os.environ.get("TAP_BENCH_SPAWNED") == "1"),
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
-                       "reward_type": reward, "packing_strategy": strategy,
-                       "instances": ("device-generated 50-block RAND instances (generate.generate_instances), initial container 7 wide"
-                                     if rolling else "RAND instances of the device-side generator (generate_blocks semantics: "
-                                     "random blocks packed into the 7-wide initial container, real precedence)"
-                                     if getattr(hp, "instances", None) == "generate" else
-                                     "fixture tiled" if getattr(hp, "instances", None) is not None else
-                                     "RAND-marginal blocks, random precedence DAG (synth.rand_instances)"),
-                       "pass": (("rolling.validate's loop: (n - window) x tap_rolling_step (placement t + window t+1 in one launch), "
-                                 "then window x tap_transition_bits on the last graph") if getattr(hp, "fused_rolling", False) else
-                                ("rolling.validate's loop: (n - window) x (tap_env_step_gather + tap_rolling_window), "
-                                 "then window x tap_transition_bits on the last graph")) if rolling else
-                               ("n x tap_transition%s (update_dynamic+update_mask+gather+add_new_block in one launch; "
-                                "first starts a fresh container, last emits calc_ratio)%s" %
-                                (("_bits", "; dynamic carried between steps as a bit shadow, the fp32 tensor is written "
-                                  "every step but not re-read") if getattr(hp, "bits", False) else ("", ""))) if hp.fused else
-                               "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio",
+                       "reward_type": reward, "packing_strategy": strategy, "instances": inst, "pass": pas,
                        "launch": "hipGraph replay" if use_graph else "eager"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": load_traffic(args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")),
-                         "alg_bytes_per_env_step": per_launch[dom] // B,
-                         "units_per_launch": B, "avg_launch_us": kt[dom]["avg_us"],
-                         "event_pair_overhead_us": empty_us},
+            "roofline": roof,
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_rolling(cfg, WINDOW[args.config]) if rolling else cpu_baseline(cfg, WINDOW.get(args.config), instances=("given", hp.static, hp.dynamic0) if getattr(hp, 'instances', None) == 'generate' else getattr(hp, 'instances', None))
-        if args.sweep:
-            for b in (8192, 32768, 131072, 524288, 2097152):
-                try:
-                    h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev, fused=hp.fused, window=hp.nw)
-                    d2, _ = time_passes(h2, 10, 3, use_graph, 1)
-                    k2, _ = kernel_event_times(h2, 3)
-                    print("sweep B=%d: %.3e env-steps/s; " % (b, b * n * 10 / d2) + "; ".join(
-                        "%s %.1f us (%.0f GB/s alg)" % (k, v["avg_us"], per_launch[k] / B * b / v["avg_us"] / 1e3)
-                        for k, v in k2.items() if k in per_launch), file=sys.stderr)
-                    del h2
-                except Exception as ex:  # out of memory at the top end is fine
-                    print("sweep B=%d failed: %s" % (b, ex), file=sys.stderr)
-                    break
-        cb = out.get("cpu_baseline")
-        rp = os.path.join(ROOT, "profiles", "r01d_reference_cpu.jsonl")
-        if cb and os.path.exists(rp):
-            # the reference's own Python path cannot run on the GPU box; scripts/time_reference.py measured, in
-            # the build container, how much slower it is than the oracle on the same core and the same work
-            key = {"c2": "c1/c2", "c3": "c3", "c4": "c4"}.get(args.config)
-            for line in open(rp):
-                r = json.loads(line)
-                if r.get("config") == key:
-                    cb["reference_derived"] = dict(
-                        value=cb["value"] / r["ratio_oracle_over_reference"], unit="env-steps/s", cores=1,
-                        how="this oracle figure / %.0f (reference vs oracle on one core of the build container, "
-                            "profiles/r01d_reference_cpu.jsonl); derived, not measured here" % r["ratio_oracle_over_reference"])
-        print(json.dumps(out))
+            cb = cpu_baseline_rolling(hp) if rolling else cpu_baseline(hp)
+            attach_reference_cpu(cb, args.config)
+            out["cpu_baseline"] = cb
+        if not args.no_variants and world == 1:
+            out["variants"] = variants(cfg, args, hp, rank, world, dev, use_graph)
+        if args.sweep and hp.kind == "transition":
+            run_sweep(cfg, hp, dev, use_graph, args.sweep_out)
+        print(json.dumps(out), flush=True)
     tdist.barrier()
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    if not ok_all:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -141,6 +141,15 @@ int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32
                    int32_t *positions_out, uint8_t *stable_out, int32_t *counters_out,
                    void *stream);
 
+/* tools.is_stable (tools.py:710-765) evaluated mask by mask, for tests of the predicate itself: the
+ * placement kernels call the same two device functions.  masks (n,) uint64, bit (i*by + j) = footprint
+ * cell (i, j) of a bx x by block rests on a voxel (tools.py:722-728); the block is off the floor.
+ * use_lut != 0: through the per-context table the 3D kernels use for footprints <= 4x4 (larger ones
+ * fall through to the direct form, as in the kernels); 0: the direct hull-free form only.
+ * stable_out (n,) uint8.  bx, by <= 8. */
+int tap_stable3d_eval(tap_ctx *ctx, int bx, int by, const unsigned long long *masks, int n,
+                      int use_lut, uint8_t *stable_out, void *stream);
+
 /* Synchronous.  Returns TAP_OK, or TAP_E_OVERFLOW / TAP_E_STEPS if any env has raised its sticky
  * error word; *n_bad_out (host, nullable) = number of such envs. */
 int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32_t *n_bad_out,
@@ -249,13 +258,17 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
  * tap_transition for 0/1 input. */
 
 /* bits_out = shadow of dynamic; *nonbinary_out (device int32, nullable, caller zeroes it) is
- * incremented by the number of elements that are neither 0 nor 1 -- the shadow is only valid at 0. */
+ * incremented by the number of elements that are neither 0 nor 1 -- the shadow is only valid at 0.
+ * bits_out NULL: count only (then rows may exceed 64). */
 int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
                  unsigned long long *bits_out, int32_t *nonbinary_out, void *stream);
 
 /* tap_mask_step on the shadow.  Every output is nullable (at least one must be given) and mask_in
  * NULL means ones, so the same entry serves pack.update_dynamic alone (no mask outputs) and
- * pack.update_mask alone (update_rows = 0, masks only).  Requires nR % 4 == 0, nR <= 256,
+ * pack.update_mask alone (update_rows = 0, masks only); ptr NULL (with update_rows = 0; static_ is then
+ * unused) gives the initial mask of model.py:297-307.  A ptr outside [0, nR) -- the reference's gather
+ * raises -- clears no row and removes no column, here and in tap_update_dynamic / tap_mask_step /
+ * tap_transition* (whose placement half also raises error bit 4 for it).  Requires nR % 4 == 0, nR <= 256,
  * rows <= 64, 16-byte aligned buffers, bits_in != bits_out. */
 int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
                        const unsigned long long *bits_in, const float *static_, int static_rows,

@@ -166,6 +166,8 @@ void orc_rolling_remove(orc_rolling *r, int local_index);
 
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) ---- */
 
+/* OpenMP threads of the three batched drivers below (timing only; results do not depend on it) */
+void orc_set_threads(int n);
 /* initial mask, model.py:297-307.  dynamic (B, rows, nR) fp32, rows = 3n ('bot') or n. */
 void orc_initial_mask(int B, int n, int nR, int rows, const float *dynamic, float *mask_out);
 /* pack.update_dynamic, pack.py:333-376.  update_time = 1 | 3.  static_ (B, static_rows, nR). */

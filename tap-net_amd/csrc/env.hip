@@ -80,6 +80,32 @@ extern "C" void tap_ctx_destroy(tap_ctx *ctx)
     delete ctx;
 }
 
+// tools.is_stable (tools.py:710-765) on explicit support masks -- see tapenv.h
+__global__ void __launch_bounds__(TAP_BLOCK) k_stable3d_eval(int bx, int by, const unsigned long long *masks, int n,
+                                                             const uint32_t *lut, uint8_t *out)
+{
+    const int i = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const u64 mc = masks[i];
+    u64 m = 0; // row-major (i*by + j) -> the kernels' stride-8 form
+    for (int r = 0; r < bx; ++r) m |= ((mc >> (r * by)) & ((1ull << by) - 1ull)) << (8 * r);
+    out[i] = (uint8_t)(lut ? tap_stable3d_any(lut, bx, by, m) : tap_stable3d(bx, by, m));
+}
+
+extern "C" int tap_stable3d_eval(tap_ctx *ctx, int bx, int by, const unsigned long long *masks, int n,
+                                 int use_lut, uint8_t *stable_out, void *stream)
+{
+    if (!ctx) return TAP_E_INVALID;
+    if (bx < 1 || by < 1 || bx > 8 || by > 8 || n < 0)
+        return tap_fail(ctx, TAP_E_INVALID, "stable3d_eval: footprint sides must be 1..8");
+    if (n == 0) return TAP_OK;
+    if (!masks || !stable_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    hipLaunchKernelGGL(k_stable3d_eval, dim3((n + TAP_BLOCK - 1) / TAP_BLOCK), dim3(TAP_BLOCK), 0, (hipStream_t)stream,
+                       bx, by, masks, n, use_lut ? ctx->stab_lut : nullptr, stable_out);
+    TAP_LAUNCH_CHECK(ctx, "k_stable3d_eval");
+    return TAP_OK;
+}
+
 extern "C" const char *tap_last_error(const tap_ctx *ctx) { return ctx ? ctx->err : ""; }
 
 static bool str_ends(const char *s, const char *suf)

@@ -44,10 +44,10 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_bits(int B, int nR, int rows,
         unsigned long long w = 0;
         for (int r = 0; r < rows; ++r) {
             const float v = slab[(size_t)r * nR + j];
-            w |= (unsigned long long)(v != 0.f) << r;
+            w |= (unsigned long long)(v != 0.f) << (r & 63);
             bad += (v != 0.f && v != 1.f);
         }
-        bits[(size_t)env * nR + j] = w;
+        if (bits) bits[(size_t)env * nR + j] = w;         // null: count only (any number of rows)
     }
     if (bad && nonbinary) atomicAdd(nonbinary, bad);
 }
@@ -74,9 +74,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     const int nR = a.nR;
     const size_t slab = (size_t)a.rows * nR;
     bool badp = false;
-    const long p = a.ptr ? tap_col((long)a.ptr[env], nR, badp) : 0;
-    // pack.py:339: block id read from row 0 of `static` as float -> long
-    const long real = (a.ptr && a.static_) ? (long)a.static_[(size_t)env * a.static_rows * nR + p] : -1;
+    const long pc = a.ptr ? tap_col((long)a.ptr[env], nR, badp) : 0;
+    // pack.py:339: block id read from row 0 of `static` as float -> long; an index outside [0, nR) (the
+    // reference's gather raises) clears nothing and removes no column
+    const long real = (a.ptr && a.static_ && !badp) ? (long)a.static_[(size_t)env * a.static_rows * nR + pc] : -1;
+    const long p = (a.ptr && !badp) ? pc : -1;
     if (a.dyn_out) {
         const ClearRanges cr = clear_ranges(a, real);
         const float *src = a.dyn_in + (size_t)env * slab;
@@ -132,8 +134,8 @@ extern "C" int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *
 {
     if (B < 0 || nR < 1 || rows < 1) return tap_fail(ctx, TAP_E_INVALID, "bad shape B=%d nR=%d rows=%d", B, nR, rows);
     if (B == 0) return TAP_OK;
-    if (rows > 64) return tap_fail(ctx, TAP_E_UNSUPPORTED, "the bit shadow holds at most 64 rows (rows=%d)", rows);
-    if (!dynamic || !bits_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    if (rows > 64 && bits_out) return tap_fail(ctx, TAP_E_UNSUPPORTED, "the bit shadow holds at most 64 rows (rows=%d)", rows);
+    if (!dynamic || (!bits_out && !nonbinary_out)) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     const int grid = (B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
     hipLaunchKernelGGL(k_dyn_bits, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, B, nR, rows, dynamic,
@@ -150,8 +152,8 @@ extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, i
     int rc = check_shape(ctx, B, n, n * R, rows);
     if (rc) return rc;
     if (B == 0) return TAP_OK;
-    if (!bits_in || !static_ || !ptr || static_rows < 1 || update_rows < 0 || update_rows > 3 ||
-        bits_in == bits_out || (!bits_out && !dyn_out && !current_out && !mask_out))
+    if (!bits_in || (ptr && (!static_ || static_rows < 1)) || update_rows < 0 || update_rows > 3 ||
+        (!ptr && update_rows != 0) || bits_in == bits_out || (!bits_out && !dyn_out && !current_out && !mask_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_bits arguments");
     MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};

@@ -89,8 +89,9 @@ __device__ __forceinline__ void mask_env(const MaskArgs &a, int env, int lane, l
 {
     const int nR = a.nR;
     const size_t slab = (size_t)a.rows * nR;
-    long real_m = p;
-    real_m = tap_mod_col(real_m, a.n, a.nR);                       // pack.py:314-316
+    // an index outside [0, nR) (the reference's gather raises) selects nothing: no row is cleared
+    // (real = -1 from the caller) and no column leaves the mask
+    const long real_m = (p >= 0 && p < nR) ? tap_mod_col(p, a.n, a.nR) : -1 - (long)a.n * a.R; // pack.py:314-316
     for (int j = lane; j < nR; j += 64) {
         float sum[3], row[3];
 #pragma unroll
@@ -162,11 +163,11 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
         if (!have_real) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                float r0 = 0.f;                                               // pack.py:339 via shuffle
-#pragma unroll
+                float r0 = -1.f;                                              // pack.py:339 via shuffle;
+#pragma unroll                                                                // stays -1 for an index outside [0, nR)
                 for (int c = 0; c < NC; ++c) {
                     const float t = __shfl(row0[k][c], (int)(p[k] & 63));
-                    if ((p[k] >> 6) == c) r0 = t;
+                    if ((p[k] >> 6) == c && p[k] >= 0 && p[k] < nR) r0 = t;
                 }
                 cr[k] = clear_ranges(a, on[k] ? (long)r0 : -1);
             }
@@ -195,8 +196,7 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
     for (int k = 0; k < NS; ++k) {
         if (!on[k]) continue;
         const int env = senv0 + k;
-        long real_m = p[k];
-        real_m = tap_mod_col(real_m, a.n, a.nR);                               // pack.py:314-316
+        const long real_m = (p[k] >= 0 && p[k] < nR) ? tap_mod_col(p[k], a.n, a.nR) : -1 - (long)a.n * a.R; // pack.py:314-316
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
@@ -240,12 +240,12 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int env = senv0 + k;
-        p[k] = on[k] ? (long)a.ptr[env] : 0;
+        p[k] = (on[k] && a.ptr) ? (long)a.ptr[env] : -1;   // no ptr: the initial mask (model.py:297-307)
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
             const bool ok = on[k] && j < nR;
-            row0[k][c] = ok ? a.static_[(size_t)env * a.static_rows * nR + j] : 0.f;
+            row0[k][c] = (ok && a.static_) ? a.static_[(size_t)env * a.static_rows * nR + j] : 0.f;
             keep[k][c] = ok ? (a.mask_in ? a.mask_in[(size_t)env * nR + j] : 1.f) : 0.f;
             bj[k][c] = ok ? a.bits_in[(size_t)env * nR + j] : 0ull;
         }
@@ -259,11 +259,11 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
     for (int k = 0; k < NS; ++k) {
         if (!on[k]) continue;
         const int env = senv0 + k;
-        float r0 = 0.f;                                                       // pack.py:339 via shuffle
-#pragma unroll
+        float r0 = -1.f;                                                      // pack.py:339 via shuffle; stays -1
+#pragma unroll                                                                        // for an index outside [0, nR)
         for (int c = 0; c < NC; ++c) {
             const float t = __shfl(row0[k][c], (int)(p[k] & 63));
-            if ((p[k] >> 6) == c) r0 = t;
+            if ((p[k] >> 6) == c && p[k] >= 0 && p[k] < nR) r0 = t;
         }
         const long real = (long)r0;
         u64 clr = 0;                                                          // pack.py:370-374
@@ -287,8 +287,7 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
                 dst[1] = make_ulonglong2(n2, n3);
             }
         }
-        long real_m = p[k];
-        real_m = tap_mod_col(real_m, a.n, a.nR);                               // pack.py:314-316
+        const long real_m = (p[k] >= 0 && p[k] < nR) ? tap_mod_col(p[k], a.n, a.nR) : -1 - (long)a.n * a.R; // pack.py:314-316
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
@@ -308,7 +307,7 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
 // the bit shadow needs 16-byte rows of words and float4 rows
 inline bool mask_bits_ok(const MaskArgs &a)
 {
-    return a.bits_in && a.ptr && a.static_ && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 && a.rows <= 64 &&
+    return a.bits_in && (a.ptr == nullptr || a.static_ != nullptr) && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 && a.rows <= 64 &&
            (reinterpret_cast<uintptr_t>(a.dyn_out) % 16 == 0) &&
            ((reinterpret_cast<uintptr_t>(a.bits_in) | reinterpret_cast<uintptr_t>(a.bits_out)) % 16 == 0);
 }

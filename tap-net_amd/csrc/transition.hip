@@ -49,8 +49,10 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
         if (!on[k]) continue;
         const int senv = senv0 + k;
         bool badp;
-        const long p = tap_col((long)m.ptr[senv], m.nR, badp);
-        const long real = (long)m.static_[(size_t)senv * m.static_rows * m.nR + p]; // pack.py:339
+        const long pc = tap_col((long)m.ptr[senv], m.nR, badp);
+        // pack.py:339; an index outside [0, nR) clears nothing and removes no column (tap_masks.h)
+        const long real = badp ? -1 : (long)m.static_[(size_t)senv * m.static_rows * m.nR + pc];
+        const long p = badp ? -1 : pc;
         const ClearRanges cr = clear_ranges(m, real);
         const float *src = m.dyn_in + (size_t)senv * slab;
         float *dst = m.dyn_out + (size_t)senv * slab;

@@ -95,8 +95,10 @@ def generate_instances(batch_size, blocks_num, block_dim, initial_container_widt
         m = max(256, int((batch_size - have) * oversample) + 64)
         idx = torch.multinomial(prob, m * blocks_num * block_dim, replacement=True, generator=gen)
         blocks = values[idx].view(m, blocks_num, block_dim).to(torch.int32)          # generate.py:896
-        pos, stable, _ = pack_blocks(blocks, cs)                                     # generate.py:908
-        ok = stable.all(dim=1)                                                       # generate.py:909-910
+        pos, stable, rew = pack_blocks(blocks, cs)                                   # generate.py:908
+        # generate.py:909-910; a packing that reaches above the initial container (NaN reward: the
+        # reference would raise or clip its voxel grid before calc_dependent) is not an instance either
+        ok = stable.all(dim=1) & ~torch.isnan(rew)
         got_blocks.append(blocks[ok]); got_pos.append(pos[ok])
         have += int(ok.sum().item())
     blocks = torch.cat(got_blocks)[:batch_size].contiguous()

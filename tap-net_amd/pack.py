@@ -77,8 +77,39 @@ def dynamic_colsum(dynamic, blocks_num):
 
 # ---- (B, nR) bit shadow of a 0/1-valued dynamic tensor (tapenv.h: tap_dyn_bits) -------------------
 # Preferred over the column sums when the tensor allows it: the step then writes the new fp32 tensor
-# from the bits and never reads the old one.  False is cached for tensors that cannot be carried.
+# from the bits and never reads the old one.  The cache is keyed by tensor identity and version: tensors
+# mutated out of band (.data writes, foreign kernels) must not be passed again.
+#   entry = shadow tensor | 'binary' (0/1 but the shape has no shadow) | 'nonbinary'
 _bshadow = {}
+_binary_mode = 'check'
+_deferred = {}          # device index -> int32 counter of non-0/1 elements seen in 'trust' mode
+
+
+def set_binary_check(mode):
+    """How the seams learn that a fresh ``dynamic`` tensor holds only 0 and 1 (what PACKDataset builds and
+    update_dynamic preserves):
+
+    'check' (default)  count the other values on the device and READ the count: one device->host sync per
+                       new tensor (once per episode), exact fallback for tensors with other values;
+    'trust'            no host read -- the seams stay asynchronous and capturable in a HIP graph; the count is
+                       accumulated on the device and ``check_binary()`` reports it when the caller asks."""
+    global _binary_mode
+    if mode not in ('check', 'trust'):
+        raise ValueError("mode must be 'check' or 'trust'")
+    _binary_mode = mode
+
+
+def check_binary(device=None):
+    """Deferred form of the 0/1 test in 'trust' mode (synchronises): raises ValueError if any tensor handed to
+    the seams since the last call held a value other than 0 or 1 -- results computed from it are invalid."""
+    bad = 0
+    for idx, cnt in list(_deferred.items()):
+        if device is None or _lib.resolve_device(device).index == idx:
+            bad += int(cnt.item())
+            cnt.zero_()
+    if bad:
+        raise ValueError("%d element(s) of a `dynamic` tensor were neither 0 nor 1 while pack.set_binary_check('trust') "
+                         "was in force" % bad)
 
 
 def _bits_put(dynamic, bits):
@@ -86,19 +117,34 @@ def _bits_put(dynamic, bits):
     _bshadow[key] = (weakref.ref(dynamic, lambda _r, k=key: _bshadow.pop(k, None)), dynamic._version, bits)
 
 
-def _bits_get(dynamic, build=False):
+def _bits_state(dynamic, build=False):
+    """-> shadow tensor | 'binary' | 'nonbinary' | None (unknown and not asked to find out)."""
     hit = _bshadow.get(id(dynamic))
     if hit is not None and hit[0]() is dynamic and hit[1] == dynamic._version:
-        return hit[2] if hit[2] is not False else None
-    if not build:
+        return hit[2]
+    if not build or dynamic.dim() != 3:
         return None
-    bits = False
-    if dynamic.dim() == 3 and bits_supported(int(dynamic.shape[1]), int(dynamic.shape[2])):
-        shadow, bad = dynamic_bits(dynamic)
-        if int(bad.item()) == 0:                     # one device->host read per episode
-            bits = shadow
-    _bits_put(dynamic, bits)
-    return bits if bits is not False else None
+    ok_shape = bits_supported(int(dynamic.shape[1]), int(dynamic.shape[2]))
+    if _binary_mode == 'trust':
+        dev = _lib.resolve_device(dynamic.device)
+        cnt = _deferred.get(dev.index)
+        if cnt is None:
+            cnt = _deferred[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+        shadow, _ = dynamic_bits(dynamic, counter=cnt, want_bits=ok_shape)
+        state = shadow if ok_shape else 'binary'
+    else:
+        shadow, bad = dynamic_bits(dynamic, want_bits=ok_shape)
+        if int(bad.item()) != 0:                     # one device->host read per episode
+            state = 'nonbinary'
+        else:
+            state = shadow if ok_shape else 'binary'
+    _bits_put(dynamic, state)
+    return state
+
+
+def _bits_get(dynamic, build=False):
+    st = _bits_state(dynamic, build)
+    return st if isinstance(st, torch.Tensor) else None
 
 
 def _mask_step_bits(bits_in, st, ptr, n, R, rows, update_rows, mask_in, bits_out, dyn_out, cur, new):
@@ -125,18 +171,27 @@ def update_dynamic(dynamic, static, chosen_idx, input_type, allow_rot):
         _mask_step_bits(bits_in, st, ptr, n, R, rows, _UPDATE_ROWS[input_type], None, bits_out, out, None, None)
         _bits_put(out, bits_out)
         return out
+    c = _lib.ctx(dyn.device)
+    if _bits_state(dynamic) == 'nonbinary':
+        # values other than 0/1: "old column sum - cleared row" in fp32 is not the re-summed value the
+        # reference tests (pack.py:323-329), so no incremental shadow -- update_mask re-reduces the tensor
+        with torch.cuda.device(dyn.device):
+            _lib.check(_lib.lib().tap_update_dynamic(
+                c, B, n, nR, rows, _UPDATE_ROWS[input_type], _lib.ptr(dyn), _lib.ptr(st), st.shape[1],
+                _lib.ptr(ptr), _lib.ptr(out), None, None, _lib.stream_of(dyn.device)), c)
+        _bits_put(out, 'nonbinary')
+        return out
     # first call of an episode: build the column-sum shadow once (one extra read of the slab) so this
     # and every later step run the single-round-trip streaming kernel and update_mask never re-reads
     cs_in = dynamic_colsum(dynamic, n)
     cs_out = torch.empty_like(cs_in)
-    c = _lib.ctx(dyn.device)
     with torch.cuda.device(dyn.device):
         _lib.check(_lib.lib().tap_update_dynamic(
             c, B, n, nR, rows, _UPDATE_ROWS[input_type], _lib.ptr(dyn), _lib.ptr(st), st.shape[1],
             _lib.ptr(ptr), _lib.ptr(out), _lib.ptr(cs_in), _lib.ptr(cs_out),
             _lib.stream_of(dyn.device)), c)
-    if cs_out is not None:
-        _shadow_put(out, cs_out)
+    _shadow_put(out, cs_out)
+    _bits_put(out, 'binary')
     return out
 
 
@@ -163,13 +218,21 @@ def update_mask(mask, dynamic, static, chosen_idx, input_type, allow_rot):
     return cur, new
 
 
-def initial_mask(dynamic, blocks_num):
-    """The mask DRL.forward builds before its loop (model.py:297-307) -> (current_mask, mask)."""
+def initial_mask(dynamic, blocks_num, bits=None):
+    """The mask DRL.forward builds before its loop (model.py:297-307) -> (current_mask, mask).
+    ``bits``: the tensor's bit shadow when the caller holds it (column sums = popcounts, the fp32 tensor is
+    not read)."""
     dyn = _f32c(dynamic)
     B, rows, nR = dyn.shape
-    cs = dynamic_colsum(dynamic, blocks_num)
     cur = torch.empty(B, nR, dtype=torch.float32, device=dyn.device)
     mask = torch.empty(B, nR, dtype=torch.float32, device=dyn.device)
+    if bits is None:
+        bits = _bits_get(dynamic)
+    if bits is not None:
+        _mask_step_bits_raw(dyn.device, B, blocks_num, nR // blocks_num, rows, 0, bits, None, 0, None, None, None, None,
+                            cur, mask)
+        return cur, mask
+    cs = dynamic_colsum(dynamic, blocks_num)
     c = _lib.ctx(dyn.device)
     with torch.cuda.device(dyn.device):
         _lib.check(_lib.lib().tap_update_mask(c, B, blocks_num, nR // blocks_num, None, _lib.ptr(cs), None,
@@ -177,19 +240,29 @@ def initial_mask(dynamic, blocks_num):
     return cur, mask
 
 
+def _mask_step_bits_raw(device, B, n, R, rows, update_rows, bits_in, st, st_rows, ptr, mask_in, bits_out, dyn_out, cur, new):
+    c = _lib.ctx(device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().tap_mask_step_bits(
+            c, B, n, R, rows, update_rows, _lib.ptr(bits_in), _lib.ptr(st), st_rows, _lib.ptr(ptr),
+            _lib.ptr(mask_in), _lib.ptr(bits_out), _lib.ptr(dyn_out), _lib.ptr(cur), _lib.ptr(new),
+            _lib.stream_of(device)), c)
+
+
 def bits_supported(rows, nR):
     """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_mask_step_bits)."""
     return rows <= 64 and nR % 4 == 0 and nR <= 256
 
 
-def dynamic_bits(dynamic):
+def dynamic_bits(dynamic, counter=None, want_bits=True):
     """Bit shadow of a 0/1-valued ``dynamic`` (B, rows <= 64, nR): -> (bits (B, nR) int64 with bit r of
     word j = dynamic[b, r, j] != 0, nonbinary (1,) int32 = number of elements that are neither 0 nor 1;
-    the shadow stands for the tensor only when that count is 0)."""
+    the shadow stands for the tensor only when that count is 0).  ``counter``: accumulate the count into
+    this device int32 instead of a fresh one; ``want_bits`` False: count only (any number of rows)."""
     dyn = _f32c(dynamic)
     B, rows, nR = dyn.shape
-    bits = torch.empty(B, nR, dtype=torch.int64, device=dyn.device)
-    bad = torch.zeros(1, dtype=torch.int32, device=dyn.device)
+    bits = torch.empty(B, nR, dtype=torch.int64, device=dyn.device) if want_bits else None
+    bad = counter if counter is not None else torch.zeros(1, dtype=torch.int32, device=dyn.device)
     c = _lib.ctx(dyn.device)
     with torch.cuda.device(dyn.device):
         _lib.check(_lib.lib().tap_dyn_bits(c, B, nR, rows, _lib.ptr(dyn), _lib.ptr(bits), _lib.ptr(bad),
@@ -214,18 +287,20 @@ class MaskStepper(object):
         self.B, self.rows, self.nR = self.dynamic.shape
         self.n = self.nR // self.R
         self.update_rows = _UPDATE_ROWS[input_type]
-        self.colsum = dynamic_colsum(self.dynamic, self.n)
-        self.current_mask, self.mask = initial_mask(self.dynamic, self.n)
-        self.bits = None
+        self.bits, self.colsum, self.nonbinary = None, None, False
         if isinstance(bits, torch.Tensor):               # a shadow the caller already holds (rolling windows)
             self.bits = bits
-        elif bits is not False and bits_supported(self.rows, self.nR):
-            shadow, bad = dynamic_bits(self.dynamic)
-            if int(bad.item()) == 0:
-                self.bits = shadow
+        else:
+            st = _bits_state(dynamic, build=True)
+            if isinstance(st, torch.Tensor) and bits is not False:
+                self.bits = st
+            self.nonbinary = isinstance(st, str) and st == 'nonbinary'
         if bits is True and self.bits is None:
             raise ValueError("dynamic cannot be carried as a bit shadow (needs rows <= 64, nR % 4 == 0, "
                              "nR <= 256 and only 0/1 values)")
+        if self.bits is None:                            # the column sums are only needed without the shadow
+            self.colsum = dynamic_colsum(self.dynamic, self.n)
+        self.current_mask, self.mask = initial_mask(self.dynamic, self.n, bits=self.bits)
 
     def _check_step_args(self, ptr, dyn_out):
         if tuple(ptr.shape) != (self.B,):
@@ -252,6 +327,9 @@ class MaskStepper(object):
             self.dynamic, self.bits, self.current_mask, self.mask = out, nb, cur, new
             return out, cur, new
         cs = torch.empty_like(self.colsum)
+        if self.nonbinary:
+            self._step_resum(ptr, out, cs, cur, new)
+            return out, cur, new
         with torch.cuda.device(out.device):
             _lib.check(_lib.lib().tap_mask_step(
                 c, self.B, self.n, self.R, self.rows, self.update_rows, _lib.ptr(self.dynamic),
@@ -260,6 +338,20 @@ class MaskStepper(object):
                 _lib.stream_of(out.device)), c)
         self.dynamic, self.colsum, self.current_mask, self.mask = out, cs, cur, new
         return out, cur, new
+
+    def _step_resum(self, ptr, out, cs, cur, new):
+        """Values other than 0/1: re-sum the new tensor like the reference (pack.py:323-326) instead of
+        "old sum - cleared row", which is only exact for 0/1 data -- three launches, exact."""
+        c = _lib.ctx(out.device)
+        L, S = _lib.lib(), _lib.stream_of(out.device)
+        with torch.cuda.device(out.device):
+            _lib.check(L.tap_update_dynamic(c, self.B, self.n, self.nR, self.rows, self.update_rows,
+                                            _lib.ptr(self.dynamic), _lib.ptr(self.static), self.static.shape[1],
+                                            _lib.ptr(ptr), _lib.ptr(out), None, None, S), c)
+            _lib.check(L.tap_dyn_colsum(c, self.B, self.n, self.nR, self.rows, _lib.ptr(out), _lib.ptr(cs), S), c)
+            _lib.check(L.tap_update_mask(c, self.B, self.n, self.R, _lib.ptr(self.mask), _lib.ptr(cs), _lib.ptr(ptr),
+                                         _lib.ptr(cur), _lib.ptr(new), S), c)
+        self.dynamic, self.colsum, self.current_mask, self.mask = out, cs, cur, new
 
 
 class EnvTransition(MaskStepper):
@@ -296,6 +388,13 @@ class EnvTransition(MaskStepper):
             self.dynamic, self.bits, self.current_mask, self.mask = out, nb, cur, new
             return out, cur, new, feat, ratio
         cs = torch.empty_like(self.colsum)
+        if self.nonbinary:                               # exact, unfused (see MaskStepper._step_resum)
+            if fresh:
+                self.env.reset()
+            self._step_resum(ptr, out, cs, cur, new)
+            feat = self.env.add_new_blocks_gather(self.static, ptr, want_feature=want_feature)
+            ratio = self.env.calc_ratios() if want_ratio else None
+            return out, cur, new, feat, ratio
         with torch.cuda.device(out.device):
             _lib.check(_lib.lib().tap_transition(
                 c, C.byref(self.env.desc), _lib.ptr(self.env._state), self.n, self.R, self.rows,

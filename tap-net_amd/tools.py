@@ -27,3 +27,18 @@ def calc_positions_lb_greedy(blocks, container_size, reward_type, device='cuda')
         + np.float64(nst) / np.float64(n)
     return (env.positions[0].cpu().numpy().astype(int), None, [bool(v) for v in env.stable[0].tolist()],
             float(ratio), [valid, box, empty, nst, max_h])
+
+
+def is_stable_masks(bx, by, masks, use_lut=True, device='cuda'):
+    """tools.is_stable (tools.py:710-765) for a batch of support patterns of one bx x by footprint that
+    is off the floor: ``masks`` (n,) integers, bit (i*by + j) = footprint cell (i, j) rests on a voxel
+    (tools.py:722-728).  -> (n,) bool tensor.  ``use_lut`` picks the table the 3D kernels use for
+    footprints <= 4x4, False the direct form; both are the device functions the placements call."""
+    dev = _lib.resolve_device(device)
+    m = torch.as_tensor(np.asarray(masks, dtype=np.uint64).view(np.int64), device=dev).contiguous()
+    out = torch.empty(m.numel(), dtype=torch.uint8, device=dev)
+    c = _lib.ctx(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().tap_stable3d_eval(c, int(bx), int(by), _lib.ptr(m), m.numel(), 1 if use_lut else 0,
+                                                _lib.ptr(out), _lib.stream_of(dev)), c)
+    return out.bool()

@@ -76,6 +76,7 @@ def lib():
         L.orc_rolling_free.argtypes = [C.c_void_p]
         L.orc_rolling_window.argtypes = [C.c_void_p] * 4
         L.orc_rolling_remove.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_threads.argtypes = [C.c_int]
         L.orc_initial_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_update_dynamic.argtypes = [C.c_int] * 6 + [C.c_void_p] * 4
         L.orc_update_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 5
@@ -258,6 +259,11 @@ def reward(static, tour, reward_type, container_width, container_height, nthread
     out = np.zeros(B, np.float32)
     nerr = lib().orc_reward(C.byref(desc), B, n, nR, rows, _p(static), _p(tour), _p(out), nthreads)
     return nerr, out
+
+
+def set_threads(n):
+    """OpenMP threads of initial_mask / update_dynamic / update_mask (timing only)."""
+    lib().orc_set_threads(int(n))
 
 
 def initial_mask(dynamic, n):
