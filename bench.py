@@ -5,9 +5,10 @@ One "step" = one full pass of the hot path over one batch of synthetic instances
 DRL.forward does around its policy network for one batch (model.py:294-515), with the actions
 replayed from a pre-computed feasible tape:
 
-    tap_dyn_bits (bit shadow of the instance batch's fp32 `dynamic`, built INSIDE the pass)
-    -> n x tap_transition_bits (update_dynamic + update_mask + gather + add_new_block in one launch;
-       the first starts a fresh container, the last emits calc_ratio)
+    tap_transition_first (step 0: reads the instance batch's fp32 `dynamic` and builds its bit shadow INSIDE
+       the launch, starts a fresh container)
+    -> (n - 1) x tap_transition_bits (update_dynamic + update_mask + gather + add_new_block in one launch;
+       the last emits calc_ratio)
     [-> when N > 1, the (B,) reward vectors of 8 consecutive passes are all-gathered with one RCCL call]
 
 value = env-steps/s = (placements in all envs on all ranks) / wall time, inputs resident in HBM before
@@ -37,6 +38,18 @@ sys.path.insert(0, ROOT)
 import tap_net_amd as T                     # noqa: E402
 from tap_net_amd import _lib, synth         # noqa: E402
 from tap_net_amd import dist as tdist       # noqa: E402
+
+
+
+def _oracle():
+    """The CPU oracle (test infrastructure): only the verification after the timed region and the
+    cpu_baseline leg load it -- never the timed path."""
+    tests = os.path.join(ROOT, "tests")
+    if tests not in sys.path:
+        sys.path.insert(0, tests)
+    import oracle_lib
+    return oracle_lib
+
 
 HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
 VERIFY_ENVS = 512        # envs of the last replayed pass compared with the oracle after the timed region
@@ -150,7 +163,7 @@ class HotPath(object):
 
     def launches_per_pass(self):
         per = 1 if self.fused else 2
-        return self.n * per + (self.windows if self.bits else 0) + (0 if self.fused else 2)
+        return self.n * per + (self.windows if self.bits and not self.fused else 0) + (0 if self.fused else 2)
 
     def episode(self):
         """fused: [tap_dyn_bits +] n launches of tap_transition (first FRESH, last emits calc_ratio);
@@ -164,16 +177,22 @@ class HotPath(object):
             st = self.static[w]
             dyn_in, cs_in, mask_in = self.dynamic0[w], self.cs0[w], self.mask0
             bits_in = None
-            if self.bits:
-                # a trainer sees fresh fp32 instances every batch (PACKDataset -> DataLoader): the shadow is
-                # built from the tensor inside the pass (reads rows*nR*4 B per env once per window)
+            if self.bits and not self.fused:
                 bits_in = self.bitb[2]
                 self._k("dyn_bits", L.tap_dyn_bits, self.ctx, self.B, self.nR, self.rows, P(dyn_in), P(bits_in), P(self.nonbin))
             for t in range(self.nw):
                 ptr = self.tape[w][t]
                 o = t & 1
                 flags = (_lib.TAP_T_FRESH if step == 0 else 0) | (_lib.TAP_T_RATIO if step == self.n - 1 else 0)
-                if self.fused and self.bits:
+                if self.fused and self.bits and t == 0:
+                    # a trainer sees fresh fp32 instances every batch (PACKDataset -> DataLoader): the window's
+                    # first step reads the fp32 tensor and builds the bit shadow inside the launch
+                    self._k("transition_first", L.tap_transition_first, self.ctx, d, P(e._state), self.nw, self.R,
+                            self.rows, 3, P(dyn_in), P(st), st.shape[1], P(ptr), P(mask_in), P(self.bitb[o]),
+                            P(self.dyn[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward),
+                            P(self.nonbin), flags)
+                    bits_in = self.bitb[o]
+                elif self.fused and self.bits:
                     self._k("transition", L.tap_transition_bits, self.ctx, d, P(e._state), self.nw, self.R,
                             self.rows, 3, P(bits_in), P(st), st.shape[1], P(ptr), P(mask_in), P(self.bitb[o]),
                             P(self.dyn[o]), P(self.cur), P(self.maskb[o]), P(self.feat), P(self.reward), flags)
@@ -202,7 +221,7 @@ class HotPath(object):
 
     # ---- after the timed region: the state the LAST pass left behind, against the oracle ---------------
     def verify(self, nenv=VERIFY_ENVS):
-        import oracle_lib as O
+        O = _oracle()
         V = min(nenv, self.B)
         self.env.check()
         if self.bits and int(self.nonbin.item()) != 0:
@@ -269,7 +288,7 @@ class EpisodeHotPath(HotPath):
                 st.shape[1], self.nR, P(self.tour), P(self.reward), P(self.pos), P(self.stab))
 
     def verify(self, nenv=VERIFY_ENVS):
-        import oracle_lib as O
+        O = _oracle()
         V = min(nenv, self.B)
         st, tour = self.static[0][:V].cpu().numpy(), self.tour[:V].cpu().numpy()
         nerr, want = O.reward(st, tour, self.reward_type, self.cs[0], self.cs[-1], nthreads=os.cpu_count() or 1)
@@ -404,7 +423,7 @@ class RollingHotPath(HotPath):
     def verify(self, nenv=VERIFY_ENVS):
         """(1) every env's calc_ratio against the eager two-launch recording run; (2) a slice against the
         oracle's InitialContainer + Container driven by the same tape: reward, positions, last masks."""
-        import oracle_lib as O
+        O = _oracle()
         self.env.check()
         bad = []
         if not torch.equal(self.reward, -self.want):
@@ -583,6 +602,12 @@ def cpu_info():
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    try:                                     # a container's CPU quota (cgroup v2) caps what threads can use
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            avail = max(1, min(avail, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
     return model, os.cpu_count() or 1, avail
 
 
@@ -598,8 +623,7 @@ def _timed_loop(fn, budget_s):
 def cpu_baseline(hp, budget_s=10.0):
     """The oracle (C port of the reference algorithm) over the same pass -- masks + placements + ratio of the
     first <= 4096 instances of THIS run -- on one host core, then on all of them (OpenMP over envs)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
+    O = _oracle()
     B = min(hp.B, 4096)
     nw, n = hp.nw, hp.n
     wins = [(s[:B].cpu().numpy(), d[:B].cpu().numpy(), t[:, :B].t().cpu().numpy())
@@ -637,15 +661,15 @@ def cpu_baseline(hp, budget_s=10.0):
                 sample="%d passes of B=%d envs x n=%d (%s) of this run's instances, %.1f s, "
                        "oracle/libtap_oracle.so single thread" % (done1 // (B * n), B, n, what, el1),
                 all_cores=dict(value=doneN / elN, cores=avail,
-                               sample="%d passes, %.1f s, OpenMP over envs, %d threads" % (doneN // (B * n), elN, avail)),
-                cpu_model=model, cpu_count=ncpu)
+                               sample="%d passes, %.1f s, OpenMP over envs, %d threads (CPUs this process may use: "
+                                      "affinity and cgroup quota)" % (doneN // (B * n), elN, avail)),
+                cpu_model=model, cpu_count=ncpu, cpus_usable=avail)
 
 
 def cpu_baseline_rolling(hp, budget_s=10.0):
     """The oracle over rolling.validate's loop (windows re-cut after every placement) on this run's instances
     and tape: one host core (driven per step from Python), then one process per core."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as O
+    O = _oracle()
     n, win, R = hp.n, hp.nw, hp.R
     V = min(hp.B, 256)
     tape = hp.tape[:, :V].cpu().numpy()
@@ -694,8 +718,8 @@ def cpu_baseline_rolling(hp, budget_s=10.0):
                 sample="%d rolling episodes of %d placements (window %d) over this run's instances and tape, %.1f s, "
                        "oracle/libtap_oracle.so single thread driven per step from Python" % (done1 // n, n, win, el1),
                 all_cores=dict(value=doneN / elN, cores=len(procs),
-                               sample="%d episodes, %.1f s, one forked process per core" % (doneN // n, elN)),
-                cpu_model=model, cpu_count=ncpu)
+                               sample="%d episodes, %.1f s, one forked process per usable CPU" % (doneN // n, elN)),
+                cpu_model=model, cpu_count=ncpu, cpus_usable=avail)
 
 
 def attach_reference_cpu(cb, config):
@@ -807,8 +831,8 @@ def run_sweep(cfg, hp, dev, use_graph, path):
             d2, g2 = time_passes(h2, steps, 2, use_graph, 1)
             k2, _, pass_us = kernel_event_times(h2, 3, g2[0] if g2 else None)
             rec = dict(config=name.split(" on ")[0], batch=b, env_steps_per_s=b * n * steps / d2,
-                       pass_us=pass_us, transition_us=k2["transition"]["avg_us"],
-                       alg_GBps=(env_b + mask_b) * b / (k2["transition"]["avg_us"] * 1e-6) / 1e9,
+                       pass_us=pass_us, step_us=pass_us / n,
+                       alg_GBps=(env_b + mask_b) * b / (pass_us / n * 1e-6) / 1e9,
                        dynamic_MB=round(h2.dynamic0[0].numel() * 4 / 1e6, 1), bits=bool(h2.bits))
             lines.append(rec)
             print("sweep " + json.dumps(rec), file=sys.stderr)
@@ -936,10 +960,11 @@ def main():
         R_ = 2 if D == 2 else 6
         win_b = (1 + D) * hp.nw * R_ * 4 + 3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 4 + 32   # static + dynamic + mask + state
         per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B,
+                      "transition_first": (env_b + mask_b) * B,
                       "rolling_window": win_b * B, "rolling_step": (win_b + env_b) * B,
                       "episode": episode_bytes(D, n) * B,
                       "dyn_bits": (3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 8) * B}
-        names = [k for k in ("transition", "rolling_step", "rolling_window", "episode", "mask_step", "env_step", "dyn_bits",
+        names = [k for k in ("transition", "transition_first", "rolling_step", "rolling_window", "episode", "mask_step", "env_step", "dyn_bits",
                              "ratio", "reset") if k in kt]
         dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
         # the dominant kernel's duration: (event-bracketed launch) - (an empty event pair); for a pass that is
@@ -994,9 +1019,10 @@ def main():
         elif hp.fused:
             pas = ("%sn x tap_transition%s (update_dynamic+update_mask+gather+add_new_block in one launch; first starts a "
                    "fresh container, last emits calc_ratio)%s" %
-                   (("tap_dyn_bits (shadow built from the fp32 instance tensor inside the pass) + ", "_bits",
-                     "; dynamic carried between steps as a bit shadow, the fp32 tensor is written every step but not "
-                     "re-read") if hp.bits else ("", "", "")))
+                   (("", "_first/_bits",
+                     "; step 0 reads the fp32 instance tensor and builds the bit shadow in the same launch, later steps "
+                     "carry dynamic as that shadow: the fp32 tensor is written every step but not re-read")
+                    if hp.bits else ("", "", "")))
         else:
             pas = "reset + n x (update_dynamic+update_mask, add_new_block) + calc_ratio"
         out = {

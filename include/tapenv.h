@@ -275,6 +275,17 @@ int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, int update_r
                        const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
                        float *dyn_out, float *current_out, float *mask_out, void *stream);
 
+/* The FIRST step of an episode on a fresh fp32 `dynamic` (what PACKDataset / a DataLoader hands over,
+ * pack.py:195): tap_mask_step_bits with the shadow built from dyn_in inside the launch (one read of the
+ * tensor), so an episode needs no separate tap_dyn_bits pass.  bits_out receives the shadow of dyn_out;
+ * *nonbinary_out (device int32, nullable, caller zeroes it) counts the elements of dyn_in that are neither
+ * 0 nor 1 -- every output of the launch is only valid when it stays 0.  ptr NULL (update_rows = 0):
+ * shadow + initial mask only. */
+int tap_mask_step_first(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows, const float *dyn_in,
+                        const float *static_, int static_rows, const int64_t *ptr, const float *mask_in,
+                        unsigned long long *bits_out, float *dyn_out, float *current_out, float *mask_out,
+                        int32_t *nonbinary_out, void *stream);
+
 /* ---- one whole lock-step in one launch --------------------------------------------------- */
 
 enum {
@@ -301,6 +312,14 @@ int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *state, int n,
                         unsigned long long *bits_out, float *dyn_out, float *current_out,
                         float *mask_out, float *feature_out, float *ratio_out, int flags,
                         void *stream);
+
+/* tap_transition_bits for the first step of an episode: the shadow is built from the fp32 tensor dyn_in
+ * inside the launch (see tap_mask_step_first). */
+int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                         int update_rows, const float *dyn_in, const float *static_, int static_rows,
+                         const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
+                         float *dyn_out, float *current_out, float *mask_out, float *feature_out,
+                         float *ratio_out, int32_t *nonbinary_out, int flags, void *stream);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,11 @@ four placement families (LB_GREEDY 2D/3D, MACS 2D/3D), every env compared with t
 (positions, stable flags, final height-map, fp64 ratio) and the number of flagged containers compared
 with the number of envs in which the reference would raise.
 
-    python scripts/stress_parity.py 3000        # round 1: 93.6 M env-steps, 0 mismatching envs
+    python scripts/stress_parity.py 3000 [out.json]   # round 1: 93.6 M env-steps, 0 mismatching envs
+
+Prints one CASE line per configuration that disagrees and a final JSON summary (also written to out.json):
+configurations, env-steps, mismatching envs, envs the oracle flags (the reference raises there) and whether
+the library flagged the same number.
 """
 import os, sys, time, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,7 +38,8 @@ def one(cs, n, reward, strategy, B, lo, hi, seed, feat="diff"):
     except Exception as e:
         flagged = -2
     return int(bad.sum()), int((~good).sum()), flagged
-t0 = time.time(); total = 0; nbad = 0
+t0 = time.time(); total = 0; nbad = 0; nflag_mismatch = 0; noracle_err = 0
+fam = {}
 cases = []
 for seed in range(int(sys.argv[1])):
     rs = np.random.RandomState(1000 + seed)
@@ -56,7 +61,17 @@ for seed in range(int(sys.argv[1])):
     B = 2048
     feat = str(rs.choice(["diff", "zero", "full"]))
     b, ne, fl = one(cs, n, reward, strat, B, 1, hi, seed, feat)
-    total += B * n; nbad += b
+    total += B * n; nbad += b; noracle_err += ne
+    f = fam.setdefault(("MACS" if strat == "MACS" else "LB_GREEDY") + (" 3D" if len(cs) == 3 else " 2D"), dict(configurations=0, env_steps=0, mismatching_envs=0))
+    f["configurations"] += 1; f["env_steps"] += B * n; f["mismatching_envs"] += b
     if b or (fl != ne and not (ne == 0 and fl == 0)):
+        nflag_mismatch += int(fl != ne)
         print("CASE", cs, n, reward, strat, "hi", hi, "mismatch", b, "oracle-err", ne, "flagged", fl)
-print("env-steps checked %d, mismatching envs %d, %.0f s" % (total, nbad, time.time() - t0))
+import json
+summary = dict(script="scripts/stress_parity.py", configurations=int(sys.argv[1]), envs_per_configuration=2048, env_steps=total,
+               mismatching_envs=nbad, envs_where_the_reference_raises=noracle_err,
+               configurations_with_a_different_flagged_count=nflag_mismatch, families=fam, seconds=round(time.time() - t0, 1),
+               compared="positions, stable flags, final height-map, fp64 calc_ratio (bit pattern) per env; flagged-container count")
+print(json.dumps(summary))
+if len(sys.argv) > 2:
+    json.dump(summary, open(sys.argv[2], "w"), indent=1)

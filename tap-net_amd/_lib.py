@@ -73,6 +73,9 @@ _PROTOS = {
     "tap_mask_step": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_dyn_bits": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tap_mask_step_bits": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tap_mask_step_first": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "tap_transition_first": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
+                                  _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tap_transition_bits": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _i, _vp]),
 }

@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_bits(int B, int nR, int rows,
 // given); NC == 0 = the generic
 // element-wise path, which also serves tap_update_mask (no copy) and tap_update_dynamic without a
 // shadow.
-template <int NC>
+// MODE: 0 = fp32 copy with the column-sum shadow (or the generic path), 1 = bit shadow, 2 = first step
+template <int NC, int MODE>
 __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
 {
     extern __shared__ float mask_lds[];
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     if (env >= a.B) return;
     if (NC > 0) {
         const bool on[1] = {true};
-        if (a.bits_in) stream_wave_bits<1, (NC > 0 ? NC : 1)>(a, env, lane, on);
+        if (MODE == 1) stream_wave_bits<1, (NC > 0 ? NC : 1), false>(a, env, lane, on);
+        else if (MODE == 2) stream_wave_bits<1, (NC > 0 ? NC : 1), true>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         else stream_wave_fast<1, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         return;
     }
@@ -97,12 +99,17 @@ static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)
     const int grid = (a.B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)ENVS_PER_BLOCK * 3 * a.nR * sizeof(float);
+    const int mode = a.bits_in ? 1 : mask_builds_bits(a) ? 2 : 0;
+#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_mask_step<NC_, M_>), dim3(grid), dim3(TAP_BLOCK), LDS_, st, a)
+#define TAP_LAUNCH_M(NC_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, lds); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, lds); else TAP_LAUNCH_T(NC_, 0, lds); } while (0)
     switch (mask_fast_path_cols(a)) {
-    case 1: hipLaunchKernelGGL(k_mask_step<1>, dim3(grid), dim3(TAP_BLOCK), lds, st, a); break;
-    case 2: hipLaunchKernelGGL(k_mask_step<2>, dim3(grid), dim3(TAP_BLOCK), lds, st, a); break;
-    case 4: hipLaunchKernelGGL(k_mask_step<4>, dim3(grid), dim3(TAP_BLOCK), lds, st, a); break;
-    default: hipLaunchKernelGGL(k_mask_step<0>, dim3(grid), dim3(TAP_BLOCK), 0, st, a); break;
+    case 1: TAP_LAUNCH_M(1); break;
+    case 2: TAP_LAUNCH_M(2); break;
+    case 4: TAP_LAUNCH_M(4); break;
+    default: TAP_LAUNCH_T(0, 0, 0); break;
     }
+#undef TAP_LAUNCH_M
+#undef TAP_LAUNCH_T
     TAP_LAUNCH_CHECK(ctx, "k_mask_step");
     return TAP_OK;
 }
@@ -157,6 +164,24 @@ extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, i
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_bits arguments");
     MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};
+    if (!mask_bits_ok(a))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+    return launch_mask_step(ctx, a, (hipStream_t)stream);
+}
+
+extern "C" int tap_mask_step_first(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
+                                   const float *dyn_in, const float *static_, int static_rows, const int64_t *ptr,
+                                   const float *mask_in, unsigned long long *bits_out, float *dyn_out,
+                                   float *current_out, float *mask_out, int32_t *nonbinary_out, void *stream)
+{
+    int rc = check_shape(ctx, B, n, n * R, rows);
+    if (rc) return rc;
+    if (B == 0) return TAP_OK;
+    if (!dyn_in || !bits_out || (ptr && (!static_ || static_rows < 1)) || update_rows < 0 || update_rows > 3 ||
+        (!ptr && update_rows != 0) || dyn_in == dyn_out)
+        return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_first arguments");
+    MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                  mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out};
     if (!mask_bits_ok(a))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
     return launch_mask_step(ctx, a, (hipStream_t)stream);

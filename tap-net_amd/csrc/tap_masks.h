@@ -20,7 +20,21 @@ struct MaskArgs {
     // dynamic[b, r, j] != 0.  When bits_in is set the step never reads dyn_in or the colsum shadow.
     const unsigned long long *bits_in;
     unsigned long long *bits_out;
+    // bits_in null + dyn_in + bits_out set: the FIRST step on a fresh fp32 tensor -- the shadow is built from
+    // dyn_in inside the step (one read of the slab); *nonbinary is incremented by the number of elements that
+    // are neither 0 nor 1 (the shadow, and the step's outputs, are only valid when it stays 0)
+    int *nonbinary;
 };
+
+__host__ __device__ __forceinline__ bool mask_builds_bits(const MaskArgs &a) { return !a.bits_in && a.bits_out && a.dyn_in; }
+
+// LDS hand-off between lanes of ONE wavefront (same as tap_wave_lds_sync in tap_place.h)
+__device__ __forceinline__ void tap_wave_lds_sync_m()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // 16-byte store of a tensor this kernel will not touch again (nontemporal: measured +9 % on the
 // write-bound bit-shadow step at B = 8192)
@@ -226,17 +240,84 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
 // comes out of the row-0 registers by shuffle, as above.  Lane (rsub, c4) = lane / (nR/4), lane %
 // (nR/4) keeps four column words and writes the float4 of rows rsub, rsub + 64/(nR/4), ...: a wave
 // store instruction covers whole consecutive rows.  Requirements: nR % 4 == 0, nR <= 64*NC, rows <= 64.
-template <int NS, int NC>
-__device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS])
+// First step of an episode (mask_builds_bits): the column words come from the fp32 slab instead of a stored
+// shadow.  Lane (rsub, c4) reads the float4 of rows rsub, rsub + RP, ... (the mapping it writes with, all
+// loads in flight together), packs "element != 0" into four partial words and ORs them into a wave-private
+// LDS tile of nR words (ds_or_b64); after the wave-level hand-off every lane picks up the words it needs.
+template <int NS>
+__device__ __forceinline__ void stream_build_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
+                                                  unsigned long long *tile /* NS * nR words */)
+{
+    typedef unsigned long long u64;
+    const int nR = a.nR, C4 = nR >> 2, rows = a.rows;
+    const int rsub = lane / C4, c4 = lane - rsub * C4, RP = 64 / C4;
+    for (int i = lane; i < NS * nR; i += 64) tile[i] = 0ull;
+    tap_wave_lds_sync_m();
+    int bad = 0;
+    // rows <= 64 and RP >= 1: at most 64 / RP row groups; the common shapes (30 rows: RP = 12 or 4) need 3 or 8
+    // loads per lane and slab -- all of a wave's loads (both slabs) are issued before the first is used
+    constexpr int U = 4;
+    for (int r0 = rsub; r0 < rows; r0 += U * RP) {
+        float4 v[NS][U];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float4 *src = reinterpret_cast<const float4 *>(a.dyn_in + (size_t)(senv0 + (on[k] ? k : 0)) * rows * nR) + c4;
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[k][u] = src[(size_t)min(r0 + u * RP, rows - 1) * C4];
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            unsigned lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * RP;
+                if (r >= rows || rsub >= RP || !on[k]) continue;
+                const float e[4] = {v[k][u].x, v[k][u].y, v[k][u].z, v[k][u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned nz = e[q] != 0.f;
+                    bad += (nz && e[q] != 1.f);
+                    if (r < 32) lo[q] |= nz << r; else hi[q] |= nz << (r - 32);
+                }
+            }
+            if (on[k] && rsub < RP) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u64 word = ((u64)hi[q] << 32) | lo[q];
+                    if (word) atomicOr(&tile[k * nR + c4 * 4 + q], word);
+                }
+            }
+        }
+    }
+    if (a.nonbinary) {
+        const unsigned long long any = __ballot(bad != 0);
+        if (any) {                                               // rare: not a 0/1 tensor
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+            if (lane == 0) atomicAdd(a.nonbinary, bad);
+        }
+    }
+    tap_wave_lds_sync_m();
+}
+
+// BUILD: the words come from the wave's LDS tile (first step, mask_builds_bits) instead of a.bits_in; a
+// compile-time switch so that neither form reads through a generic pointer.
+template <int NS, int NC, bool BUILD = false>
+__device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
+                                                 float *lds = nullptr)
 {
     typedef unsigned long long u64;
     const int nR = a.nR, C4 = nR >> 2, rows = a.rows;
     const int rsub = lane / C4, c4 = lane - rsub * C4, RP = 64 / C4;
     const bool lane_on = rsub < RP;
+    constexpr bool build = BUILD;
+    u64 *tile = reinterpret_cast<u64 *>(lds);
     long p[NS];
     float row0[NS][NC], keep[NS][NC];
     u64 bj[NS][NC];
     ulonglong2 w[NS][2];
+    // every small input is requested up front (in the first-step form: before the slab is read, so the
+    // step still has one memory round trip)
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int env = senv0 + k;
@@ -247,12 +328,30 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
             const bool ok = on[k] && j < nR;
             row0[k][c] = (ok && a.static_) ? a.static_[(size_t)env * a.static_rows * nR + j] : 0.f;
             keep[k][c] = ok ? (a.mask_in ? a.mask_in[(size_t)env * nR + j] : 1.f) : 0.f;
-            bj[k][c] = ok ? a.bits_in[(size_t)env * nR + j] : 0ull;
         }
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + c4 * 4);
+    }
+    if (BUILD) stream_build_bits<NS>(a, senv0, lane, on, tile);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int env = senv0 + k;
+        const size_t wbase = build ? (size_t)k * nR : (size_t)env * nR;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            const bool ok = on[k] && j < nR;
+            if (BUILD) bj[k][c] = ok ? tile[wbase + j] : 0ull;
+            else bj[k][c] = ok ? a.bits_in[wbase + j] : 0ull;
+        }
         const bool ok = on[k] && lane_on;
-        w[k][0] = ok ? src[0] : make_ulonglong2(0, 0);
-        w[k][1] = ok ? src[1] : make_ulonglong2(0, 0);
+        if (BUILD) {
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(tile + wbase + c4 * 4);
+            w[k][0] = ok ? src[0] : make_ulonglong2(0, 0);
+            w[k][1] = ok ? src[1] : make_ulonglong2(0, 0);
+        } else {
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + wbase + c4 * 4);
+            w[k][0] = ok ? src[0] : make_ulonglong2(0, 0);
+            w[k][1] = ok ? src[1] : make_ulonglong2(0, 0);
+        }
     }
     const u64 nmask = (a.n >= 64) ? ~0ull : ((1ull << a.n) - 1ull);
 #pragma unroll
@@ -307,15 +406,16 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
 // the bit shadow needs 16-byte rows of words and float4 rows
 inline bool mask_bits_ok(const MaskArgs &a)
 {
-    return a.bits_in && (a.ptr == nullptr || a.static_ != nullptr) && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 && a.rows <= 64 &&
-           (reinterpret_cast<uintptr_t>(a.dyn_out) % 16 == 0) &&
+    return (a.bits_in || mask_builds_bits(a)) && (a.ptr == nullptr || a.static_ != nullptr) && (a.nR % 4 == 0) &&
+           a.nR <= 256 && a.rows >= 1 && a.rows <= 64 &&
+           ((reinterpret_cast<uintptr_t>(a.dyn_out) | reinterpret_cast<uintptr_t>(a.dyn_in)) % 16 == 0) &&
            ((reinterpret_cast<uintptr_t>(a.bits_in) | reinterpret_cast<uintptr_t>(a.bits_out)) % 16 == 0);
 }
 
 // columns per lane the fast path needs: 1, 2 or 4; 0 = use the generic element-wise path
 inline int mask_fast_path_cols(const MaskArgs &a)
 {
-    if (a.bits_in) return a.nR <= 64 ? 1 : a.nR <= 128 ? 2 : 4; // mask_bits_ok checked by the caller
+    if (a.bits_in || mask_builds_bits(a)) return a.nR <= 64 ? 1 : a.nR <= 128 ? 2 : 4; // mask_bits_ok checked by the caller
     const bool ok = a.dyn_out && a.ptr && a.static_ && a.cs_in && (a.nR % 4 == 0) && a.nR <= 256 && a.rows >= 1 &&
                     ((reinterpret_cast<uintptr_t>(a.dyn_in) | reinterpret_cast<uintptr_t>(a.dyn_out)) % 16 == 0);
     return !ok ? 0 : a.nR <= 64 ? 1 : a.nR <= 128 ? 2 : 4;

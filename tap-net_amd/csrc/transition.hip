@@ -32,14 +32,16 @@ struct TransArgs {
 
 // ---- a stream wave: out-of-place copy of SPW consecutive slabs with the chosen rows cleared
 //      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
-template <int SPW, int NC>
+// MODE: 0 = fp32 copy with the column-sum shadow, 1 = on the bit shadow, 2 = first step (shadow built in the launch)
+template <int SPW, int NC, int MODE>
 __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
 {
     bool on[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
     if (NC > 0) {
-        if (m.bits_in) stream_wave_bits<SPW, (NC > 0 ? NC : 1)>(m, senv0, lane, on);
+        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false>(m, senv0, lane, on, lds);
+        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true>(m, senv0, lane, on, lds);
         else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         return;
     }
@@ -73,7 +75,7 @@ template <int G, int SW> struct TransGeom {
     static constexpr int THREADS = 64 * (ENV_WAVES + STREAM_WAVES);
 };
 
-template <int D, int G, int NC, int SW>
+template <int D, int G, int NC, int SW, int MODE>
 __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TransArgs a)
 {
     using Geo = TransGeom<G, SW>;
@@ -85,7 +87,7 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     const int env_base = blockIdx.x * EPB;
 
     if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, NC>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+        trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
         return;
     }
@@ -98,7 +100,7 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
 }
 
 // ---- the same fusion for MACS / MUL 2D (tap_macs.h): G = 8/16 lanes per env ---------------------
-template <int G, int NC>
+template <int G, int NC, int MODE>
 __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(TransArgs a)
 {
     using Geo = TransGeom<G, 4>;
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
     const int env_base = blockIdx.x * EPB;
     const int B = a.s.d.B, W = a.s.d.W, H = a.s.d.H;
     if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, NC>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+        trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
         return;
     }
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
 }
 
 // ---- and for MACS / MUL 3D (tap_macs3.h): G = 8..64 lanes per env --------------------------------
-template <int G, int NC>
+template <int G, int NC, int MODE>
 __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3(TransArgs a)
 {
     using Geo = TransGeom<G, 4>;
@@ -194,7 +196,7 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
     if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, NC>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
+        trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
         return;
     }
@@ -212,12 +214,17 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
                        (size_t)EPB * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
     if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
+    const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
+#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
-    case 1: hipLaunchKernelGGL((k_transition_macs3<G, 1>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((k_transition_macs3<G, 2>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((k_transition_macs3<G, 4>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_transition_macs3<G, 0>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 1: TAP_LAUNCH_M(1, lds); break;
+    case 2: TAP_LAUNCH_M(2, lds); break;
+    case 4: TAP_LAUNCH_M(4, lds); break;
+    default: TAP_LAUNCH_T(0, 0, lds); break;
     }
+#undef TAP_LAUNCH_M
+#undef TAP_LAUNCH_T
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs3");
     return TAP_OK;
 }
@@ -232,12 +239,17 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
                        (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max, a.s.d.W) * sizeof(int);
     if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
+    const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
+#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition_macs<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
-    case 1: hipLaunchKernelGGL((k_transition_macs<G, 1>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((k_transition_macs<G, 2>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((k_transition_macs<G, 4>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_transition_macs<G, 0>), dim3(grid), dim3(THREADS), lds, st, a); break;
+    case 1: TAP_LAUNCH_M(1, lds); break;
+    case 2: TAP_LAUNCH_M(2, lds); break;
+    case 4: TAP_LAUNCH_M(4, lds); break;
+    default: TAP_LAUNCH_T(0, 0, lds); break;
     }
+#undef TAP_LAUNCH_M
+#undef TAP_LAUNCH_T
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs");
     return TAP_OK;
 }
@@ -249,12 +261,17 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     const int grid = (a.s.d.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
+    const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
+#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
-    case 1: hipLaunchKernelGGL((k_transition<D, G, 1, SW>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((k_transition<D, G, 2, SW>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((k_transition<D, G, 4, SW>), dim3(grid), dim3(THREADS), lds, st, a); break;
-    default: hipLaunchKernelGGL((k_transition<D, G, 0, SW>), dim3(grid), dim3(THREADS), 0, st, a); break;
+    case 1: TAP_LAUNCH_M(1, lds); break;
+    case 2: TAP_LAUNCH_M(2, lds); break;
+    case 4: TAP_LAUNCH_M(4, lds); break;
+    default: TAP_LAUNCH_T(0, 0, 0); break;
     }
+#undef TAP_LAUNCH_M
+#undef TAP_LAUNCH_T
     TAP_LAUNCH_CHECK(ctx, "k_transition");
     return TAP_OK;
 }
@@ -324,6 +341,26 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
     a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                    mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};
+    if (!mask_bits_ok(a.m))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+    return transition_dispatch(ctx, d, a, stream);
+}
+
+extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                    int update_rows, const float *dyn_in, const float *static_, int static_rows,
+                                    const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
+                                    float *dyn_out, float *current_out, float *mask_out, float *feature_out,
+                                    float *ratio_out, int32_t *nonbinary_out, int flags, void *stream)
+{
+    if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
+    TransArgs a = {};
+    int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
+                               current_out, mask_out, feature_out, ratio_out, flags, a);
+    if (rc) return rc;
+    if (!dyn_in || !bits_out || dyn_in == dyn_out)
+        return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
+    a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                   mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out};
     if (!mask_bits_ok(a.m))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);

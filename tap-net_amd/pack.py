@@ -249,6 +249,28 @@ def _mask_step_bits_raw(device, B, n, R, rows, update_rows, bits_in, st, st_rows
             _lib.stream_of(device)), c)
 
 
+def first_shadow_and_mask(dynamic, blocks_num, counter=None):
+    """Bit shadow AND initial mask (model.py:297-307) of a fresh 0/1 ``dynamic`` in one launch that reads the
+    tensor once (tap_mask_step_first, ptr = NULL) -> (bits, current_mask, mask).  The count of elements that
+    are neither 0 nor 1 goes to ``counter`` (default: the deferred per-device counter check_binary() reads)."""
+    dyn = _f32c(dynamic)
+    B, rows, nR = dyn.shape
+    dev = _lib.resolve_device(dyn.device)
+    if counter is None:
+        counter = _deferred.get(dev.index)
+        if counter is None:
+            counter = _deferred[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+    bits = torch.empty(B, nR, dtype=torch.int64, device=dev)
+    cur = torch.empty(B, nR, dtype=torch.float32, device=dev)
+    mask = torch.empty(B, nR, dtype=torch.float32, device=dev)
+    c = _lib.ctx(dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().tap_mask_step_first(
+            c, B, blocks_num, nR // blocks_num, rows, 0, _lib.ptr(dyn), None, 0, None, None, _lib.ptr(bits), None,
+            _lib.ptr(cur), _lib.ptr(mask), _lib.ptr(counter), _lib.stream_of(dev)), c)
+    return bits, cur, mask
+
+
 def bits_supported(rows, nR):
     """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_mask_step_bits)."""
     return rows <= 64 and nR % 4 == 0 and nR <= 256
@@ -288,8 +310,14 @@ class MaskStepper(object):
         self.n = self.nR // self.R
         self.update_rows = _UPDATE_ROWS[input_type]
         self.bits, self.colsum, self.nonbinary = None, None, False
+        first = None
         if isinstance(bits, torch.Tensor):               # a shadow the caller already holds (rolling windows)
             self.bits = bits
+        elif (bits is not False and _binary_mode == 'trust' and _bits_state(dynamic) is None and
+              bits_supported(self.rows, self.nR)):
+            first = first_shadow_and_mask(self.dynamic, self.n)   # shadow + initial mask: one read, no host sync
+            self.bits = first[0]
+            _bits_put(dynamic, self.bits)
         else:
             st = _bits_state(dynamic, build=True)
             if isinstance(st, torch.Tensor) and bits is not False:
@@ -300,7 +328,10 @@ class MaskStepper(object):
                              "nR <= 256 and only 0/1 values)")
         if self.bits is None:                            # the column sums are only needed without the shadow
             self.colsum = dynamic_colsum(self.dynamic, self.n)
-        self.current_mask, self.mask = initial_mask(self.dynamic, self.n, bits=self.bits)
+        if first is not None:
+            self.current_mask, self.mask = first[1], first[2]
+        else:
+            self.current_mask, self.mask = initial_mask(self.dynamic, self.n, bits=self.bits)
 
     def _check_step_args(self, ptr, dyn_out):
         if tuple(ptr.shape) != (self.B,):
