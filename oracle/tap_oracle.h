@@ -164,6 +164,33 @@ int orc_rolling_window(orc_rolling *r, float *static_out, float *dynamic_out, in
 /* InitialContainer.remove_block(sub_graph_nodes[local_index]) (generate.py:1824-1835) */
 void orc_rolling_remove(orc_rolling *r, int local_index);
 
+/* ---- PPSG: perfect-packing instances (generate.py:17-301); see the section comment in tap_oracle.c ---- */
+typedef struct orc_rng orc_rng;
+/* word source = an explicit 32-bit stream (words recorded from numpy's RandomState: the pin) ... */
+orc_rng *orc_rng_words(const uint32_t *words, int64_t n);
+/* ... or the counter generator shared with the HIP kernels */
+orc_rng *orc_rng_counter(uint64_t key);
+uint64_t orc_rng_key(uint64_t seed, uint64_t a, uint64_t b, uint64_t c);
+void orc_rng_free(orc_rng *r);
+int64_t orc_rng_consumed(const orc_rng *r);
+int orc_rng_exhausted(const orc_rng *r);
+/* BPP_Generator_3D (generate.py:232-301), one call: blocks, positions (n,3); -> 1 if every side is in
+ * [min_size, max_size) (check_all_blocks_size, generate.py:41-53), 0 if not */
+int orc_bpp3d(orc_rng *rng, int n, const int32_t *gt_size, int min_size, int max_size,
+              int32_t *blocks, int32_t *positions);
+/* generate.py:108-158 for a proposed layout order: hard LB_GREEDY packing, all stable, removable in reverse */
+int orc_ppsg_try_layout(int n, const int32_t *init_size, int arm_size, const int32_t *blocks, int input_simple,
+                        int32_t *positions_out);
+/* generate_blocks_with_GT (generate.py:17-161), block_dim 3 */
+int orc_generate_blocks_with_gt(orc_rng *rng, int n, const int32_t *gt_size, const int32_t *init_size,
+                                int arm_size, int min_size, int max_size, int input_simple, int allow_rot,
+                                int64_t max_bpp, int32_t *blocks_out, int32_t *positions_out, int64_t *stats);
+/* the pieces as the HIP kernels key their counter streams (tap_ppsg_gt / tap_ppsg_order) */
+int64_t orc_ppsg_gt(uint64_t seed, int64_t instance, int gen, int S, int ns, int W, const int32_t *heights,
+                    int min_size, int max_size, int64_t max_attempts, int32_t *gt_blocks, int32_t *gt_positions);
+int orc_ppsg_order(uint64_t seed, int64_t instance, int gen, int trial, int n, const int32_t *gt_size,
+                   const int32_t *gt_blocks, const int32_t *gt_positions, int32_t *blocks_out);
+
 /* ---- precedence tensors (pack.py:276-376, model.py:297-307) ---- */
 
 /* OpenMP threads of the three batched drivers below (timing only; results do not depend on it) */

@@ -16,6 +16,7 @@ Fixtures:
   reward_tour.npz                    pack.reward on those tours
   kat.npz                            hand-checkable known answers
   rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
+  ppsg3d.npz                         generate.BPP_Generator_3D / generate_blocks_with_GT (3D) under recorded seeds
   ppsg_2d.npz                        (--only ppsg) 64 instances of the reference's PPSG generator + MACS traces over them
 """
 import argparse
@@ -258,6 +259,62 @@ def make_ppsg(tools, pack, src=None):
     save("ppsg_2d.npz", static=static, dynamic=dynamic, **files, **pack_cases(cases))
 
 
+def make_ppsg3d(pack, generate):
+    """The reference's 3D perfect-packing generator under recorded seeds:
+
+    * `bpp_*`: single calls of generate.BPP_Generator_3D(n, gt_size, [1, 5]) after np.random.seed(seed), for a
+      spread of (n, gt_size), accepted or not -> blocks, positions;
+    * `gt_*`: whole generate.generate_blocks_with_GT(n, gt_size, [7, 7, 50], 1, [1, 5], 'bot', 0) runs after
+      np.random.seed(seed) -> its five return values, laid out as pack.create_dataset_gt writes them and read
+      back through the reference's PACKDataset (static, dynamic), plus blocks / positions in layout order.
+
+    The functions draw from numpy's global RandomState; a test re-creates the same MT19937 word stream with
+    numpy (RandomState(seed)._bit_generator.random_raw) and feeds it to the oracle's restatement, which must
+    then make the same decisions draw for draw.  Only seeds, parameters and outputs are stored."""
+    out = {}
+    bpp = []
+    k = 0
+    for n, gt in ((2, [5, 5, 1]), (3, [5, 5, 2]), (6, [5, 5, 4]), (10, [5, 5, 6]), (10, [5, 5, 7]), (12, [6, 4, 8]),
+                  (20, [5, 5, 12]), (50, [5, 5, 31]), (64, [7, 7, 20])):
+        for seed in range(40 if n <= 12 else 12):
+            np.random.seed(1000 * n + seed)
+            blocks, positions, _ = generate.BPP_Generator_3D(n, list(gt), [1, 5])
+            out["bpp%d_blocks" % k] = blocks.astype(np.int16)
+            out["bpp%d_positions" % k] = positions.astype(np.int16)
+            bpp.append((n, gt[0], gt[1], gt[2], 1000 * n + seed))
+            k += 1
+    out["bpp_cases"] = np.asarray(bpp, dtype=np.int64)
+    # accepted perfect packings by rejection, as generate_blocks_with_GT's first loop finds them
+    full = []
+    k = 0
+    tmp = tempfile.mkdtemp()
+    for n, gt in ((6, [5, 5, 4]), (8, [5, 5, 5]), (10, [5, 5, 6]), (10, [5, 5, 7])):
+        for seed in range(6):
+            sd = 77000 + 100 * n + 10 * gt[2] + seed
+            np.random.seed(sd)
+            rb, pos, dm, small, large = generate.generate_blocks_with_GT(n, list(gt), [7, 7, 50], 1, [1, 5], "bot", 0)
+            d = os.path.join(tmp, "gt%d" % k) + "/"
+            os.makedirs(d)
+            with open(d + "blocks.txt", "w") as fb, open(d + "dep_small.txt", "w") as fs, open(d + "dep_large.txt", "w") as fl:
+                for r in range(len(rb)):                       # pack.py:536-539
+                    fb.write(" ".join(str(int(v)) for v in rb[r]) + "\n")
+                    fs.write(" ".join(str(int(v)) for v in small[r]) + "\n")
+                    fl.write(" ".join(str(int(v)) for v in large[r]) + "\n")
+            open(d + "pos.txt", "w").write(" ".join(str(int(v)) for v in pos) + "\n")
+            open(d + "dep_move.txt", "w").write(" ".join(str(int(v)) for v in dm) + "\n")
+            open(d + "container.txt", "w").write(" ".join("0" for _ in range(n)) + "\n")
+            ds = pack.PACKDataset(d, n, 1, 12345, "bot", "diff", True, 5, unit=1)
+            out["gt%d_static" % k] = ds.static.detach().numpy()[0].astype(np.int8)
+            out["gt%d_dynamic" % k] = ds.dynamic.detach().numpy()[0].astype(np.int8)
+            out["gt%d_blocks" % k] = np.asarray(rb[0]).reshape(3, n).T.astype(np.int16)   # rotation 0, layout order
+            out["gt%d_positions" % k] = np.asarray(pos).reshape(3, n).T.astype(np.int16)
+            full.append((n, gt[0], gt[1], gt[2], sd))
+            k += 1
+            print("ppsg3d gt case", k, n, gt, flush=True)
+    out["gt_cases"] = np.asarray(full, dtype=np.int64)
+    save("ppsg3d.npz", **out)
+
+
 def make_masks(pack, D, static, dynamic):
     """Random feasible action tapes through the reference's update_dynamic / update_mask."""
     import torch
@@ -428,6 +485,7 @@ def main():
     if want("macs2d"): make_macs2d(tools)
     if want("macs3d"): make_macs3d(tools)
     if args.only and "ppsg" in args.only: make_ppsg(tools, pack, args.ppsg_dir)   # slow: only on request
+    if want("ppsg3d"): make_ppsg3d(pack, generate)
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)

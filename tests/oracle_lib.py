@@ -76,6 +76,25 @@ def lib():
         L.orc_rolling_free.argtypes = [C.c_void_p]
         L.orc_rolling_window.argtypes = [C.c_void_p] * 4
         L.orc_rolling_remove.argtypes = [C.c_void_p, C.c_int]
+        L.orc_rng_words.restype = C.c_void_p
+        L.orc_rng_words.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_rng_counter.restype = C.c_void_p
+        L.orc_rng_counter.argtypes = [C.c_uint64]
+        L.orc_rng_key.restype = C.c_uint64
+        L.orc_rng_key.argtypes = [C.c_uint64] * 4
+        L.orc_rng_free.argtypes = [C.c_void_p]
+        L.orc_rng_consumed.restype = C.c_int64
+        L.orc_rng_consumed.argtypes = [C.c_void_p]
+        L.orc_rng_exhausted.argtypes = [C.c_void_p]
+        L.orc_bpp3d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_ppsg_try_layout.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_generate_blocks_with_gt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                  C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ppsg_gt.restype = C.c_int64
+        L.orc_ppsg_gt.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                  C.c_int64, C.c_void_p, C.c_void_p]
+        L.orc_ppsg_order.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_int]
         L.orc_initial_mask.argtypes = [C.c_int] * 4 + [C.c_void_p] * 2
         L.orc_update_dynamic.argtypes = [C.c_int] * 6 + [C.c_void_p] * 4
@@ -339,3 +358,81 @@ class Rolling:
 
     def remove(self, local_index):
         lib().orc_rolling_remove(self._h, int(local_index))
+
+
+# ---- PPSG (generate.py:17-301) -------------------------------------------------------------------------
+
+def numpy_mt_words(seed, count):
+    """The 32-bit words numpy's legacy RandomState(seed) hands out, in order (what np.random.* consumes after
+    np.random.seed(seed)): numpy's MT19937, not reference code."""
+    return np.random.RandomState(int(seed))._bit_generator.random_raw(int(count)).astype(np.uint32)
+
+
+class Rng:
+    """Word source for the PPSG restatement: an explicit stream (``words``) or the counter generator (``key``)."""
+
+    def __init__(self, words=None, key=None):
+        self._words = None if words is None else np.ascontiguousarray(words, dtype=np.uint32)
+        self._h = (lib().orc_rng_words(_p(self._words), len(self._words)) if words is not None
+                   else lib().orc_rng_counter(C.c_uint64(int(key))))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_rng_free(self._h)
+            self._h = None
+
+    @property
+    def consumed(self):
+        return lib().orc_rng_consumed(self._h)
+
+    @property
+    def exhausted(self):
+        return bool(lib().orc_rng_exhausted(self._h))
+
+
+def rng_key(seed, a, b, c):
+    return int(lib().orc_rng_key(int(seed), int(a), int(b), int(c)))
+
+
+def bpp3d(rng, n, gt_size, size_range=(1, 5)):
+    gt = np.ascontiguousarray(gt_size, dtype=np.int32)
+    blocks, pos = np.zeros((n, 3), np.int32), np.zeros((n, 3), np.int32)
+    rc = lib().orc_bpp3d(rng._h, n, _p(gt), int(size_range[0]), int(size_range[1]), _p(blocks), _p(pos))
+    return rc, blocks, pos
+
+
+def ppsg_try_layout(blocks, init_size, arm_size=1, input_simple=False):
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    n = blocks.shape[0]
+    cs = np.ascontiguousarray(init_size, dtype=np.int32)
+    pos = np.zeros((n, 3), np.int32)
+    rc = lib().orc_ppsg_try_layout(n, _p(cs), arm_size, _p(blocks), int(input_simple), _p(pos))
+    return rc, pos
+
+
+def generate_blocks_with_gt(rng, n, gt_size, init_size, arm_size=1, size_range=(1, 5), input_simple=False,
+                            allow_rot=True, max_bpp=10 ** 7):
+    gt = np.ascontiguousarray(gt_size, dtype=np.int32)
+    cs = np.ascontiguousarray(init_size, dtype=np.int32)
+    blocks, pos = np.zeros((n, 3), np.int32), np.zeros((n, 3), np.int32)
+    stats = np.zeros(2, np.int64)
+    rc = lib().orc_generate_blocks_with_gt(rng._h, n, _p(gt), _p(cs), arm_size, int(size_range[0]), int(size_range[1]),
+                                           int(input_simple), int(allow_rot), int(max_bpp), _p(blocks), _p(pos), _p(stats))
+    return rc, blocks, pos, stats
+
+
+def ppsg_gt(seed, instance, gen, S, ns, W, heights, size_range=(1, 5), max_attempts=10 ** 7):
+    h = np.ascontiguousarray(heights, dtype=np.int32)
+    blocks, pos = np.zeros((S * ns, 3), np.int32), np.zeros((S * ns, 3), np.int32)
+    used = lib().orc_ppsg_gt(int(seed), int(instance), int(gen), S, ns, W, _p(h), int(size_range[0]), int(size_range[1]),
+                             int(max_attempts), _p(blocks), _p(pos))
+    return used, blocks, pos
+
+
+def ppsg_order(seed, instance, gen, trial, gt_size, gt_blocks, gt_positions):
+    gb = np.ascontiguousarray(gt_blocks, dtype=np.int32)
+    gp = np.ascontiguousarray(gt_positions, dtype=np.int32)
+    gs = np.ascontiguousarray(gt_size, dtype=np.int32)
+    out = np.zeros_like(gb)
+    rc = lib().orc_ppsg_order(int(seed), int(instance), int(gen), int(trial), gb.shape[0], _p(gs), _p(gb), _p(gp), _p(out))
+    return rc, out

@@ -200,3 +200,40 @@ def test_rolling_windows():
             assert np.array_equal(dy, z[tag + "dynamic"][t].astype(np.float32)), (i, t)
             if t < T - 1:
                 ro.remove(int(z[tag + "ptr"][t]) % meta["child"])
+
+
+def test_bpp_generator_3d_draw_for_draw():
+    """generate.BPP_Generator_3D (generate.py:232-301): fed the MT19937 words numpy's RandomState(seed) hands
+    out, the restatement must make the reference's cuts draw for draw (accepted packings or not)."""
+    z = G.load("ppsg3d.npz")
+    naccepted = 0
+    for k, (n, gx, gy, gz, seed) in enumerate(z["bpp_cases"]):
+        rng = O.Rng(words=O.numpy_mt_words(seed, 4096))
+        rc, blocks, pos = O.bpp3d(rng, int(n), [int(gx), int(gy), int(gz)])
+        assert rc >= 0 and not rng.exhausted
+        assert np.array_equal(blocks, z["bpp%d_blocks" % k]), (k, n, seed)
+        assert np.array_equal(pos, z["bpp%d_positions" % k]), (k, n, seed)
+        want_ok = bool(((z["bpp%d_blocks" % k] >= 1) & (z["bpp%d_blocks" % k] < 5)).all())
+        assert bool(rc) == want_ok
+        naccepted += rc
+    assert len(z["bpp_cases"]) > 250 and naccepted > 0
+
+
+def test_generate_blocks_with_gt_draw_for_draw():
+    """generate.generate_blocks_with_GT (generate.py:17-230), 3D: rejection loop over BPP_Generator_3D, random
+    unpacking order, random rotations, hard LB_GREEDY layout, stability and take-apart tests -- same word
+    stream in, the reference's instance out (blocks / positions in layout order, and through
+    instance_from_blocks the PACKDataset tensors the reference's own reader makes of its return values)."""
+    z = G.load("ppsg3d.npz")
+    for k, (n, gx, gy, gz, seed) in enumerate(z["gt_cases"]):
+        n = int(n)
+        rng = O.Rng(words=O.numpy_mt_words(seed, 6_000_000))
+        rc, blocks, pos, stats = O.generate_blocks_with_gt(rng, n, [int(gx), int(gy), int(gz)], [7, 7, 50])
+        assert rc == 1 and not rng.exhausted, (k, rc)
+        assert np.array_equal(blocks, z["gt%d_blocks" % k]), (k, stats)
+        assert np.array_equal(pos, z["gt%d_positions" % k]), (k, stats)
+        ok, pos2, st, dyn = O.instance_from_blocks(blocks, [7, 7, 50], 1)
+        assert ok == 1 and np.array_equal(pos2, pos)
+        assert np.array_equal(st, z["gt%d_static" % k].astype(np.float32))
+        assert np.array_equal(dyn, z["gt%d_dynamic" % k].astype(np.float32))
+    assert len(z["gt_cases"]) == 24
