@@ -698,27 +698,37 @@ def cpu_baseline_rolling(hp, budget_s=10.0):
     model, ncpu, avail = cpu_info()
     O.set_threads(1)
     done1, el1 = _timed_loop(lambda: episodes(0, V), budget_s)
-    # all cores: the per-step driver is Python, so one forked process per core over disjoint slices
+    # all cores: the per-step driver is Python, so one forked process per usable CPU, each looping over its own
+    # slice of the instances for the same wall time
     import multiprocessing as mp
-    t0 = time.perf_counter()
-    per = max(1, V // avail)
-    procs = []
     ctxm = mp.get_context("fork")
+    per = max(1, V // avail)
+    q = ctxm.Queue()
+
+    def worker(lo, hi, seconds):
+        d, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            d += episodes(lo, hi)
+        q.put(d)
+
+    t0 = time.perf_counter()
+    procs = []
     for k in range(avail):
         lo, hi = k * per, min(V, (k + 1) * per)
         if lo < hi:
-            pr = ctxm.Process(target=episodes, args=(lo, hi))
+            pr = ctxm.Process(target=worker, args=(lo, hi, budget_s / 2))
             pr.start()
-            procs.append((pr, hi - lo))
-    for pr, _ in procs:
+            procs.append(pr)
+    doneN = sum(q.get() for _ in procs)
+    for pr in procs:
         pr.join()
     elN = time.perf_counter() - t0
-    doneN = sum(c for _, c in procs) * n
     return dict(value=done1 / el1, unit="env-steps/s", cores=1, kind="port",
                 sample="%d rolling episodes of %d placements (window %d) over this run's instances and tape, %.1f s, "
                        "oracle/libtap_oracle.so single thread driven per step from Python" % (done1 // n, n, win, el1),
                 all_cores=dict(value=doneN / elN, cores=len(procs),
-                               sample="%d episodes, %.1f s, one forked process per usable CPU" % (doneN // n, elN)),
+                               sample="%d episodes, %.1f s, one forked process per usable CPU, each looping over its "
+                                      "slice of the instances" % (doneN // n, elN)),
                 cpu_model=model, cpu_count=ncpu, cpus_usable=avail)
 
 
@@ -999,8 +1009,10 @@ def main():
                 "kernel_us": dom_us, "kernel_us_how": how, "kernel_us_rocprof": tr.get("kernel_us") if tr else None,
                 "pass_us": pass_us, "launches_per_pass": launches, "event_pair_overhead_us": empty_us}
         if rolling:
-            inst = ("MIX (pack.py:67-97): envs [0,B/2) PPSG-like guillotine instances (BPP_Generator_3D semantics), "
-                    "[B/2,B) RAND; device-generated, initial container 7 wide" if hp.mix else
+            inst = ("MIX (pack.py:67-97): envs [0,B/2) perfect-packing (PPSG) instances, [B/2,B) RAND, both device-generated "
+                    "into a 7x7x250 initial container.  PPSG = generate_blocks_with_GT's steps on 5 stacked 10-block "
+                    "BPP_Generator_3D packings with the 'simple' take-apart test: the reference's own loop cannot reach "
+                    "50 blocks (its acceptance test passes < 2e-8 of 50-block cuts and 0 of 200 layouts)" if hp.mix else
                     "device-generated 50-block RAND instances (generate.generate_instances), initial container 7 wide")
         elif getattr(hp, "instances", None) == "generate":
             inst = ("RAND instances of the device-side generator (generate_blocks semantics: random blocks packed into "

@@ -187,6 +187,39 @@ int tap_precedence(tap_ctx *ctx, int B, int D, int n, const int32_t *container_s
                    const int32_t *blocks, const int32_t *positions, float *static_out,
                    float *dynamic_out, void *stream);
 
+/* ---- perfect-packing ("PPSG") instances (generate.py:17-301) -------------------------------- */
+/* Random draws are made the way numpy's RandomState makes them (random_sample, masked-rejection randint,
+ * choice(p) by searchsorted on the fp64 cumulative sum) on counter-based word streams: word i of the stream
+ * with key k = high 32 bits of splitmix64-finalise(k + i * 0x9E3779B97F4A7C15), k = key(seed, a, b, c) as
+ * csrc/ppsg.hip / oracle/tap_oracle.c define it.  ids (B,) int64 = global instance ids (nullable:
+ * instance0 + b), so any sharding generates the same instances. */
+
+/* generate.BPP_Generator_3D (generate.py:232-301) inside generate_blocks_with_GT's acceptance loop
+ * (generate.py:66-73): for every instance S slabs of ns <= 16 blocks, slab s = n - 1 guillotine cuts of a
+ * W x W x heights[b, s] box, re-drawn (attempt a = 0, 1, ...; stream key(seed, id*S + s, gen, a)) until every
+ * side is in [min_size, max_size); the slabs are stacked along z -- S = 1 is the reference's generator,
+ * S > 1 builds perfect packings of S*ns blocks, which the reference's single rejection loop cannot reach
+ * (acceptance < 2e-8 at 50 blocks).  gt_blocks_out / gt_positions_out (B, S*ns, 3) i32; attempts_out (B, S)
+ * i32 nullable (-1 = max_attempts reached, that slab is then invalid). */
+int tap_ppsg_gt(tap_ctx *ctx, int B, int S, int ns, int W, const int32_t *heights, int min_size,
+                int max_size, uint64_t seed, const int64_t *ids, int64_t instance0, int gen,
+                int64_t max_attempts, int32_t *gt_blocks_out, int32_t *gt_positions_out,
+                int32_t *attempts_out, void *stream);
+
+/* generate.py:86-105: a random order in which the perfect packing can be taken apart from the top and a
+ * random rotation per block (stream key(seed, id, gen, 1000 + trial)) -> blocks_out (B, n, 3) i32 in layout
+ * order, to be packed into the initial container with tap_pack_blocks ('C+P+S-lb-hard').  n <= 64. */
+int tap_ppsg_order(tap_ctx *ctx, int B, int n, const int32_t *gt_blocks, const int32_t *gt_positions,
+                   uint64_t seed, const int64_t *ids, int64_t instance0, int gen, int trial,
+                   int32_t *blocks_out, void *stream);
+
+/* generate.py:110-156: accept a packed layout iff every block is stable (stable (B, n) u8 of
+ * tap_pack_blocks) and the blocks can be taken out again last-packed-first (rel (B, 5, n) u64 of
+ * tap_rolling_init: nothing on top, one free side per horizontal axis; input_simple != 0 ignores the
+ * sides).  ok_out (B,) u8. */
+int tap_ppsg_check(tap_ctx *ctx, int B, int n, int input_simple, const uint64_t *rel, const uint8_t *stable,
+                   uint8_t *ok_out, void *stream);
+
 /* ---- rolling precedence windows (generate.py:1589-1839, rolling.py:589-637) ------------- */
 
 /* generate.InitialContainer.__init__: the five dependency graphs of B fully packed initial

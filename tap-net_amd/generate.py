@@ -107,3 +107,140 @@ def generate_instances(batch_size, blocks_num, block_dim, initial_container_widt
     if return_aux:
         return static, dynamic, blocks, positions
     return static, dynamic
+
+
+# ---- perfect-packing ("PPSG") instances: generate.generate_blocks_with_GT (generate.py:17-230) ---------------
+
+def height_distribution(block_dim, blocks_num, size_range, initial_container_width, target_container_width,
+                        samples=10000, seed=12345, device='cuda'):
+    """generate.generate_height_prob (generate.py:977-1041): the distribution of perfect-packing heights,
+    int(volume of a 10-block RAND instance / container bottom * blocks_num / 10) over ``samples`` accepted RAND
+    instances -- the reference reads them from its 10 000-sample validation file, here they come from the
+    device generator.  -> (prob, key) tensors, keys ascending."""
+    _, _, blocks, _ = generate_instances(samples, 10, block_dim, initial_container_width, 50, 1, size_range,
+                                         seed=seed, device=device, return_aux=True)
+    bottom = target_container_width if block_dim == 2 else target_container_width * target_container_width
+    vol = blocks.to(torch.int64).prod(dim=2).sum(dim=1)
+    key = (vol.to(torch.float64) / bottom * (blocks_num / 10)).to(torch.int64)       # generate.py:1010
+    keys, counts = torch.unique(key, return_counts=True)
+    # A box W x W x H only splits into blocks_num blocks with every side < max_size if
+    # ceil(W/(max_size-1))^(D-1) * ceil(H/(max_size-1)) <= blocks_num (pick points more than max_size-1 apart:
+    # no two share a block).  For other heights generate_blocks_with_GT's acceptance loop (generate.py:66-73)
+    # never ends -- the reference hangs there; those keys are dropped and the rest re-normalised.
+    lim = int(size_range[1]) - 1
+    per_layer = (-(-target_container_width // lim)) ** (block_dim - 1)
+    ok = (per_layer * ((keys + lim - 1) // lim) <= blocks_num) & (keys >= 1)
+    keys, counts = keys[ok], counts[ok]
+    return counts.to(torch.float64) / counts.sum(), keys
+
+
+def generate_ppsg_instances(batch_size, blocks_num, initial_container_width=7, initial_container_height=50,
+                            target_container_width=5, size_range=(1, 5), seed=12345, start=0, slab_blocks=10,
+                            heights=None, device='cuda', max_generations=50, return_stats=False, input_type='bot'):
+    """B perfect-packing instances (3D) as generate.generate_blocks_with_GT builds them (generate.py:57-161):
+    a guillotine-cut perfect packing of a target_width^2 x H box (BPP_Generator_3D + its acceptance test), a
+    random take-apart order with random rotations, the blocks packed in that order into the initial container
+    with hard LB_GREEDY, accepted when all are stable and can be taken out again in reverse; up to 20 orders
+    per perfect packing, then a new one.  -> (blocks, positions) (B, n, 3) int32 on ``device``, layout order.
+
+    blocks_num > slab_blocks: the perfect packing is blocks_num / slab_blocks stacked slabs, each cut by the
+    reference's generator (its single rejection loop accepts < 2e-8 of its draws at 50 blocks and cannot
+    produce such an instance).  Instances are keyed by global index ``start + i``: any sharding sees the same
+    ones.  ``heights`` (B, S) overrides the per-slab heights drawn from height_distribution().
+
+    ``input_type`` selects the take-apart test as the reference does (generate.py:135-141): 'simple' asks only
+    that nothing rests on a block when its turn comes; every other type ('bot') also asks for one free side per
+    horizontal axis.  Measured with the pinned restatement: the 'bot' form accepts about 1 % of the stable
+    layouts at 10 blocks and none of 200 at 20 or 50 blocks, so instances above ~10 blocks need 'simple'."""
+    import ctypes as C
+    dev = _lib.resolve_device(device)
+    n, B = int(blocks_num), int(batch_size)
+    ns = min(int(slab_blocks), n)
+    if n % ns:
+        raise ValueError("blocks_num must be a multiple of slab_blocks")
+    S, W = n // ns, int(target_container_width)
+    ids = torch.arange(start, start + B, dtype=torch.int64, device=dev)
+    if heights is None:
+        prob, keys = height_distribution(3, ns, size_range, initial_container_width, W, seed=seed, device=dev)
+        g = torch.Generator(device='cpu')
+        rows = []
+        for i in range(B):                               # keyed per instance id so shards agree
+            g.manual_seed((int(seed) * 1000003 + start + i) % (2 ** 63))
+            rows.append(torch.multinomial(prob.cpu().float(), S, replacement=True, generator=g))
+        heights = keys.cpu()[torch.stack(rows)]
+    heights = heights.to(device=dev, dtype=torch.int32).contiguous()
+    cs = initial_container(3, initial_container_width, initial_container_height)
+    c, L = _lib.ctx(dev), _lib.lib()
+    out_blocks = torch.zeros(B, n, 3, dtype=torch.int32, device=dev)
+    out_pos = torch.zeros(B, n, 3, dtype=torch.int32, device=dev)
+    done = torch.zeros(B, dtype=torch.bool, device=dev)
+    stats = dict(generations=0, layouts=0)
+    from .rolling import RollingWindows
+    for gen in range(max_generations):
+        todo = (~done).nonzero().squeeze(1)
+        m = int(todo.numel())
+        if m == 0:
+            break
+        stats['generations'] = gen + 1
+        tid, th = ids[todo].contiguous(), heights[todo].contiguous()
+        gtb = torch.empty(m, n, 3, dtype=torch.int32, device=dev)
+        gtp = torch.empty(m, n, 3, dtype=torch.int32, device=dev)
+        att = torch.empty(m, S, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.tap_ppsg_gt(c, m, S, ns, W, _lib.ptr(th), int(size_range[0]), int(size_range[1]), int(seed),
+                                     _lib.ptr(tid), 0, gen, 1 << 22, _lib.ptr(gtb), _lib.ptr(gtp), _lib.ptr(att),
+                                     _lib.stream_of(dev)), c)
+        if bool((att < 0).any()):
+            raise _lib.TapError(_lib.TAP_E_INVALID, "a perfect packing was not found within the attempt cap")
+        alive = torch.ones(m, dtype=torch.bool, device=dev)
+        for trial in range(20):                                                     # generate.py:83-87
+            sel = alive.nonzero().squeeze(1)
+            k = int(sel.numel())
+            if k == 0:
+                break
+            stats['layouts'] += k
+            blocks = torch.empty(k, n, 3, dtype=torch.int32, device=dev)
+            # named temporaries: an unnamed one is freed as soon as its pointer is taken and the next one would
+            # be handed the same memory
+            sb, sp, si = gtb[sel].contiguous(), gtp[sel].contiguous(), tid[sel].contiguous()
+            with torch.cuda.device(dev):
+                _lib.check(L.tap_ppsg_order(c, k, n, _lib.ptr(sb), _lib.ptr(sp), int(seed), _lib.ptr(si), 0, gen, trial,
+                                            _lib.ptr(blocks), _lib.stream_of(dev)), c)
+            pos, stable, rew = pack_blocks(blocks, cs)                               # generate.py:108
+            rw = RollingWindows(blocks, pos, cs, child_graph_size=1)                # the five relations (:111-112)
+            ok = torch.empty(k, dtype=torch.uint8, device=dev)
+            st8 = stable.to(torch.uint8).contiguous()
+            with torch.cuda.device(dev):
+                _lib.check(L.tap_ppsg_check(c, k, n, 1 if input_type == 'simple' else 0, _lib.ptr(rw.rel), _lib.ptr(st8),
+                                            _lib.ptr(ok), _lib.stream_of(dev)), c)
+            good = ok.bool() & ~torch.isnan(rew)
+            hit = sel[good]
+            out_blocks[todo[hit]] = blocks[good]
+            out_pos[todo[hit]] = pos[good]
+            done[todo[hit]] = True
+            alive[hit] = False
+    if not bool(done.all()):
+        raise _lib.TapError(_lib.TAP_E_INVALID, "%d PPSG instances not found in %d generations" % (int((~done).sum()), max_generations))
+    if return_stats:
+        return out_blocks, out_pos, stats
+    return out_blocks, out_pos
+
+
+def generate_mix_instances(batch_size, blocks_num, block_dim=3, initial_container_width=7, initial_container_height=50,
+                           seed=12345, start=0, device='cuda', target_container_width=5, size_range=(1, 5),
+                           input_type=None):
+    """The MIX series as PACKDataset mixes its two files (pack.py:67-97): the first half of the batch from the
+    perfect-packing generator, the second half RAND.  -> (blocks, positions) (B, n, D) int32.
+    ``input_type``: the PPSG half's take-apart test (see generate_ppsg_instances); default 'bot' up to 10
+    blocks, 'simple' above (where 'bot' accepts nothing)."""
+    if input_type is None:
+        input_type = 'bot' if int(blocks_num) <= 10 else 'simple'
+    if block_dim != 3:
+        raise ValueError("the device PPSG generator is 3D (BPP_Generator_3D)")
+    half = int(batch_size) // 2
+    pb, pp = generate_ppsg_instances(half, blocks_num, initial_container_width, initial_container_height,
+                                     target_container_width, size_range, seed=seed, start=start, device=device,
+                                     input_type=input_type)
+    _, _, rb, rp = generate_instances(int(batch_size) - half, blocks_num, block_dim, initial_container_width,
+                                      initial_container_height, 1, size_range, seed=seed, device=device, return_aux=True)
+    return torch.cat([pb, rb]).contiguous(), torch.cat([pp, rp]).contiguous()
