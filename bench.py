@@ -375,19 +375,21 @@ class RollingHotPath(HotPath):
         cs2 = None if self.bits else self.csb[2]          # the column sums are only needed without the bit shadow
         self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
                 P(rw.blocks), P(rw.rel), P(self.state), None, P(st[0]), P(self.dyn[2]), P(cs2),
-                P(self.bitb[2]), P(self.cur), None, None)
+                P(self.bitb[2] if n1 == 0 else None), P(self.cur), None, None)
         prev_ev = None
         for t in range(n1):
+            # the bit shadow is a by-product only the LAST window's full episode consumes
+            wbits = self.bitb[2] if t == n1 - 1 else None
             if self.fused_rolling:                                # placement t + window t+1: one launch
                 self._k("rolling_step", L.tap_rolling_step, self.ctx, d, P(e._state), self.n, self.nw, P(rw.blocks),
                         P(rw.rel), P(self.state), P(self.tape[t]), P(st[t & 1]), P(st[(t + 1) & 1]), P(self.dyn[2]),
-                        P(cs2), P(self.bitb[2]), P(self.cur), None, None, P(self.feat))
+                        P(cs2), P(wbits), P(self.cur), None, None, P(self.feat))
             elif not self.overlap:
                 self._k("env_step", L.tap_env_step_gather, self.ctx, d, P(e._state), P(st[t & 1]),
                         self.static.shape[1], self.nR, P(self.tape[t]), None, P(self.feat))
                 self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
                         P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
-                        P(cs2), P(self.bitb[2]), P(self.cur), None, None)
+                        P(cs2), P(wbits), P(self.cur), None, None)
             else:
                 # placement t and window t+1 on two HIP streams (measured slower, kept as an option)
                 main = torch.cuda.current_stream(self.device)
@@ -402,7 +404,7 @@ class RollingHotPath(HotPath):
                 prev_ev = ev
                 self._k("rolling_window", L.tap_rolling_window, self.ctx, self.B, self.D, self.n, self.nw,
                         P(rw.blocks), P(rw.rel), P(self.state), P(self.tape[t]), P(st[(t + 1) & 1]), P(self.dyn[2]),
-                        P(cs2), P(self.bitb[2]), P(self.cur), None, None)
+                        P(cs2), P(wbits), P(self.cur), None, None)
         if self.overlap and not self.fused_rolling:
             torch.cuda.current_stream(self.device).wait_stream(self.side)
         self.static_last = st[n1 & 1]

@@ -261,25 +261,23 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
     const u64 bit = 1ull << v, below = bit - 1ull;
     const bool isnode = v < N;
-    u64 rel[5] = {0, 0, 0, 0, 0};
-    int bdim[3] = {0, 0, 0};                         // this node's block (rotation 0)
-    if (isnode) {
-#pragma unroll
-        for (int k = 0; k < 5; ++k) rel[k] = a.rel[((size_t)inst * 5 + k) * N + v];
-#pragma unroll
-        for (int k = 0; k < D; ++k) bdim[k] = a.blocks[((size_t)inst * N + v) * D + k];
-    }
-    // (entered, window) are wave-uniform: in scalar registers the set arithmetic below costs no VALU slots
+    // Every input of the graph step is requested up front: the window state, the previous pick and each
+    // node's movement mask.  The four side masks and the block sizes are only needed for the (at most
+    // `child`) nodes of the new window and are requested once it is known, under the set-order emulation.
     auto uniform64 = [](u64 x) -> u64 {
         return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)x);
     };
-    u64 entered = uniform64(a.state[(size_t)inst * 2]), window = uniform64(a.state[(size_t)inst * 2 + 1]);
+    const u64 rel0 = isnode ? a.rel[(size_t)inst * 5 * N + v] : 0ull;
+    const u64 st_entered = a.state[(size_t)inst * 2], st_window = a.state[(size_t)inst * 2 + 1];
+    const long ptr_raw = a.remove_ptr ? (long)a.remove_ptr[inst] : 0;
+    // (entered, window) are wave-uniform: in scalar registers the set arithmetic below costs no VALU slots
+    u64 entered = uniform64(st_entered), window = uniform64(st_window);
 
     PROF(0);
     // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
     if (a.remove_ptr) {
-        long slot = (long)uniform64((u64)a.remove_ptr[inst]);
+        long slot = (long)uniform64((u64)ptr_raw);
         slot = tap_mod_col(slot, child, nRc);                        // rolling.py:632-633
         const bool hit = (window & bit) && __popcll(window & below) == slot;
         window &= ~__ballot(hit);
@@ -291,7 +289,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     u64 added = 0;
     while (count < child) {
         const u64 gmc = all & ~(entered | added);                    // nodes still in gm_copy
-        const bool free_ = isnode && (gmc & bit) && (__popcll(gmc) == 1 || (rel[0] & gmc) == 0);
+        const bool free_ = isnode && (gmc & bit) && (__popcll(gmc) == 1 || (rel0 & gmc) == 0);
         const u64 fm = __ballot(free_);
         if (fm == 0) break;
         const int need = child - count;
@@ -304,6 +302,15 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     entered |= added;   // after_nodes_list.remove (:1745) and, the window being full, decompose() (:1712-1721)
     window |= added;
     const int short_window = count != child;
+    const bool inwin = (window & bit) != 0;
+    u64 rel[5] = {rel0, 0, 0, 0, 0};
+    int bdim[3] = {0, 0, 0};                         // this node's block (rotation 0)
+    if (inwin && !short_window) {
+#pragma unroll
+        for (int k = 1; k < 5; ++k) rel[k] = a.rel[((size_t)inst * 5 + k) * N + v];
+#pragma unroll
+        for (int k = 0; k < D; ++k) bdim[k] = a.blocks[((size_t)inst * N + v) * D + k];
+    }
     tap_wave_lds_sync();
 
     PROF(1);
@@ -311,7 +318,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     if (2 * child < N) {
         if (child <= 18) { if (!short_window) pyset_order_wave(S.lst, child, S.ord, v); } // wave-uniform branch
         else if (v == 0 && !short_window) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
-    } else if (window & bit) {
+    } else if (inwin) {
         S.ord[__popcll(window & below)] = (unsigned char)v;
     }
     tap_wave_lds_sync();
@@ -328,10 +335,9 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     PROF(2);
     // (4) tensors (generate.py:1778-1822).  Window-node lanes publish their five column masks (with
     //     the :1690-1705 rule: a blocker that has not entered any window yet => the side counts as
-    //     self-blocked) by sub-graph index; then ALL 64 lanes write the tensors element-wise with
-    //     consecutive addresses, so every store instruction covers 256 contiguous bytes.
+    //     self-blocked) by sub-graph index.
     const u64 after = all & ~entered;               // after_nodes_list
-    if (window & bit) {
+    if (inwin) {
         const int midx = S.pos[v];
         S.side[0][midx] = rel[0] & window;
 #pragma unroll
@@ -353,13 +359,31 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (D == 3 && p[D - 1] == 1) return 2 + sec; // forward / backward
         return -1;                                   // up / down: empty
     };
-    // lane = column (r, cm): static, column sums, initial mask, and the column's word of `dynamic`
-    // (rows re-indexed from node ids to sub-graph order).  When the tensor fits the bit-shadow form
-    // (3*child <= 64 rows, nRc % 4 == 0, nRc <= 256) the words go through LDS and the fp32 tensor is
-    // expanded from them as in stream_wave_bits (tap_masks.h): a store instruction covers 64/(nRc/4)
-    // whole rows with 16 bytes per lane, nontemporal.  Otherwise each lane walks its column.
     const int rows = 3 * child;
     const bool packed = rows <= 64 && (nRc & 3) == 0 && nRc <= 256;
+    // The five masks of a window node re-indexed from node ids to sub-graph rows (bit rm = node ord[rm]) are
+    // the same for every rotation's column, so they are gathered ONCE per (relation, node) -- lane = (k, cm),
+    // 5 * child <= 64 lanes when child <= 12 -- instead of three times in each of the child*R column lanes.
+    const bool once = packed && 5 * child <= 64 && child <= 21;
+    unsigned *iw = reinterpret_cast<unsigned *>(&S.side[0][0]);  // re-uses the relation slots (hand-off below)
+    if (once) {
+        const int k5 = v / child, cm5 = v - k5 * child;
+        const bool on5 = v < 5 * child;
+        const u64 m = on5 ? S.side[k5][cm5] : 0ull;
+        unsigned w = 0u;
+        for (int rm = 0; rm < child; ++rm) {
+            const int node = __builtin_amdgcn_readfirstlane((int)S.ord[rm]);     // wave-uniform
+            const unsigned half = node >= 32 ? (unsigned)(m >> 32) : (unsigned)m;
+            w |= ((half >> (node & 31)) & 1u) << rm;
+        }
+        tap_wave_lds_sync();                        // every lane holds its mask: the slots may be overwritten
+        if (on5) iw[v] = w;
+        tap_wave_lds_sync();
+    }
+    // lane = column (r, cm): static, column sums, initial mask, and the column's word of `dynamic`.  When the
+    // tensor fits the bit-shadow form (3*child <= 64 rows, nRc % 4 == 0, nRc <= 256) the words go through LDS
+    // and the fp32 tensor is expanded from them as in stream_wave_bits (tap_masks.h): a store instruction
+    // covers 64/(nRc/4) whole rows with 16 bytes per lane, nontemporal.  Otherwise each lane walks its column.
     for (int col0 = 0; col0 < nRc; col0 += 64) {
         const int col = col0 + v;
         const bool oncol = col < nRc;
@@ -374,6 +398,21 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         st[col] = (float)cm;                                                      // :1795-1801
         for (int k = 0; k < D; ++k)
             st[(size_t)(1 + k) * nRc + col] = (float)(p[k] == 0 ? side_len[0] : p[k] == 1 ? side_len[1] : side_len[2]);
+        if (once) {
+            unsigned ws[3];
+#pragma unroll
+            for (int sec = 0; sec < 3; ++sec) {
+                const int k = side_of(r, sec);
+                ws[sec] = k < 0 ? 0u : iw[k * child + cm];                        // dynamic: cm = sub-graph index
+                if (a.colsum_out) a.colsum_out[((size_t)inst * 3 + sec) * nRc + col] = (float)__popc(ws[sec]);
+            }
+            if (a.cur_mask_out)                                                   // model.py:297-307
+                a.cur_mask_out[(size_t)inst * nRc + col] = (__popc(ws[1]) * __popc(ws[2]) + __popc(ws[0]) != 0) ? 0.f : 1.f;
+            const u64 w = (u64)ws[0] | ((u64)ws[1] << child) | ((u64)ws[2] << (2 * child));
+            S.cw[col] = w;
+            if (a.bits_out) a.bits_out[(size_t)inst * nRc + col] = w;
+            continue;
+        }
         u64 m[3];
         float sum[3];
 #pragma unroll
@@ -411,11 +450,19 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     tap_wave_lds_sync();
     const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
     if (rsub < RP) {
-        const u64 w0 = S.cw[c4 * 4], w1 = S.cw[c4 * 4 + 1], w2 = S.cw[c4 * 4 + 2], w3 = S.cw[c4 * 4 + 3];
-        float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
-        for (int r = rsub; r < rows; r += RP)
-            store_stream(&dst[(size_t)r * C4], make_float4(bit_as_float(w0, r), bit_as_float(w1, r),
-                                                           bit_as_float(w2, r), bit_as_float(w3, r)));
+        // rows rsub, rsub + RP, ...: the words are shifted down by rsub once, so that row i*RP sits at the
+        // wave-uniform bit i*RP and the per-row work is a bit-field extract and a convert
+        const u64 w0 = S.cw[c4 * 4] >> rsub, w1 = S.cw[c4 * 4 + 1] >> rsub, w2 = S.cw[c4 * 4 + 2] >> rsub,
+                  w3 = S.cw[c4 * 4 + 3] >> rsub;
+        float4 *dst = reinterpret_cast<float4 *>(dy) + c4 + (size_t)rsub * C4;
+        for (int q = 0; q * RP + rsub < rows; ++q) {
+            const int sh = q * RP;                                       // wave-uniform
+            const unsigned h0 = sh < 32 ? (unsigned)w0 : (unsigned)(w0 >> 32), h1 = sh < 32 ? (unsigned)w1 : (unsigned)(w1 >> 32),
+                           h2 = sh < 32 ? (unsigned)w2 : (unsigned)(w2 >> 32), h3 = sh < 32 ? (unsigned)w3 : (unsigned)(w3 >> 32);
+            const int s5 = sh & 31;
+            store_stream(&dst[(size_t)sh * C4], make_float4((float)((h0 >> s5) & 1u), (float)((h1 >> s5) & 1u),
+                                                            (float)((h2 >> s5) & 1u), (float)((h3 >> s5) & 1u)));
+        }
     }
     PROF(5);
 }
