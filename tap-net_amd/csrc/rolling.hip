@@ -182,9 +182,7 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
         // have distinct homes in the FINAL table (its size depends on n alone), every key sits at its
         // home whatever the insertion and resize history was, and the iteration order is the order of
         // the homes.  Only sets with two keys congruent modulo the table size need the emulation.
-        int fsize = 8;
-        for (int f = 1; f <= n; ++f)
-            if (f * 5 >= (fsize - 1) * 3) { int ns = 8; while (ns <= f * 4) ns <<= 1; fsize = ns; }
+        const int fsize = n < 5 ? 8 : 32;   // n <= 18: the table grows once, 8 -> 32 slots, at the fifth key
         u64 homes = 0;
         for (int k = 0; k < n; ++k) homes |= 1ull << (__builtin_amdgcn_readlane(mykey, k) & (fsize - 1));
         if (__popcll(homes) == n) {
@@ -250,89 +248,43 @@ extern "C" int tap_prof_read(unsigned int *out)
 #define PROF_BEGIN do { } while (0)
 #endif
 
+// Per-node inputs of the tensor emission: the four side masks and the block sizes, only for window nodes
+struct RollNode {
+    u64 rel[5];
+    int bdim[3];
+};
+
 template <int D>
-__device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
+__device__ __forceinline__ RollNode rolling_node_loads(const RollArgs &a, int inst, int v, bool on, u64 rel0)
 {
-    if (inst >= a.B) return;
-    PROF_BEGIN;
+    RollNode nd = {{rel0, 0, 0, 0, 0}, {0, 0, 0}};
+    if (on) {
+#pragma unroll
+        for (int k = 1; k < 5; ++k) nd.rel[k] = a.rel[((size_t)inst * 5 + k) * a.N + v];
+#pragma unroll
+        for (int k = 0; k < D; ++k) nd.bdim[k] = a.blocks[((size_t)inst * a.N + v) * D + k];
+    }
+    return nd;
+}
+
+// (4) tensors (generate.py:1778-1822) of one instance by one wavefront, lane v = node v: S.ord holds the
+//     sub-graph node order, (entered, window) the state after the graph step.  LDS = any struct with ord, pos,
+//     srt (bytes), cw (u64 per column, packed form only) and side[5][>= child] (u64).
+template <int D, class LDS>
+__device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS &S, u64 entered, u64 window,
+                                         const RollNode &nd)
+{
     const int N = a.N, child = a.child;
     constexpr int R = D == 2 ? 2 : 6;
     const int nRc = child * R;
     const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
     const u64 bit = 1ull << v, below = bit - 1ull;
-    const bool isnode = v < N;
-    // Every input of the graph step is requested up front: the window state, the previous pick and each
-    // node's movement mask.  The four side masks and the block sizes are only needed for the (at most
-    // `child`) nodes of the new window and are requested once it is known, under the set-order emulation.
-    auto uniform64 = [](u64 x) -> u64 {
-        return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
-               (unsigned)__builtin_amdgcn_readfirstlane((int)x);
-    };
-    const u64 rel0 = isnode ? a.rel[(size_t)inst * 5 * N + v] : 0ull;
-    const u64 st_entered = a.state[(size_t)inst * 2], st_window = a.state[(size_t)inst * 2 + 1];
-    const long ptr_raw = a.remove_ptr ? (long)a.remove_ptr[inst] : 0;
-    // (entered, window) are wave-uniform: in scalar registers the set arithmetic below costs no VALU slots
-    u64 entered = uniform64(st_entered), window = uniform64(st_window);
-
-    PROF(0);
-    // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
-    if (a.remove_ptr) {
-        long slot = (long)uniform64((u64)ptr_raw);
-        slot = tap_mod_col(slot, child, nRc);                        // rolling.py:632-633
-        const bool hit = (window & bit) && __popcll(window & below) == slot;
-        window &= ~__ballot(hit);
-    }
-    // (2) top the window up: in-degree-0 nodes of gm_copy, layer by layer, ascending ids
-    //     (generate.py:1724-1750); list order = old window (sorted by the previous call) + appended
-    int count = __popcll(window);
-    if (window & bit) S.lst[__popcll(window & below)] = (unsigned char)v;
-    u64 added = 0;
-    while (count < child) {
-        const u64 gmc = all & ~(entered | added);                    // nodes still in gm_copy
-        const bool free_ = isnode && (gmc & bit) && (__popcll(gmc) == 1 || (rel0 & gmc) == 0);
-        const u64 fm = __ballot(free_);
-        if (fm == 0) break;
-        const int need = child - count;
-        const bool take = free_ && __popcll(fm & below) < need;
-        if (take) S.lst[count + __popcll(fm & below)] = (unsigned char)v;
-        const u64 tm = __ballot(take);
-        added |= tm;
-        count += __popcll(tm);
-    }
-    entered |= added;   // after_nodes_list.remove (:1745) and, the window being full, decompose() (:1712-1721)
-    window |= added;
-    const int short_window = count != child;
     const bool inwin = (window & bit) != 0;
-    u64 rel[5] = {rel0, 0, 0, 0, 0};
-    int bdim[3] = {0, 0, 0};                         // this node's block (rotation 0)
-    if (inwin && !short_window) {
-#pragma unroll
-        for (int k = 1; k < 5; ++k) rel[k] = a.rel[((size_t)inst * 5 + k) * N + v];
-#pragma unroll
-        for (int k = 0; k < D; ++k) bdim[k] = a.blocks[((size_t)inst * N + v) * D + k];
-    }
+    const u64 (&rel)[5] = nd.rel;
+    const int (&bdim)[3] = nd.bdim;
+    if (v < child) S.pos[S.ord[v]] = (unsigned char)v;
     tap_wave_lds_sync();
 
-    PROF(1);
-    // (3) node order of the induced sub-graphs (:1684-1688, 1758-1761)
-    if (2 * child < N) {
-        if (child <= 18) { if (!short_window) pyset_order_wave(S.lst, child, S.ord, v); } // wave-uniform branch
-        else if (v == 0 && !short_window) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
-    } else if (inwin) {
-        S.ord[__popcll(window & below)] = (unsigned char)v;
-    }
-    tap_wave_lds_sync();
-    if (v < child && !short_window) S.pos[S.ord[v]] = (unsigned char)v;
-    tap_wave_lds_sync();
-
-    if (v == 0) {
-        a.state[(size_t)inst * 2] = entered;
-        a.state[(size_t)inst * 2 + 1] = window;
-        if (a.err_out) a.err_out[inst] = short_window;
-    }
-    if (short_window) return;
-
-    PROF(2);
     // (4) tensors (generate.py:1778-1822).  Window-node lanes publish their five column masks (with
     //     the :1690-1705 rule: a blocker that has not entered any window yet => the side counts as
     //     self-blocked) by sub-graph index.
@@ -346,7 +298,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + __popcll(window & below)] = v;
     }
     tap_wave_lds_sync();
-    PROF(3);
+    
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
@@ -370,9 +322,10 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         const int k5 = v / child, cm5 = v - k5 * child;
         const bool on5 = v < 5 * child;
         const u64 m = on5 ? S.side[k5][cm5] : 0ull;
+        const int ordv = S.ord[v < child ? v : 0];  // lane rm holds ord[rm]: one LDS read, then lane reads
         unsigned w = 0u;
         for (int rm = 0; rm < child; ++rm) {
-            const int node = __builtin_amdgcn_readfirstlane((int)S.ord[rm]);     // wave-uniform
+            const int node = __builtin_amdgcn_readlane(ordv, rm);                // wave-uniform
             const unsigned half = node >= 32 ? (unsigned)(m >> 32) : (unsigned)m;
             w |= ((half >> (node & 31)) & 1u) << rm;
         }
@@ -445,7 +398,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
             }
         }
     }
-    PROF(4);
+    
     if (!packed) return;
     tap_wave_lds_sync();
     const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
@@ -464,9 +417,83 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
                                                             (float)((h2 >> s5) & 1u), (float)((h3 >> s5) & 1u)));
         }
     }
-    PROF(5);
+    
 }
 
+template <int D>
+__device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
+{
+    if (inst >= a.B) return;
+    PROF_BEGIN;
+    const int N = a.N, child = a.child;
+    constexpr int R = D == 2 ? 2 : 6;
+    const int nRc = child * R;
+    const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
+    const u64 bit = 1ull << v, below = bit - 1ull;
+    const bool isnode = v < N;
+    // Every input of the graph step is requested up front: the window state, the previous pick and each
+    // node's movement mask.  The four side masks and the block sizes are only needed for the (at most
+    // `child`) nodes of the new window and are requested once it is known, under the set-order emulation.
+    auto uniform64 = [](u64 x) -> u64 {
+        return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+    };
+    const u64 rel0 = isnode ? a.rel[(size_t)inst * 5 * N + v] : 0ull;
+    const u64 st_entered = a.state[(size_t)inst * 2], st_window = a.state[(size_t)inst * 2 + 1];
+    const long ptr_raw = a.remove_ptr ? (long)a.remove_ptr[inst] : 0;
+    // (entered, window) are wave-uniform: in scalar registers the set arithmetic below costs no VALU slots
+    u64 entered = uniform64(st_entered), window = uniform64(st_window);
+
+    PROF(0);
+    // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
+    if (a.remove_ptr) {
+        long slot = (long)uniform64((u64)ptr_raw);
+        slot = tap_mod_col(slot, child, nRc);                        // rolling.py:632-633
+        const bool hit = (window & bit) && __popcll(window & below) == slot;
+        window &= ~__ballot(hit);
+    }
+    // (2) top the window up: in-degree-0 nodes of gm_copy, layer by layer, ascending ids
+    //     (generate.py:1724-1750); list order = old window (sorted by the previous call) + appended
+    int count = __popcll(window);
+    if (window & bit) S.lst[__popcll(window & below)] = (unsigned char)v;
+    u64 added = 0;
+    while (count < child) {
+        const u64 gmc = all & ~(entered | added);                    // nodes still in gm_copy
+        const bool free_ = isnode && (gmc & bit) && (__popcll(gmc) == 1 || (rel0 & gmc) == 0);
+        const u64 fm = __ballot(free_);
+        if (fm == 0) break;
+        const int need = child - count;
+        const bool take = free_ && __popcll(fm & below) < need;
+        if (take) S.lst[count + __popcll(fm & below)] = (unsigned char)v;
+        const u64 tm = __ballot(take);
+        added |= tm;
+        count += __popcll(tm);
+    }
+    entered |= added;   // after_nodes_list.remove (:1745) and, the window being full, decompose() (:1712-1721)
+    window |= added;
+    const int short_window = count != child;
+    const bool inwin = (window & bit) != 0;
+    RollNode nd = rolling_node_loads<D>(a, inst, v, inwin && !short_window, rel0);   // in flight under the set order
+    tap_wave_lds_sync();
+
+    PROF(1);
+    // (3) node order of the induced sub-graphs (:1684-1688, 1758-1761)
+    if (2 * child < N) {
+        if (child <= 18) { if (!short_window) pyset_order_wave(S.lst, child, S.ord, v); } // wave-uniform branch
+        else if (v == 0 && !short_window) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
+    } else if (inwin) {
+        S.ord[__popcll(window & below)] = (unsigned char)v;
+    }
+    tap_wave_lds_sync();
+    if (v == 0) {
+        a.state[(size_t)inst * 2] = entered;
+        a.state[(size_t)inst * 2 + 1] = window;
+        if (a.err_out) a.err_out[inst] = short_window;
+    }
+    if (short_window) return;
+    PROF(2);
+    rolling_emit_wave<D>(a, inst, v, S, entered, window, nd);
+}
 
 // 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
 // were resident, so one workgroup in eight ran as a second round
@@ -487,11 +514,14 @@ struct RollStepArgs {
     StepArgs s;
 };
 
+constexpr int ROLL_EPB = 2;   // instances per workgroup of the fused step (2: 3-wave workgroups pack a CU's 28 wave slots
+                              // better than 6-wave ones: 9 x 3 = 27 against 4 x 6 = 24)
+
 template <int D, int G>
-__global__ void __launch_bounds__((64 * (4 + 4 * G / 64 + (4 * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(7, 8)))
+__global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_rolling_step(RollStepArgs a)
 {
-    constexpr int EPB = 4;                                  // instances per workgroup
+    constexpr int EPB = ROLL_EPB;                           // instances per workgroup
     constexpr int ENV_WAVES = (EPB * G + 63) / 64;
     __shared__ RollLds S[EPB];
     __shared__ int s_old[64 * ENV_WAVES];
@@ -567,7 +597,7 @@ extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, 
 
 template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollStepArgs &a, hipStream_t st)
 {
-    constexpr int EPB = 4, ENV_WAVES = (EPB * G + 63) / 64, THREADS = 64 * (ENV_WAVES + EPB);
+    constexpr int EPB = ROLL_EPB, ENV_WAVES = (EPB * G + 63) / 64, THREADS = 64 * (ENV_WAVES + EPB);
     const int grid = (a.r.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     hipLaunchKernelGGL((k_rolling_step<D, G>), dim3(grid), dim3(THREADS), 0, st, a);
