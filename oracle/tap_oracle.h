@@ -26,7 +26,8 @@ extern "C" {
 #endif
 
 /* packing strategy (tools.py:3617-3620, 3679-3690) */
-enum { ORC_LB_GREEDY = 0, ORC_MACS = 1 /* 'MACS' and 'MUL' run the same function: tools.py:2451 (2D), :2751 (3D) */ };
+enum { ORC_LB_GREEDY = 0, ORC_MACS = 1 /* 'MACS' and 'MUL' run the same function: tools.py:2451 (2D), :2751 (3D) */,
+       ORC_LB = 2 /* legacy 'LB': calc_one_position_greedy, tools.py:1602-1955 */ };
 
 /* flag word = the string tests the reference performs on reward_type */
 enum {

@@ -8,7 +8,7 @@ no reference source text.  Usage:
     python tests/golden/make_golden.py [--only NAME ...]
 
 Fixtures:
-  lbg2d.npz, lbg3d.npz, macs2d.npz, macs3d.npz   tools.Container.add_new_block / calc_ratio step traces
+  lbg2d.npz, lbg3d.npz, macs2d.npz, macs3d.npz, lb_legacy.npz   tools.Container.add_new_block / calc_ratio step traces
   stable3d.npz                       tools.is_stable, exhaustive over footprints <= 4x4 (+5xk samples)
   dataset_2d.npz, dataset_3d.npz     pack.create_dataset -> text files -> pack.PACKDataset tensors
   masks_2d.npz, masks_3d.npz         pack.update_dynamic / pack.update_mask traces on random feasible tapes
@@ -131,6 +131,37 @@ def make_lbg3d(tools):
         meta = dict(cs=[W, W, 90], n=12, reward=reward, feat=feat, strategy="LB_GREEDY")
         cases.append((meta, trace_container(tools, [W, W, 90], 12, reward, feat, "LB_GREEDY", blocks), blocks))
     save("lbg3d.npz", **pack_cases(cases))
+
+
+def make_lb_legacy(tools):
+    """packing_strategy 'LB' (tools.py:3683-3686 -> calc_one_position_greedy_2d / _3d, :1602-1955): step traces
+    of the reference Container, 2D and 3D, soft and hard, several widths and feature types."""
+    cases = []
+    for reward in ("C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft", "C+P-lb-hard"):
+        blocks = rand_blocks(501, 128, 10, 2)
+        meta = dict(cs=[5, 50], n=10, reward=reward, feat="diff", strategy="LB")
+        cases.append((meta, trace_container(tools, [5, 50], 10, reward, "diff", "LB", blocks), blocks))
+    for W in range(1, 9):
+        for reward, feat in (("C+P+S-lb-soft", "diff"), ("C+P+S-lb-hard", "zero"), ("C+P-lb-soft", "full")):
+            blocks = rand_blocks(520 + W, 16, 8, 2, 1, 6, marginal=False)
+            meta = dict(cs=[W, 60], n=8, reward=reward, feat=feat, strategy="LB")
+            cases.append((meta, trace_container(tools, [W, 60], 8, reward, feat, "LB", blocks), blocks))
+    blocks = rand_blocks(503, 32, 20, 2)
+    meta = dict(cs=[7, 100], n=20, reward="C+P+S-lb-soft", feat="diff", strategy="LB")
+    cases.append((meta, trace_container(tools, [7, 100], 20, "C+P+S-lb-soft", "diff", "LB", blocks), blocks))
+    for reward in ("C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft"):
+        blocks = rand_blocks(541, 96, 10, 3)
+        meta = dict(cs=[5, 5, 50], n=10, reward=reward, feat="diff", strategy="LB")
+        cases.append((meta, trace_container(tools, [5, 5, 50], 10, reward, "diff", "LB", blocks), blocks))
+    for W, L, hi, reward, feat in ((3, 3, 4, "C+P+S-lb-soft", "full"), (4, 6, 5, "C+P+S-lb-hard", "zero"),
+                                   (6, 4, 6, "C+P+S-lb-soft", "diff"), (7, 7, 5, "C+P+S-lb-hard", "diff")):
+        blocks = rand_blocks(550 + W, 16, 12, 3, 1, hi, marginal=False)
+        meta = dict(cs=[W, L, 90], n=12, reward=reward, feat=feat, strategy="LB")
+        cases.append((meta, trace_container(tools, [W, L, 90], 12, reward, feat, "LB", blocks), blocks))
+    blocks = rand_blocks(560, 12, 30, 3)
+    meta = dict(cs=[5, 5, 150], n=30, reward="C+P+S-lb-soft", feat="diff", strategy="LB")
+    cases.append((meta, trace_container(tools, [5, 5, 150], 30, "C+P+S-lb-soft", "diff", "LB", blocks), blocks))
+    save("lb_legacy.npz", **pack_cases(cases))
 
 
 def make_macs2d(tools):
@@ -482,6 +513,7 @@ def main():
     want = lambda k: args.only is None or k in args.only  # noqa: E731
     if want("lbg2d"): make_lbg2d(tools)
     if want("lbg3d"): make_lbg3d(tools)
+    if want("lb_legacy"): make_lb_legacy(tools)
     if want("macs2d"): make_macs2d(tools)
     if want("macs3d"): make_macs3d(tools)
     if args.only and "ppsg" in args.only: make_ppsg(tools, pack, args.ppsg_dir)   # slow: only on request

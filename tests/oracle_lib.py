@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _LIB_PATH = os.path.join(ORACLE_DIR, "libtap_oracle.so")
 
-LB_GREEDY, MACS = 0, 1
+LB_GREEDY, MACS, LB = 0, 1, 2
 F_HARD, F_USE_P, F_USE_S, F_MCS_ZERO, F_MCS_TIE = 1, 2, 4, 8, 16
 R_C, R_CxS, R_CP, R_CPxS, R_CPS, R_2CPS, R_CxPxS, R_CP_HALF = range(8)
 FEAT = {"full": 0, "zero": 1, "diff": 2}
@@ -115,7 +115,7 @@ def make_desc(container_size, blocks_num, reward_type, heightmap_type="diff",
         packing_strategy = "MUL"
     elif reward_type in ("C+P+S-mcs-soft", "C+P+S-mcs-hard"):
         packing_strategy = "MACS"
-    strategy = MACS if packing_strategy in ("MACS", "MUL") else LB_GREEDY
+    strategy = MACS if packing_strategy in ("MACS", "MUL") else LB if packing_strategy == "LB" else LB_GREEDY
     flags = 0
     if reward_type.endswith("hard"):
         flags |= F_HARD

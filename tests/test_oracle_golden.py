@@ -23,7 +23,7 @@ def _check_trace(meta, tr):
     assert np.array_equal(np.nan_to_num(out["cps"], nan=-7.0), np.nan_to_num(tr["cps"], nan=-7.0)), meta
 
 
-@pytest.mark.parametrize("fixture", ["lbg2d.npz", "lbg3d.npz", "macs2d.npz", "macs3d.npz"])
+@pytest.mark.parametrize("fixture", ["lbg2d.npz", "lbg3d.npz", "macs2d.npz", "macs3d.npz", "lb_legacy.npz"])
 def test_container_traces(fixture):
     ncases = 0
     for meta, tr in G.cases(fixture):

@@ -54,6 +54,16 @@ def test_lbg3d(ref, reward):
     _diff(ref[0], [6, 6, 80], 12, reward, "diff", "LB_GREEDY", 12, 23, 1, 7)
 
 
+@pytest.mark.parametrize("reward", ["C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft"])
+def test_lb_legacy(ref, reward):
+    """packing_strategy 'LB' (tools.py:3683-3686, :1602-1955), full state incl. the voxel grid."""
+    _diff(ref[0], [5, 50], 10, reward, "diff", "LB", 40, 51)
+    _diff(ref[0], [7, 100], 20, reward, "zero", "LB", 10, 52)
+    _diff(ref[0], [3, 60], 8, reward, "full", "LB", 15, 53, 1, 6)
+    _diff(ref[0], [5, 5, 50], 10, reward, "diff", "LB", 20, 54)
+    _diff(ref[0], [4, 6, 80], 12, reward, "full", "LB", 6, 55, 1, 6)
+
+
 @pytest.mark.parametrize("reward", ["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "C+P-mcs-soft"])
 def test_macs2d(ref, reward):
     _diff(ref[0], [7, 100], 20, reward, "diff", "MACS", 25, 31)
