@@ -45,7 +45,8 @@ enum {
 };
 
 /* packing strategy, tools.py:3617-3620 / 3679-3690 */
-enum { TAP_LB_GREEDY = 0, TAP_MACS = 1 /* 'MACS' and 'MUL' */ };
+enum { TAP_LB_GREEDY = 0, TAP_MACS = 1 /* 'MACS' and 'MUL' */,
+       TAP_LB = 2 /* the legacy 'LB' (tools.py:1602-1955): voxel-level state, tap_env_step only */ };
 
 /* flag word: the string tests the reference performs on reward_type */
 enum {
@@ -73,7 +74,7 @@ typedef struct tap_env_desc {
     int32_t D;          /* 2 | 3 */
     int32_t W, L, H;    /* container_size; L = 1 when D == 2 */
     int32_t n_max;      /* blocks_num */
-    int32_t strategy;   /* TAP_LB_GREEDY | TAP_MACS */
+    int32_t strategy;   /* TAP_LB_GREEDY | TAP_MACS | TAP_LB */
     int32_t flags;      /* TAP_F_* */
     int32_t ratio_mode; /* TAP_R_* */
     int32_t feature;    /* TAP_FEAT_* */
@@ -92,7 +93,7 @@ const char *tap_last_error(const tap_ctx *ctx);
 
 /* Fill `d` from the arguments of tools.Container.__init__ (tools.py:3611-3661), performing its
  * string tests once on the host: container_size = D ints, reward_type e.g. "C+P+S-lb-soft",
- * heightmap_type "full"|"zero"|"diff", packing_strategy "LB_GREEDY"|"MACS"|"MUL" (the reward
+ * heightmap_type "full"|"zero"|"diff", packing_strategy "LB_GREEDY"|"MACS"|"MUL"|"LB" (the reward
  * string overrides it exactly as tools.py:3617-3620 does).  Host only, no device work. */
 int tap_env_desc_init(tap_env_desc *d, int B, int D, const int32_t *container_size, int blocks_num,
                       const char *reward_type, const char *heightmap_type,

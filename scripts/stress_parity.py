@@ -1,5 +1,5 @@
 """Randomised parity sweep on the GPU: random container shapes / block counts / reward strings for the
-four placement families (LB_GREEDY 2D/3D, MACS 2D/3D), every env compared with the CPU oracle
+placement families (LB_GREEDY 2D/3D, MACS 2D/3D, legacy LB 2D/3D), every env compared with the CPU oracle
 (positions, stable flags, final height-map, fp64 ratio) and the number of flagged containers compared
 with the number of envs in which the reference would raise.
 
@@ -43,8 +43,15 @@ fam = {}
 cases = []
 for seed in range(int(sys.argv[1])):
     rs = np.random.RandomState(1000 + seed)
-    kind = seed % 4
-    if kind == 0:    # MACS 3D
+    kind = seed % 5
+    if kind == 4:    # legacy LB, 2D and 3D (voxel-level kernel)
+        if rs.rand() < 0.5:
+            W = int(rs.randint(1, 12)); cs = [W, int(rs.choice([40, 60, 120]))]
+        else:
+            cs = [int(rs.randint(1, 9)), int(rs.randint(1, 9)), int(rs.choice([40, 60, 120]))]
+        n = int(rs.randint(4, 20)); hi = int(rs.randint(2, 7))
+        reward = str(rs.choice(["C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft", "C+P-lb-hard"])); strat = "LB"
+    elif kind == 0:    # MACS 3D
         W, L = rs.randint(2, 8), rs.randint(2, 8)
         cs = [int(W), int(L), int(rs.choice([40, 64, 100, 200]))]; n = int(rs.randint(6, 22)); hi = int(min(W, L, 5)) + 1
         reward = str(rs.choice(["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "C+P+S-mul-hard", "mcs-soft", "mcs-hard", "C+P-mcs-soft"])); strat = "MACS"
@@ -62,7 +69,7 @@ for seed in range(int(sys.argv[1])):
     feat = str(rs.choice(["diff", "zero", "full"]))
     b, ne, fl = one(cs, n, reward, strat, B, 1, hi, seed, feat)
     total += B * n; nbad += b; noracle_err += ne
-    f = fam.setdefault(("MACS" if strat == "MACS" else "LB_GREEDY") + (" 3D" if len(cs) == 3 else " 2D"), dict(configurations=0, env_steps=0, mismatching_envs=0))
+    f = fam.setdefault(("MACS" if strat == "MACS" else "LB (legacy)" if strat == "LB" else "LB_GREEDY") + (" 3D" if len(cs) == 3 else " 2D"), dict(configurations=0, env_steps=0, mismatching_envs=0))
     f["configurations"] += 1; f["env_steps"] += B * n; f["mismatching_envs"] += b
     if b or (fl != ne and not (ne == 0 and fl == 0)):
         nflag_mismatch += int(fl != ne)

@@ -15,7 +15,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tapenv.h")
 
 TAP_OK = 0
 TAP_E_INVALID, TAP_E_UNSUPPORTED, TAP_E_HIP, TAP_E_OVERFLOW, TAP_E_NODEVICE, TAP_E_STEPS = -1, -2, -3, -4, -5, -6
-TAP_LB_GREEDY, TAP_MACS = 0, 1
+TAP_LB_GREEDY, TAP_MACS, TAP_LB = 0, 1, 2
 TAP_DT_F32, TAP_DT_I32 = 0, 1
 TAP_T_FRESH, TAP_T_RATIO = 1, 2
 

@@ -129,7 +129,8 @@ extern "C" int tap_env_desc_init(tap_env_desc *d, int B, int D, const int32_t *c
     else if (!strcmp(reward, "C+P+S-mcs-soft") || !strcmp(reward, "C+P+S-mcs-hard")) st = "MACS";
     if (!strcmp(st, "MACS") || !strcmp(st, "MUL")) d->strategy = TAP_MACS;
     else if (!strcmp(st, "LB_GREEDY")) d->strategy = TAP_LB_GREEDY;
-    else return TAP_E_UNSUPPORTED; // 'LB' (legacy) and the pack-net back-ends are out of scope
+    else if (!strcmp(st, "LB")) d->strategy = TAP_LB;              // tools.py:3683-3686 (lb.hip)
+    else return TAP_E_UNSUPPORTED; // the pack-net back-ends are out of scope
     if (str_ends(reward, "hard")) d->flags |= TAP_F_HARD;          // tools.py:2113
     if (strchr(reward, 'P')) d->flags |= TAP_F_USE_P;              // tools.py:2135
     if (strchr(reward, 'S')) d->flags |= TAP_F_USE_S;              // tools.py:2138
@@ -164,7 +165,7 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "3D footprints wider than 8 are not supported");
     if (d->H > 4000 || d->n_max > 4096)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "H or blocks_num too large for the 32-bit sort key");
-    if (d->strategy != TAP_LB_GREEDY && d->strategy != TAP_MACS)
+    if (d->strategy != TAP_LB_GREEDY && d->strategy != TAP_MACS && d->strategy != TAP_LB)
         return tap_fail(ctx, TAP_E_INVALID, "bad strategy %d", d->strategy);
     return TAP_OK;
 }
@@ -235,6 +236,7 @@ template <int D, int G> static int launch_step(tap_ctx *ctx, const StepArgs &a, 
     } while (0)
 
 int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st); // macs.hip
+int tap_lb_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st); // lb.hip
 
 static int step_common(tap_ctx *ctx, const tap_env_desc *d, void *state, StepArgs &a, void *stream)
 {
@@ -247,6 +249,7 @@ static int step_common(tap_ctx *ctx, const tap_env_desc *d, void *state, StepArg
     a.flen = tap_env_feature_len(d);
     a.lut = ctx ? ctx->stab_lut : nullptr;
     if (d->strategy == TAP_MACS) return tap_macs2d_step(ctx, a, (hipStream_t)stream);
+    if (d->strategy == TAP_LB) return tap_lb_step(ctx, a, state, (hipStream_t)stream);
     TAP_DISPATCH_DG(launch_step, d, ctx, a, (hipStream_t)stream);
 }
 
