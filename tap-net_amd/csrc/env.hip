@@ -159,10 +159,16 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
         (d->D == 2 && d->L != 1))
         return tap_fail(ctx, TAP_E_INVALID, "bad descriptor B=%d D=%d W=%d L=%d H=%d n=%d", d->B,
                         d->D, d->W, d->L, d->H, d->n_max);
-    if (tap_group_size(d) == 0)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 64 lanes per container", d->W * d->L);
-    if (d->D == 3 && (d->W > 8 || d->L > 8))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "3D footprints wider than 8 are not supported");
+    if (tap_is_big(d)) {                                           // one thread per container (big.hip)
+        if (d->W * d->L > 4096) return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 4096", d->W * d->L);
+    } else if (d->strategy == TAP_LB) {                            // one thread per container (lb.hip)
+        if (d->W > 248 || (d->D == 3 && d->L > 248)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "legacy LB: side > 248");
+    } else {
+        if (tap_group_size(d) == 0)
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL: W*L = %d cells > 64 lanes per container", d->W * d->L);
+        if (d->D == 3 && (d->W > 8 || d->L > 8))
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: sides above 8 are not supported");
+    }
     if (d->H > 4000 || d->n_max > 4096)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "H or blocks_num too large for the 32-bit sort key");
     if (d->strategy != TAP_LB_GREEDY && d->strategy != TAP_MACS && d->strategy != TAP_LB)
@@ -250,6 +256,7 @@ static int step_common(tap_ctx *ctx, const tap_env_desc *d, void *state, StepArg
     a.lut = ctx ? ctx->stab_lut : nullptr;
     if (d->strategy == TAP_MACS) return tap_macs2d_step(ctx, a, (hipStream_t)stream);
     if (d->strategy == TAP_LB) return tap_lb_step(ctx, a, state, (hipStream_t)stream);
+    if (tap_is_big(d)) return tap_big_step(ctx, a, state, (hipStream_t)stream);
     TAP_DISPATCH_DG(launch_step, d, ctx, a, (hipStream_t)stream);
 }
 
@@ -322,6 +329,8 @@ extern "C" int tap_env_feature(tap_ctx *ctx, const tap_env_desc *d, const void *
     if (!state || !feature_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
+    if (tap_is_big(d) || d->strategy == TAP_LB)
+        return tap_big_feature(ctx, d, v, feature_out, tap_env_feature_len(d), (hipStream_t)stream);
     TAP_DISPATCH_DG(launch_feature, d, ctx, d, v, feature_out, (hipStream_t)stream);
 }
 
@@ -516,6 +525,8 @@ extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, in
     if (B == 0) return TAP_OK; // an empty batch has no buffers to check (d->B is ignored here)
     if (d->strategy != TAP_LB_GREEDY)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
+    if (tap_is_big(d))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: containers above 64 cells are stepped with tap_env_step_gather");
     if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
         return tap_fail(ctx, TAP_E_INVALID, "bad episode arguments");
     EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, nullptr};
@@ -529,7 +540,8 @@ extern "C" int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (B == 0) return TAP_OK; // an empty batch has no buffers to check (d->B is ignored here)
-    if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY only");
+    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY on containers of at most 64 cells");
     if (!blocks || B < 0 || n < 1) return tap_fail(ctx, TAP_E_INVALID, "bad pack_blocks arguments");
     EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, score64_out};
     TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);

@@ -615,7 +615,8 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
-    if (d->strategy != TAP_LB_GREEDY) return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: LB_GREEDY only");
+    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d))
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: LB_GREEDY on containers of at most 64 cells (use tap_env_step_gather + tap_rolling_window)");
     rc = roll_check(ctx, d->B, d->D, N, child);
     if (rc) return rc;
     if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||

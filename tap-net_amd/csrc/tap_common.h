@@ -76,6 +76,12 @@ struct EnvView {
 
 inline size_t tap_align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// LB_GREEDY containers beyond the lane-per-cell kernels (more than 64 cells, or a 3D side above 8): big.hip
+inline bool tap_is_big(const tap_env_desc *d)
+{
+    return d->strategy == TAP_LB_GREEDY && (d->W * d->L > 64 || (d->D == 3 && (d->W > 8 || d->L > 8)));
+}
+
 inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
 {
     const size_t B = (size_t)d->B, cells = (size_t)d->W * d->L, nD = (size_t)d->n_max * d->D;
@@ -86,6 +92,7 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
     size_t o_pos = take(nD * B * 4), o_st = take((size_t)d->n_max * B);
     size_t o_blk = (d->strategy == TAP_MACS || d->strategy == TAP_LB) ? take(nD * B * 4) : 0;
     size_t o_occ = (d->strategy == TAP_MACS && d->D == 3) ? take(B * cells * 8 * (size_t)((d->H + 63) / 64)) : 0;
+    if (tap_is_big(d)) take(B * cells * 4);   // big.hip: W*L ints of scratch per container, last section
     if (d->strategy == TAP_LB) {   // legacy LB (lb.hip): voxel ids, level lists and their lengths; see tap_lb_layout
         take(B * cells * (size_t)d->H * 2);
         take(B * (size_t)d->H * d->L * (size_t)(d->W + 2));
@@ -101,6 +108,16 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
         v->occ = (d->strategy == TAP_MACS && d->D == 3) ? reinterpret_cast<unsigned long long *>(p + o_occ) : nullptr;
     }
     return off;
+}
+
+// big.hip's scratch: the last section of an LB_GREEDY blob (no blk / occ sections for that strategy)
+inline int32_t *tap_big_scratch(const tap_env_desc *d, void *base)
+{
+    const size_t B = (size_t)d->B, cells = (size_t)d->W * d->L, nD = (size_t)d->n_max * d->D;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = tap_align256(off + bytes); return o; };
+    take(B * cells * 4); take(B * 16); take(B * 4); take(nD * B * 4); take((size_t)d->n_max * B);
+    return reinterpret_cast<int32_t *>(static_cast<char *>(base) + take(B * cells * 4));
 }
 
 // the extra sections of a legacy-LB state blob (they follow everything tap_env_layout hands out above them)
@@ -146,3 +163,5 @@ inline int tap_group_size(const tap_env_desc *d)
     const int cells = d->W * d->L;
     return cells <= 8 ? 8 : cells <= 16 ? 16 : cells <= 32 ? 32 : cells <= 64 ? 64 : 0;
 }
+int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st);                                      // big.hip
+int tap_big_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, int flen, hipStream_t st);   // big.hip

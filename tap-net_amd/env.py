@@ -47,6 +47,15 @@ class BatchedContainer(object):
         self._flen = _lib.lib().tap_env_feature_len(C.byref(self.desc))
         self.reset()
 
+    @property
+    def fused_ok(self):
+        """False for the shapes / strategies without a fused step (tap_transition*, tap_rolling_step): the legacy
+        'LB' strategy and LB_GREEDY containers above 64 cells or with a 3D side above 8 (one thread per container,
+        lb.hip / big.hip); the episode loops then take the two-launch path."""
+        d = self.desc
+        big = d.strategy == _lib.TAP_LB_GREEDY and (d.W * d.L > 64 or (d.D == 3 and (d.W > 8 or d.L > 8)))
+        return not (big or d.strategy == _lib.TAP_LB)
+
     # ---- plumbing ---------------------------------------------------------------------------
     def _call(self, fn, *args):
         with torch.cuda.device(self.device):

@@ -491,6 +491,15 @@ def reward(static, tour_indices, reward_type, input_type, allow_rot, container_w
     cs = [container_width, container_height] if block_dim == 2 else \
         [container_width, container_width, container_height]                       # pack.py:408-411
     desc = _lib.make_desc(B, cs, n, reward_type, 'full', 'LB_GREEDY')
+    if desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8)):
+        # above the whole-episode kernel's container size: the same episode, one placement launch per block;
+        # tools.calc_positions_lb_greedy returns C + P + S un-normalised (tools.py:2442-2449)
+        from .env import BatchedContainer
+        env = BatchedContainer(B, cs, n, reward_type, 'full', packing_strategy='LB_GREEDY', device=st.device)
+        for t in range(n):
+            env.add_new_blocks_gather(st, tour[:, t].contiguous(), want_feature=False)
+        cps = env.calc_CPS()
+        return -((cps[:, 0] + cps[:, 1]) + cps[:, 2]).to(torch.float32)
     out = torch.empty(B, dtype=torch.float32, device=st.device)
     import ctypes as C
     c = _lib.ctx(st.device)

@@ -126,7 +126,7 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
     decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
     ar = torch.arange(B, device=dev)
     tour, picked, feats = [], [], []
-    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY
+    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY and env.fused_ok
     ptr, ratio, step = None, None, 0
     win = rw.next(None)
     for _ in range(N - child):                                   # one_step windows

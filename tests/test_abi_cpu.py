@@ -45,7 +45,8 @@ def test_desc_matches_reference_string_tests(reward, strategy):
 
 def test_desc_rejects_unknown():
     with pytest.raises(T.TapError):
-        _lib.make_desc(1, [5, 50], 10, "C+P+S-lb-soft", "diff", "LB")        # legacy strategy: out of scope
+        _lib.make_desc(1, [5, 50], 10, "C+P+S-lb-soft", "diff", "PNET")      # the pack-net back-ends: out of scope
+    assert _lib.make_desc(1, [5, 50], 10, "C+P+S-lb-soft", "diff", "LB").strategy == _lib.TAP_LB   # legacy strategy
     with pytest.raises(T.TapError):
         _lib.make_desc(1, [5, 50], 10, "C+P+S-lb-soft", "nope", "LB_GREEDY")
 
