@@ -46,18 +46,43 @@ with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.csv" % (tag, cfg)), 
         w.writerow([k, m.get("calls_FETCH_SIZE", 0), "%.3f" % fs, "%.3f" % ws, int((2 * fs + ws) * 1024)])
 tpath = os.path.join(ROOT, "profiles", "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-short = {"k_mask_step": "mask_step", "k_env_step": "env_step", "k_transition": "transition",
-         "k_rolling_window": "rolling_window", "k_rolling_step": "rolling_step", "k_macs2d_step": "macs_step", "k_macs3d_step": "macs_step"}
-for k, m in means.items():
-    for pat, name in short.items():
+# per-kernel average duration from the --stats pass of the same command
+avg_ns = {}
+for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))):
+    avg_ns[r["Name"]] = float(r["AverageNs"])
+
+
+def short_name(k):
+    """bench.py's name of a kernel (the last template argument of k_transition* is the form of the precedence
+    update: 0 fp32 copy, 1 bit shadow, 2 first step building the shadow)."""
+    import re
+    m = re.match(r"(?:void )?k_transition(?:_macs3?)?<(.*)>", k)
+    if m:
+        mode = m.group(1).split(",")[-1].strip()
+        return {"0": "transition_copy", "1": "transition", "2": "transition_first"}.get(mode, "transition")
+    for pat, name in (("k_mask_step", "mask_step"), ("k_env_step", "env_step"), ("k_rolling_window", "rolling_window"),
+                      ("k_rolling_step", "rolling_step"), ("k_macs2d_step", "macs_step"), ("k_macs3d_step", "macs_step"),
+                      ("k_episode", "episode"), ("k_dyn_bits", "dyn_bits")):
         if pat in k:
-            traffic["%s:%s" % (cfg, name)] = int((2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024)
-traffic.setdefault("_note", "")
-traffic["_source"] = "profiles/summarize.py from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; bytes per launch"
+            return name
+    return None
+
+
+for k, m in means.items():
+    name = short_name(k)
+    if name is None:
+        continue
+    traffic["%s:%s" % (cfg, name)] = dict(
+        bytes=int((2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024), profile=tag,
+        kernel_us=round(avg_ns.get(k, 0.0) / 1e3, 3) or None, kernel=k[:80])
+traffic["_note"] = ("per-launch HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes and the "
+                    "kernel's average duration from the --kernel-trace --stats pass of the same bench.py command; "
+                    "`profile` names the profile set (profiles/<profile>_<config>_*.csv) the entry comes from")
+traffic["_source"] = "profiles/summarize.py"
 json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
 # bench lines under profiles/ come from clean runs (gpurun_out/bench_<tag>/<cfg>.json), never from the
 # profiled run, whose timings the tracer perturbs
 bj = os.path.join(src, "bench_%s" % tag, "%s.json" % cfg)
 if os.path.exists(bj) and os.path.getsize(bj):
     shutil.copy(bj, os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, cfg)))
-print(json.dumps(traffic, indent=1))
+print(json.dumps({k: v for k, v in traffic.items() if k.startswith(cfg + ":")}, indent=1))

@@ -3,7 +3,9 @@ container) next to the C oracle on the same work, so the oracle's timing on the 
 translated: ref_on_box ~= oracle_on_box * (ref_here / oracle_here)   (CPU baseline plan).
 
 Work = what bench.py's cpu_baseline times: per env and step update_dynamic + update_mask + add_new_block,
-plus calc_ratio at the end; B = 128 (BASELINE configs[0]), median of 3 repeats, one process, one core.
+plus calc_ratio at the end; B = 128 (BASELINE configs[0]), median of 3 repeats.  Two figures per config, as
+SURVEY 8(d) asks: one process on one core, and -- the reference being single-threaded (trainer.py:155-156,
+num_workers = 0) -- one forked process per CPU of this container on disjoint batch slices, summed.
 
     python scripts/time_reference.py            -> one JSON line per config
 """
@@ -17,6 +19,8 @@ import ref_loader                                                    # noqa: E40
 from tap_net_amd import synth                                        # noqa: E402  (host-side generators only)
 
 tools, pack = ref_loader.load()[:2]
+O.set_threads(1)                                                     # the oracle's "1 core" figure really is one thread
+torch.set_num_threads(1)
 CASES = [("c1/c2", 2, [5, 50], 10, "C+P+S-lb-soft", "LB_GREEDY"), ("c3", 3, [5, 5, 50], 10, "C+P+S-lb-soft", "LB_GREEDY"),
          ("c4", 2, [7, 100], 20, "C+P+S-mcs-soft", "MACS")]
 B = 128
@@ -54,6 +58,27 @@ for name, D, cs, n, reward, strategy in CASES:
 
     t_ref = med(ref_pass, 3)
     t_orc = med(lambda: [orc_pass() for _ in range(20)], 3) / 20
+    # all CPUs: P forked processes, each running the whole B = 128 pass on its own copy (disjoint slices of a
+    # P*B batch), wall time of the slowest; torch pinned to one thread per process
+    import multiprocessing as mp
+    P = len(os.sched_getaffinity(0))
+    def worker(q):
+        torch.set_num_threads(1)
+        t0 = time.perf_counter(); ref_pass(); q.put(time.perf_counter() - t0)
+    ctxm = mp.get_context("fork")
+    runs = []
+    for _ in range(3):
+        q = ctxm.Queue()
+        ps = [ctxm.Process(target=worker, args=(q,)) for _ in range(P)]
+        t0 = time.perf_counter()
+        for p_ in ps: p_.start()
+        for p_ in ps: p_.join()
+        runs.append(time.perf_counter() - t0)
+    t_par = float(np.median(runs))
+    model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][:1]
     print(json.dumps(dict(config=name, B=B, n=n, reference_env_steps_per_s=B * n / t_ref, oracle_env_steps_per_s=B * n / t_orc,
                           ratio_oracle_over_reference=t_ref / t_orc, cores=1,
-                          note="reference = tools.Container + pack.update_dynamic/update_mask (torch CPU), this container")))
+                          procs=P, reference_env_steps_per_s_procs=P * B * n / t_par,
+                          cpu_model=model[0] if model else None,
+                          note="reference = tools.Container + pack.update_dynamic/update_mask (torch CPU), this container; "
+                               "procs = one forked process per CPU, each a whole B = 128 pass")), flush=True)
