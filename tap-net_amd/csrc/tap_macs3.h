@@ -14,7 +14,7 @@
 //         x-neighbours of the row AND every cell of the row (the "strictly inside" case)
 //     (checked against the reference's lists over 2.3e5 rows, scratch notes in DESIGN.md).  Each
 //     cell carries its column of F as ceil(H/64) u64 (bit z), stored complemented so that a zeroed state
-//     blob is the empty container; ceil(H/64) <= 4 words per cell, hence H <= 256.
+//     blob is the empty container; ceil(H/64) <= 8 words per cell, hence H <= 512.
 //   * voxel *values* (which block) are only compared in the "partly covered top" case
 //     (tools.py:2924-2942) and are recomputed from the placement history when that case occurs.
 //
@@ -33,7 +33,8 @@
 #include "tap_place.h"
 
 constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 8x8, 40 blocks)
-constexpr int MACS3_MAX_H = 256;   // HW = ceil(H / 64) <= 4 words per cell
+constexpr int MACS3_MAX_H = 512;   // HW = ceil(H / 64) <= 8 words per cell
+constexpr int MACS3_MAX_HW = MACS3_MAX_H / 64;
 constexpr int MACS3_HIST = 2;      // ints per history entry: x | y<<4 | xx<<8 | yy<<12 | placed<<16,  z | zz<<16
 
 __host__ __device__ constexpr int macs3_hw(int H) { return (H + 63) / 64; }
@@ -528,11 +529,11 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         res.placed = 1; res.x = px; res.y = py; res.z = Z; res.stab = stab;
         const int cx = cell / L, cy = cell - cx * L;
         const bool foot = cell < cells && cx >= px && cx < px + bx && cy >= py && cy < py + by;
-        u64 nw[4] = {0, 0, 0, 0};
+        u64 nw[MACS3_MAX_HW] = {};
         if (foot) {
             // update_level_free_space (:2989-3041) on this cell's column of F, 64 levels at a time
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
+            for (int w = 0; w < MACS3_MAX_HW; ++w) {
                 if (w >= HW) break;
                 u64 keep = 0;
                 if (px > 0 && px + bx < W) {
@@ -549,7 +550,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         tap_wave_lds_sync(); // every neighbour word is read before any is replaced
         if (foot) {
 #pragma unroll
-            for (int w = 0; w < 4; ++w) if (w < HW) S.occ[(size_t)cell * HW + w] = nw[w];
+            for (int w = 0; w < MACS3_MAX_HW; ++w) if (w < HW) S.occ[(size_t)cell * HW + w] = nw[w];
         }
         cnt.valid += vol;
         cnt.empty = emp;
