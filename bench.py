@@ -105,7 +105,7 @@ class HotPath(object):
     rolling = False
     kind = "transition"
 
-    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None, bits=True, instances=None):
+    def __init__(self, cfg, B, start, device, seed=12345, fused=True, window=None, bits=True, instances=None, tile_from=None):
         _, D, cs, n, _, reward, strategy = cfg
         self.cfg = cfg
         self.D, self.cs, self.n, self.B, self.device = D, cs, n, B, device
@@ -117,6 +117,14 @@ class HotPath(object):
         self.instances = instances
         self.static, self.dynamic0, self.tape, self.cs0 = [], [], [], []
         for w in range(self.windows):
+            if tile_from is not None:                               # batch sweep: another pass's instances and tape, tiled
+                k = B // tile_from.B
+                assert k * tile_from.B == B
+                self.static.append(tile_from.static[w].repeat(k, 1, 1))
+                self.dynamic0.append(tile_from.dynamic0[w].repeat(k, 1, 1))
+                self.tape.append(tile_from.tape[w].repeat(1, k).contiguous())
+                self.cs0.append(T.pack.dynamic_colsum(self.dynamic0[-1], self.nw).clone() if not bits else None)
+                continue
             if instances == "generate":                             # RAND instances of the device-side generator (f1)
                 static, dynamic = synth.device_rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start, device=device)
                 static, dynamic = static.cpu(), dynamic.cpu()
@@ -836,12 +844,15 @@ def run_sweep(cfg, hp, dev, use_graph, path):
     env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
     lines = []
     for b in (8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304):
+        if b % hp.B:
+            continue
         try:
             h2 = HotPath((name, D, cs, n, b, reward, strategy), b, 0, dev, fused=hp.fused, bits=hp.bits,
-                         instances=None)                 # host-generated synthetic precedence: setup time stays bounded
+                         instances=hp.instances, tile_from=hp)   # this run's instances and tape, tiled
             steps = 20 if b <= 131072 else 6
             d2, g2 = time_passes(h2, steps, 2, use_graph, 1)
             k2, _, pass_us = kernel_event_times(h2, 3, g2[0] if g2 else None)
+            h2.env.check()
             rec = dict(config=name.split(" on ")[0], batch=b, env_steps_per_s=b * n * steps / d2,
                        pass_us=pass_us, step_us=pass_us / n,
                        alg_GBps=(env_b + mask_b) * b / (pass_us / n * 1e-6) / 1e9,
