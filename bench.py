@@ -791,12 +791,17 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
     out = {}
     if hp.kind != "transition" or world != 1:
         return out
+    trace = (lambda m: print("variants: " + m, file=sys.stderr, flush=True)) if os.environ.get("TAP_BENCH_TRACE") else (lambda m: None)
     # (a) cold: rotate over enough instance batches (inputs AND output buffers per slot) that the working set
     #     exceeds the 256 MB Infinity Cache several times over -- nothing a pass reads is cache-resident
     per_slot = sum(t.numel() * t.element_size() for t in (hp.dynamic0 + hp.static + hp.dyn + [hp.cur] + hp.maskb))
     slots = max(3, int(np.ceil(1.2e9 / per_slot)))
     slots = min(slots, 40)
+    skip = os.environ.get("TAP_BENCH_SKIP", "").split(",")
+    trace("cold")
     try:
+        if "cold" in skip:
+            raise RuntimeError("skipped")
         hps = [hp] + [HotPath(cfg, B, 0, dev, seed=777 + 1000 * k, fused=hp.fused, window=hp.nw if hp.windows > 1 else None,
                               bits=hp.bits, instances=hp.instances) for k in range(1, slots)]
         steps = max(slots * 4, 40)
@@ -812,7 +817,10 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
         out["cold"] = dict(error=str(ex))
     # (b) a policy between the steps: rollout.run_episode with RandomFeasiblePolicy (torch.multinomial on
     #     current_mask), eager launches, fresh output tensors every step -- the loop a trainer would run
+    trace("policy_in_loop")
     try:
+        if "eager" in skip:
+            raise RuntimeError("skipped")
         g = torch.Generator(device=dev)
         g.manual_seed(4242)
         pol = T.RandomFeasiblePolicy(g)
@@ -820,7 +828,8 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
         cw, ch = cs[0], cs[-1]
 
         def run():
-            return T.run_episode(st, dy, pol, cw, ch, reward_type=reward, packing_strategy=strategy)
+            # a fresh tensor per episode, as a DataLoader would hand over: its bit shadow is built again
+            return T.run_episode(st, dy.clone(), pol, cw, ch, reward_type=reward, packing_strategy=strategy)
         for _ in range(3):
             r = run()
         torch.cuda.synchronize(dev)
@@ -836,6 +845,64 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
                                           "between the fused steps, eager launches, bit shadow built per episode")
     except Exception as ex:                                  # pragma: no cover
         out["policy_in_loop"] = dict(error=str(ex))
+    # (c) the same loop -- policy included -- captured once in a hipGraph: with pack.set_binary_check('trust') the
+    #     seams make no host read, so episode set-up (fresh container, shadow + initial mask in one launch), the
+    #     policy's torch ops and the fused steps all replay from one graph
+    trace("policy_in_loop_graph")
+    try:
+        T.pack.set_binary_check('trust')
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(4243)
+        u = torch.rand(B, hp.nw, device=dev, generator=g2)      # refreshed (eagerly) before every replay
+        pol2 = T.UniformPickPolicy(u)
+        st, dy = hp.static[0], hp.dynamic0[0]
+        cw, ch = cs[0], cs[-1]
+
+        def run2():
+            return T.run_episode(st, dy.clone(), pol2, cw, ch, reward_type=reward, packing_strategy=strategy)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run2(); run2()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        trace("capture")
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            rec = run2()
+        trace("replay")
+        for _ in range(3):
+            u.uniform_(generator=g2)
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        trace("timed replays")
+        steps = 100
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            u.uniform_(generator=g2)
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        rec["env"].check()
+        T.pack.check_binary()
+        # the replayed episode is a real one: its tour is feasible and its reward is what the oracle gives for it
+        O = _oracle()
+        V = min(VERIFY_ENVS, B)
+        tour = rec["tour_idx"][:V].cpu().numpy()
+        stn = st[:V].cpu().numpy()
+        blocks = np.stack([stn[np.arange(V), 1:, tour[:, k]] for k in range(hp.nw)], axis=1).astype(np.int32)
+        want = O.run_episodes(O.make_desc(cs, hp.nw, reward, "diff", strategy), blocks, nthreads=os.cpu_count() or 1,
+                              want_heightmaps=False)
+        okv = want["nerr"] == 0 and np.array_equal(rec["reward"][:V].cpu().numpy(), -want["ratio"].astype(np.float32))
+        out["policy_in_loop_graph"] = dict(value=B * hp.nw * steps / dt, unit="env-steps/s", steps=steps, verified=bool(okv),
+                                           what="rollout.run_episode with UniformPickPolicy (k-th selectable column by "
+                                                "cumulative sum, from uniforms drawn before each replay) captured in one "
+                                                "hipGraph -- fresh container, shadow + initial mask, the policy's torch ops and "
+                                                "the fused steps (pack.set_binary_check('trust'): no host read in the seams)")
+    except Exception as ex:                                  # pragma: no cover
+        out["policy_in_loop_graph"] = dict(error=str(ex)[:300])
+    finally:
+        T.pack.set_binary_check('check')
     return out
 
 

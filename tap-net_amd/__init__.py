@@ -12,8 +12,8 @@ from .generate import generate_instances                       # noqa: F401
 from .pack import (EnvTransition, MaskStepper, PACKDataset, initial_mask, reward,   # noqa: F401
                    update_dynamic, update_mask)
 from .rolling import RollingWindows, run_rolling_episode            # noqa: F401
-from .rollout import RandomFeasiblePolicy, TapePolicy, run_episode   # noqa: F401
+from .rollout import RandomFeasiblePolicy, TapePolicy, UniformPickPolicy, run_episode   # noqa: F401
 
 __all__ = ["BatchedContainer", "Container", "MaskStepper", "EnvTransition", "PACKDataset", "initial_mask", "reward",
-           "update_dynamic", "update_mask", "run_episode", "TapePolicy", "RandomFeasiblePolicy",
+           "update_dynamic", "update_mask", "run_episode", "TapePolicy", "RandomFeasiblePolicy", "UniformPickPolicy",
            "generate_instances", "RollingWindows", "run_rolling_episode", "TapError", "TapOverflowError"]

@@ -34,6 +34,22 @@ class RandomFeasiblePolicy(object):
         return torch.multinomial(current_mask, 1, generator=self.generator).squeeze(1)
 
 
+class UniformPickPolicy(object):
+    """Uniformly random selectable column from PRE-DRAWN uniforms ``u`` (B, steps) in [0, 1): the k-th selectable
+    column of ``current_mask`` with k = floor(u * count), by cumulative sum -- plain deterministic torch ops, so
+    an episode with this policy can be captured in a HIP graph and replayed on refreshed ``u`` (torch's own
+    in-graph RNG, ``torch.multinomial`` with a graph-registered generator, aborted under back-to-back replays on
+    this ROCm stack)."""
+
+    def __init__(self, u):
+        self.u = u
+
+    def __call__(self, step, current_mask, **_):
+        cnt = current_mask.sum(1)
+        k = torch.minimum((self.u[:, step] * cnt).floor(), cnt - 1).clamp_(min=0)
+        return (current_mask.cumsum(1) > k.unsqueeze(1)).to(torch.float32).argmax(1)
+
+
 def run_episode(static, dynamic, policy, container_width, container_height,
                 reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
                 input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True, bits=None,
