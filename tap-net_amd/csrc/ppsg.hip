@@ -199,8 +199,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_ppsg_check(int B, int n, int inpu
     const u64 *r = rel + (size_t)b * 5 * n;
     u64 left = n == 64 ? ~0ull : ((1ull << n) - 1ull);                        // blocks still in the container
     for (int s = n - 1; s >= 0 && ok; --s) {
-        const u64 mv = r[s] & left, lf = r[n + s] & left, rt = r[2 * n + s] & left, fw = r[3 * n + s] & left,
-                  bw = r[4 * n + s] & left;
+        const u64 *q = r + n + 4 * s;                                       // tap_rolling_init's layout (tapenv.h)
+        const u64 mv = r[s] & left, lf = q[0] & left, rt = q[1] & left, fw = q[2] & left, bw = q[3] & left;
         const bool x = fw && bw, y = lf && rt;
         if (mv == 0 && (input_simple || (!x && !y))) left &= ~(1ull << s);   // :142-149
         else ok = false;

@@ -106,8 +106,13 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_init(RollArgs a)
         if (y == 0) fwd |= 1ull << b;
         if (y + by == a.L) bwd |= 1ull << b;
     }
+    // layout per instance (5*N words): the N movement masks first (every live node's is read each step: 8*N
+    // contiguous bytes), then one 4-word record per node with its side masks (only the <= child window nodes'
+    // records are read each step: one 32-byte piece of a cache line each instead of four scattered words)
     u64 *r = a.rel + (size_t)inst * 5 * n;
-    r[b] = move; r[n + b] = left; r[2 * n + b] = right; r[3 * n + b] = fwd; r[4 * n + b] = bwd;
+    r[b] = move;
+    u64 *q = r + n + 4 * b;
+    q[0] = left; q[1] = right; q[2] = fwd; q[3] = bwd;
 #undef BX
 #undef BY
 #undef BZ
@@ -260,7 +265,7 @@ __device__ __forceinline__ RollNode rolling_node_loads(const RollArgs &a, int in
     RollNode nd = {{rel0, 0, 0, 0, 0}, {0, 0, 0}};
     if (on) {
 #pragma unroll
-        for (int k = 1; k < 5; ++k) nd.rel[k] = a.rel[((size_t)inst * 5 + k) * a.N + v];
+        for (int k = 1; k < 5; ++k) nd.rel[k] = a.rel[(size_t)inst * 5 * a.N + a.N + 4 * v + (k - 1)];   // the node's record
 #pragma unroll
         for (int k = 0; k < D; ++k) nd.bdim[k] = a.blocks[((size_t)inst * a.N + v) * D + k];
     }
