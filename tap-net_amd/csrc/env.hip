@@ -56,7 +56,9 @@ extern "C" int tap_ctx_create(int device, tap_ctx **out)
     c->stab_lut = nullptr;
     int prev = 0;
     (void)hipGetDevice(&prev);
+    c->chk = nullptr;
     bool ok = hipSetDevice(device) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&c->chk), 2 * sizeof(int32_t)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&c->stab_lut), TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipMemset(c->stab_lut, 0, TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess;
     if (ok) {
@@ -65,6 +67,7 @@ extern "C" int tap_ctx_create(int device, tap_ctx **out)
     }
     (void)hipSetDevice(prev);
     if (!ok) {
+        if (c->chk) (void)hipFree(c->chk);
         if (c->stab_lut) (void)hipFree(c->stab_lut);
         delete c;
         return TAP_E_HIP;
@@ -77,6 +80,7 @@ extern "C" void tap_ctx_destroy(tap_ctx *ctx)
 {
     if (!ctx) return;
     if (ctx->stab_lut) (void)hipFree(ctx->stab_lut);
+    if (ctx->chk) (void)hipFree(ctx->chk);
     delete ctx;
 }
 
@@ -406,6 +410,18 @@ extern "C" int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *s
     return TAP_OK;
 }
 
+__global__ void __launch_bounds__(TAP_BLOCK) k_env_check(int B, const int32_t *err, int32_t *out)
+{
+    int bad = 0, bits = 0;
+    for (int i = blockIdx.x * TAP_BLOCK + threadIdx.x; i < B; i += gridDim.x * TAP_BLOCK) {
+        const int e = err[i];
+        bad += e != 0;
+        bits |= e;
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o); bits |= __shfl_xor(bits, o); }
+    if ((threadIdx.x & 63) == 0 && bad) { atomicAdd(&out[0], bad); atomicOr(&out[1], bits); }
+}
+
 extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *state,
                              int32_t *n_bad_out, void *stream)
 {
@@ -415,20 +431,26 @@ extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *st
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
-    int32_t *host = new int32_t[d->B > 0 ? d->B : 1];
-    hipError_t e = hipMemcpyAsync(host, v.err, (size_t)d->B * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) {
-        delete[] host;
-        return tap_fail(ctx, TAP_E_HIP, "error-word readback failed: %s", hipGetErrorString(e));
+    // the sticky error words are reduced on the device (count of flagged envs, OR of their bits): the host
+    // reads 8 bytes, not B words
+    int32_t host[2] = {0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ctx->chk, 0, 2 * sizeof(int32_t), st);
+    if (e == hipSuccess) {
+        const int grid = min((d->B + TAP_BLOCK - 1) / TAP_BLOCK, 1024);
+        hipLaunchKernelGGL(k_env_check, dim3(grid), dim3(TAP_BLOCK), 0, st, d->B, v.err, ctx->chk);
+        e = hipGetLastError();
     }
-    int bad = 0, bits = 0;
-    for (int i = 0; i < d->B; ++i) if (host[i]) { ++bad; bits |= host[i]; }
-    delete[] host;
+    if (e == hipSuccess) e = hipMemcpyAsync(host, ctx->chk, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return tap_fail(ctx, TAP_E_HIP, "error-word readback failed: %s", hipGetErrorString(e));
+    const int bad = host[0], bits = host[1];
     if (n_bad_out) *n_bad_out = bad;
     if (bits & 1) return tap_fail(ctx, TAP_E_OVERFLOW, "%d container(s) exceeded height H=%d", bad, d->H);
     if (bits & 2) return tap_fail(ctx, TAP_E_STEPS, "%d container(s) stepped more than blocks_num=%d times", bad, d->n_max);
     if (bits & 4) return tap_fail(ctx, TAP_E_INVALID, "%d container(s) were given a block side < 1 or a column index outside [0, nR)", bad);
+    if (bits & 8) return tap_fail(ctx, TAP_E_OVERFLOW, "%d container(s) reached a state in which the reference's MACS code raises (tools.py:2550 IndexError / :2865 UnboundLocalError)", bad);
+    if (bits & 16) return tap_fail(ctx, TAP_E_UNSUPPORTED, "%d container(s) exceeded the MACS candidate-list capacity", bad);
     return TAP_OK;
 }
 

@@ -13,6 +13,7 @@
 struct tap_ctx {
     int device;
     uint32_t *stab_lut; // device: tap_stable3d for footprints <= 4x4 (tap_place.h), built at create
+    int32_t *chk;       // device: 2 ints (flagged envs, OR of their error words) for tap_env_check
     char err[512];
 };
 
