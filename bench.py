@@ -41,6 +41,11 @@ from tap_net_amd import dist as tdist       # noqa: E402
 
 
 
+def _usable_cpus():
+    """CPUs this process may use (affinity and cgroup quota), capped: the oracle's OpenMP team for verification"""
+    return max(1, min(cpu_info()[2], 32))
+
+
 def _oracle():
     """The CPU oracle (test infrastructure): only the verification after the timed region and the
     cpu_baseline leg load it -- never the timed path."""
@@ -240,7 +245,7 @@ class HotPath(object):
         blocks = np.concatenate([np.stack([s[ar, 1:, t[:, k]] for k in range(self.nw)], axis=1)
                                  for s, t in zip(st, tp)], axis=1).astype(np.int32)
         ref = O.run_episodes(O.make_desc(self.cs, self.n, self.reward_type, "diff", self.strategy), blocks,
-                             nthreads=os.cpu_count() or 1, want_heightmaps=True)
+                             nthreads=_usable_cpus(), want_heightmaps=True)
         if ref["nerr"]:
             return dict(verified=False, why="the oracle flags %d envs of the slice" % ref["nerr"])
         bad = []
@@ -299,11 +304,11 @@ class EpisodeHotPath(HotPath):
         O = _oracle()
         V = min(nenv, self.B)
         st, tour = self.static[0][:V].cpu().numpy(), self.tour[:V].cpu().numpy()
-        nerr, want = O.reward(st, tour, self.reward_type, self.cs[0], self.cs[-1], nthreads=os.cpu_count() or 1)
+        nerr, want = O.reward(st, tour, self.reward_type, self.cs[0], self.cs[-1], nthreads=_usable_cpus())
         ar = np.arange(V)
         blocks = np.stack([st[ar, 1:, tour[:, k]] for k in range(self.n)], axis=1).astype(np.int32)
         ref = O.run_episodes(O.make_desc(self.cs, self.n, self.reward_type, "full", "LB_GREEDY"), blocks,
-                             nthreads=os.cpu_count() or 1, want_heightmaps=False)
+                             nthreads=_usable_cpus(), want_heightmaps=False)
         bad = []
         if nerr or not np.array_equal(self.reward[:V].cpu().numpy(), want):
             bad.append("reward")
@@ -891,7 +896,7 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
         tour = rec["tour_idx"][:V].cpu().numpy()
         stn = st[:V].cpu().numpy()
         blocks = np.stack([stn[np.arange(V), 1:, tour[:, k]] for k in range(hp.nw)], axis=1).astype(np.int32)
-        want = O.run_episodes(O.make_desc(cs, hp.nw, reward, "diff", strategy), blocks, nthreads=os.cpu_count() or 1,
+        want = O.run_episodes(O.make_desc(cs, hp.nw, reward, "diff", strategy), blocks, nthreads=_usable_cpus(),
                               want_heightmaps=False)
         okv = want["nerr"] == 0 and np.array_equal(rec["reward"][:V].cpu().numpy(), -want["ratio"].astype(np.float32))
         out["policy_in_loop_graph"] = dict(value=B * hp.nw * steps / dt, unit="env-steps/s", steps=steps, verified=bool(okv),
@@ -1061,18 +1066,19 @@ def main():
         # nothing but that kernel the graph-replayed pass / launches is the cleaner figure (it includes the gap)
         launches = hp.launches_per_pass()
         if hp.kind == "transition" and hp.fused:
-            other = sum(max(kt[k]["avg_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
+            other = sum(max(kt[k]["med_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
             dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
             how = "(graph-replayed pass - the other kernels' event time) / launches; includes the inter-kernel gap"
         elif hp.kind == "episode":
             dom_us, how = pass_us, "event-bracketed pass (one launch)"
         else:
-            dom_us = max(kt[dom]["avg_us"] - empty_us, 1e-3)
-            how = "event-bracketed launch minus an empty event pair"
+            dom_us = max(kt[dom]["med_us"] - empty_us, 1e-3)
+            how = "median event-bracketed launch minus an empty event pair"
         ach = per_launch[dom] / (dom_us * 1e-6) / 1e9
         kernels = {}
         for k in names:
-            kernels[k] = dict(avg_us_event_pair=round(kt[k]["avg_us"], 3), launches_per_pass=kt[k]["launches"] // npass)
+            kernels[k] = dict(med_us_event_pair=round(kt[k]["med_us"], 3), avg_us_event_pair=round(kt[k]["avg_us"], 3),
+                              launches_per_pass=kt[k]["launches"] // npass)
             if k in per_launch:
                 kernels[k]["alg_bytes_per_launch"] = per_launch[k]
         tkey = args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")

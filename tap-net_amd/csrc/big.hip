@@ -221,7 +221,8 @@ int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
 {
     const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
     if (grid == 0) return TAP_OK;
-    hipLaunchKernelGGL(k_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, tap_big_scratch(&a.d, state));
+    (void)state;
+    hipLaunchKernelGGL(k_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.scratch);
     TAP_LAUNCH_CHECK(ctx, "k_big_step");
     return TAP_OK;
 }

@@ -254,9 +254,8 @@ int tap_lb_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
     if (a.d.W + 2 > 250) return tap_fail(ctx, TAP_E_UNSUPPORTED, "legacy LB: container width %d too large", a.d.W);
     const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
     if (grid == 0) return TAP_OK;
-    LbExtra x;
-    tap_lb_layout(&a.d, state, &x);
-    hipLaunchKernelGGL(k_lb_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, x.vox, x.lfs, x.lfn, x.cap);
+    (void)state;
+    hipLaunchKernelGGL(k_lb_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.vox, a.v.lfs, a.v.lfn, a.d.W + 2);
     TAP_LAUNCH_CHECK(ctx, "k_lb_step");
     return TAP_OK;
 }

@@ -73,6 +73,10 @@ struct EnvView {
     uint8_t *stable;
     int32_t *blk;
     unsigned long long *occ;
+    int32_t *scratch; // LB_GREEDY above 64 cells (big.hip): cells ints per container
+    int16_t *vox;     // legacy LB (lb.hip): [B][cells][H] block ids, -1 under covered holes   (tools.py:3630)
+    uint8_t *lfs;     //   [B][H*L][W+2] level_free_space lists                                (tools.py:3649-3653)
+    int8_t *lfn;      //   [B][H*L] list length - 1: the zeroed blob is the initial [0] everywhere
 };
 
 inline size_t tap_align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -93,13 +97,16 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
     size_t o_pos = take(nD * B * 4), o_st = take((size_t)d->n_max * B);
     size_t o_blk = (d->strategy == TAP_MACS || d->strategy == TAP_LB) ? take(nD * B * 4) : 0;
     size_t o_occ = (d->strategy == TAP_MACS && d->D == 3) ? take(B * cells * 8 * (size_t)((d->H + 63) / 64)) : 0;
-    if (tap_is_big(d)) take(B * cells * 4);   // big.hip: W*L ints of scratch per container, last section
-    if (d->strategy == TAP_LB) {   // legacy LB (lb.hip): voxel ids, level lists and their lengths; see tap_lb_layout
-        take(B * cells * (size_t)d->H * 2);
-        take(B * (size_t)d->H * d->L * (size_t)(d->W + 2));
-        take(B * (size_t)d->H * d->L);
-    }
+    const bool lb = d->strategy == TAP_LB;
+    size_t o_scr = tap_is_big(d) ? take(B * cells * 4) : 0;
+    size_t o_vox = lb ? take(B * cells * (size_t)d->H * 2) : 0;
+    size_t o_lfs = lb ? take(B * (size_t)d->H * d->L * (size_t)(d->W + 2)) : 0;
+    size_t o_lfn = lb ? take(B * (size_t)d->H * d->L) : 0;
     if (v) {
+        v->scratch = tap_is_big(d) ? reinterpret_cast<int32_t *>(p + o_scr) : nullptr;
+        v->vox = lb ? reinterpret_cast<int16_t *>(p + o_vox) : nullptr;
+        v->lfs = lb ? reinterpret_cast<uint8_t *>(p + o_lfs) : nullptr;
+        v->lfn = lb ? reinterpret_cast<int8_t *>(p + o_lfn) : nullptr;
         v->hm = reinterpret_cast<int32_t *>(p + o_hm);
         v->cnt = reinterpret_cast<int32_t *>(p + o_cnt);
         v->err = reinterpret_cast<int32_t *>(p + o_err);
@@ -109,37 +116,6 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
         v->occ = (d->strategy == TAP_MACS && d->D == 3) ? reinterpret_cast<unsigned long long *>(p + o_occ) : nullptr;
     }
     return off;
-}
-
-// big.hip's scratch: the last section of an LB_GREEDY blob (no blk / occ sections for that strategy)
-inline int32_t *tap_big_scratch(const tap_env_desc *d, void *base)
-{
-    const size_t B = (size_t)d->B, cells = (size_t)d->W * d->L, nD = (size_t)d->n_max * d->D;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = tap_align256(off + bytes); return o; };
-    take(B * cells * 4); take(B * 16); take(B * 4); take(nD * B * 4); take((size_t)d->n_max * B);
-    return reinterpret_cast<int32_t *>(static_cast<char *>(base) + take(B * cells * 4));
-}
-
-// the extra sections of a legacy-LB state blob (they follow everything tap_env_layout hands out above them)
-struct LbExtra {
-    int16_t *vox; // [B][cells][H] block ids, -1 under covered holes   (tools.py:3630)
-    uint8_t *lfs; // [B][H*L][cap] level_free_space lists              (tools.py:3649-3653)
-    int8_t *lfn;  // [B][H*L] list length - 1: the zeroed blob is the initial [0] everywhere
-    int cap;
-};
-
-inline void tap_lb_layout(const tap_env_desc *d, void *base, LbExtra *x)
-{
-    const size_t B = (size_t)d->B, cells = (size_t)d->W * d->L, nD = (size_t)d->n_max * d->D;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = tap_align256(off + bytes); return o; };
-    take(B * cells * 4); take(B * 16); take(B * 4); take(nD * B * 4); take((size_t)d->n_max * B); take(nD * B * 4);
-    char *p = static_cast<char *>(base);
-    x->cap = d->W + 2;
-    x->vox = reinterpret_cast<int16_t *>(p + take(B * cells * (size_t)d->H * 2));
-    x->lfs = reinterpret_cast<uint8_t *>(p + take(B * (size_t)d->H * d->L * (size_t)x->cap));
-    x->lfn = reinterpret_cast<int8_t *>(p + take(B * (size_t)d->H * d->L));
 }
 
 // arguments of one lock-step placement launch (env.hip, macs.hip)

@@ -169,6 +169,14 @@ def generate_ppsg_instances(batch_size, blocks_num, initial_container_width=7, i
             rows.append(torch.multinomial(prob.cpu().float(), S, replacement=True, generator=g))
         heights = keys.cpu()[torch.stack(rows)]
     heights = heights.to(device=dev, dtype=torch.int32).contiguous()
+    if tuple(heights.shape) != (B, S):
+        raise ValueError("heights must be (%d, %d)" % (B, S))
+    # a W x W x h box needs ceil(W/lim)^2 * ceil(h/lim) blocks to keep every side below max_size: for other
+    # heights the acceptance loop of generate.py:66-73 never ends (and the kernel would spin to its attempt cap)
+    lim = int(size_range[1]) - 1
+    need = (-(-W // lim)) ** 2 * ((heights + lim - 1) // lim)
+    if bool(((need > ns) | (heights < 1)).any()):
+        raise ValueError("a slab height cannot be cut into %d blocks with sides < %d" % (ns, int(size_range[1])))
     cs = initial_container(3, initial_container_width, initial_container_height)
     c, L = _lib.ctx(dev), _lib.lib()
     out_blocks = torch.zeros(B, n, 3, dtype=torch.int32, device=dev)
@@ -188,7 +196,7 @@ def generate_ppsg_instances(batch_size, blocks_num, initial_container_width=7, i
         att = torch.empty(m, S, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
             _lib.check(L.tap_ppsg_gt(c, m, S, ns, W, _lib.ptr(th), int(size_range[0]), int(size_range[1]), int(seed),
-                                     _lib.ptr(tid), 0, gen, 1 << 22, _lib.ptr(gtb), _lib.ptr(gtp), _lib.ptr(att),
+                                     _lib.ptr(tid), 0, gen, 1 << 20, _lib.ptr(gtb), _lib.ptr(gtp), _lib.ptr(att),
                                      _lib.stream_of(dev)), c)
         if bool((att < 0).any()):
             raise _lib.TapError(_lib.TAP_E_INVALID, "a perfect packing was not found within the attempt cap")
