@@ -224,11 +224,13 @@ int tap_ppsg_check(tap_ctx *ctx, int B, int n, int input_simple, const uint64_t 
 /* ---- rolling precedence windows (generate.py:1589-1839, rolling.py:589-637) ------------- */
 
 /* generate.InitialContainer.__init__: the five dependency graphs of B fully packed initial
- * containers with N <= 64 blocks each, as 64-bit column masks with bit a of a node j's mask = "block a
- * blocks block j": rel_out holds 5*N uint64 per instance -- first the N movement masks, then one 4-word
- * record (left, right, forward, backward) per node, so that a step reads the window nodes' side masks as
- * one piece of a cache line each;
- * state_out (B, 2) uint64 = (entered, window), both cleared. */
+ * containers with N <= 256 blocks each, as column masks of NW = ceil(N/64) uint64 words with bit a of a
+ * node j's mask = "block a blocks block j": rel_out holds 5*N*NW words per instance -- first the N movement
+ * masks, then one record of four masks (left, right, forward, backward) per node, so that a step reads the
+ * window nodes' side masks as one piece of a cache line each; state_out holds 2*NW words (entered, window).
+ * Up to 64 blocks an instance is handled by one wavefront (lane = node); above that by one thread per
+ * instance (tap_rolling_window only, not tap_rolling_step);
+ * state_out is cleared. */
 int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container_size, int arm_size,
                      const int32_t *blocks, const int32_t *positions, uint64_t *rel_out,
                      uint64_t *state_out, void *stream);

@@ -544,10 +544,197 @@ k_rolling_step(RollStepArgs a)
     rolling_window_wave<D>(a.r, base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
 }
 
+// ---- more than 64 blocks per instance ------------------------------------------------------------------------
+// The kernels above hold a node per lane and a graph per 64-bit mask.  Instances of 65 .. 256 blocks (the
+// reference's --total_blocks_num is free, rolling.py:702) take this path instead: the same steps with masks of
+// NW = ceil(N/64) words, ONE THREAD per instance (relations: one thread per node) -- a correctness path like
+// big.hip, not a tuned one.  Layout: rel = 5*N*NW words per instance (N movement masks, then per node the four
+// side masks), state = 2*NW words (entered, window).
+constexpr int ROLL_MAX_N = 256, ROLL_MAX_NW = ROLL_MAX_N / 64;
+
+struct NMask {
+    u64 w[ROLL_MAX_NW];
+};
+__device__ __forceinline__ bool nm_test(const NMask &m, int i) { return (m.w[i >> 6] >> (i & 63)) & 1ull; }
+__device__ __forceinline__ void nm_set(NMask &m, int i) { m.w[i >> 6] |= 1ull << (i & 63); }
+__device__ __forceinline__ void nm_clear(NMask &m, int i) { m.w[i >> 6] &= ~(1ull << (i & 63)); }
+__device__ __forceinline__ int nm_count(const NMask &m, int NW) { int c = 0; for (int k = 0; k < NW; ++k) c += __popcll(m.w[k]); return c; }
+__device__ __forceinline__ bool nm_meets(const u64 *a, const NMask &b, int NW) { bool r = false; for (int k = 0; k < NW; ++k) r |= (a[k] & b.w[k]) != 0; return r; }
+
+template <int D>
+__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_init_big(RollArgs a)
+{
+    const long t = (long)blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const int n = a.N, NW = (n + 63) / 64;
+    if (t >= (long)a.B * n) return;
+    const int inst = (int)(t / n), b = (int)(t - (long)inst * n);
+    const int32_t *blk = a.blocks + (size_t)inst * n * D, *pos = a.positions + (size_t)inst * n * D;
+    if (b == 0) for (int k = 0; k < 2 * NW; ++k) a.state[(size_t)inst * 2 * NW + k] = 0;
+#define BX(i) blk[(i) * D]
+#define BY(i) (D == 3 ? blk[(i) * D + 1] : 1)
+#define BZ(i) blk[(i) * D + D - 1]
+#define PX(i) pos[(i) * D]
+#define PY(i) (D == 3 ? pos[(i) * D + 1] : 0)
+#define PZ(i) pos[(i) * D + D - 1]
+    const int x = PX(b), y = PY(b), z = PZ(b), bx = BX(b), by = BY(b), bz = BZ(b);
+    const int top = z + bz, z_mid = z + (bz - 1) / 2;
+    NMask m[5] = {};
+    if (D == 2) {                                                     // generate.py:575-647
+        for (int o = 0; o < n; ++o) {
+            if (o == b) continue;
+            const int ox = PX(o), oz = PZ(o), obx = BX(o), otop = oz + BZ(o);
+            if (rng_meet(ox, ox + obx, x, x + bx) && oz > z) nm_set(m[0], o);
+            if (x >= a.arm && rng_meet(ox, ox + obx, x - a.arm, x) && otop > z_mid) nm_set(m[1], o);
+            if (x + bx <= a.W - a.arm && rng_meet(ox, ox + obx, x + bx, x + bx + a.arm) && otop > z_mid) nm_set(m[2], o);
+        }
+        if (x < a.arm) nm_set(m[1], b);
+        if (x + bx > a.W - a.arm) nm_set(m[2], b);
+    } else {                                                          // generate.py:649-752
+        for (int i = 0; i < bx; ++i)
+            for (int j = 0; j < by; ++j) {
+                const int cx = x + i, cy = y + j;
+                int best = -1, bestz = INT_MAX;
+                for (int o = 0; o < n; ++o) {
+                    if (o == b) continue;
+                    const int ox = PX(o), oy = PY(o), oz = PZ(o);
+                    if (cx >= ox && cx < ox + BX(o) && cy >= oy && cy < oy + BY(o) && oz >= top && oz < bestz) { bestz = oz; best = o; }
+                }
+                if (best >= 0) nm_set(m[0], best);
+            }
+        const int ymid = y + (by - 1) / 2, xmid = x + (bx - 1) / 2;
+        for (int o = 0; o < n; ++o) {
+            if (o == b) continue;
+            const int ox = PX(o), oy = PY(o), otop = PZ(o) + BZ(o);
+            if (otop <= z_mid) continue;
+            const bool in_y = ymid >= oy && ymid < oy + BY(o), in_x = xmid >= ox && xmid < ox + BX(o);
+            if (x > 0 && in_y && x - 1 >= ox && x - 1 < ox + BX(o)) nm_set(m[1], o);
+            if (x + bx < a.W && in_y && x + bx >= ox && x + bx < ox + BX(o)) nm_set(m[2], o);
+            if (y > 0 && in_x && y - 1 >= oy && y - 1 < oy + BY(o)) nm_set(m[3], o);
+            if (y + by < a.L && in_x && y + by >= oy && y + by < oy + BY(o)) nm_set(m[4], o);
+        }
+        if (x == 0) nm_set(m[1], b);
+        if (x + bx == a.W) nm_set(m[2], b);
+        if (y == 0) nm_set(m[3], b);
+        if (y + by == a.L) nm_set(m[4], b);
+    }
+#undef BX
+#undef BY
+#undef BZ
+#undef PX
+#undef PY
+#undef PZ
+    u64 *r = a.rel + (size_t)inst * 5 * n * NW;
+    for (int k = 0; k < NW; ++k) r[(size_t)b * NW + k] = m[0].w[k];
+    u64 *q = r + (size_t)n * NW + (size_t)b * 4 * NW;
+    for (int s5 = 0; s5 < 4; ++s5) for (int k = 0; k < NW; ++k) q[s5 * NW + k] = m[1 + s5].w[k];
+}
+
+// remove_block + convert_to_input of ONE instance by one thread (rolling_window_wave, serial form)
+template <int D>
+__global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
+{
+    const int inst = blockIdx.x * 64 + threadIdx.x;
+    if (inst >= a.B) return;
+    const int N = a.N, NW = (N + 63) / 64, child = a.child;
+    constexpr int R = D == 2 ? 2 : 6;
+    const int nRc = child * R;
+    const u64 *rel0 = a.rel + (size_t)inst * 5 * N * NW;
+    const u64 *side = rel0 + (size_t)N * NW;
+    u64 *stp = a.state + (size_t)inst * 2 * NW;
+    NMask entered = {}, window = {}, all = {};
+    for (int k = 0; k < NW; ++k) { entered.w[k] = stp[k]; window.w[k] = stp[NW + k]; }
+    for (int i = 0; i < N; ++i) nm_set(all, i);
+    if (a.remove_ptr) {                                               // (1) rolling.py:632-637
+        long slot = tap_mod_col((long)a.remove_ptr[inst], child, nRc);
+        for (int i = 0; i < N; ++i)
+            if (nm_test(window, i) && slot-- == 0) { nm_clear(window, i); break; }
+    }
+    unsigned char lst[80], ord[80], pos[ROLL_MAX_N];
+    int count = 0;                                                    // (2) generate.py:1724-1750
+    for (int i = 0; i < N; ++i) if (nm_test(window, i)) lst[count++] = (unsigned char)i;
+    NMask added = {};
+    while (count < child) {
+        NMask gmc;
+        for (int k = 0; k < NW; ++k) gmc.w[k] = all.w[k] & ~(entered.w[k] | added.w[k]);
+        const bool single = nm_count(gmc, NW) == 1;
+        const int need = child - count;
+        int got = 0;
+        NMask take = {};
+        for (int j = 0; j < N && got < need; ++j)
+            if (nm_test(gmc, j) && (single || !nm_meets(rel0 + (size_t)j * NW, gmc, NW))) { nm_set(take, j); lst[count + got++] = (unsigned char)j; }
+        if (got == 0) break;
+        for (int k = 0; k < NW; ++k) added.w[k] |= take.w[k];
+        count += got;
+    }
+    for (int k = 0; k < NW; ++k) { entered.w[k] |= added.w[k]; window.w[k] |= added.w[k]; }
+    const int short_window = count != child;
+    for (int k = 0; k < NW; ++k) { stp[k] = entered.w[k]; stp[NW + k] = window.w[k]; }
+    if (a.err_out) a.err_out[inst] = short_window;
+    if (short_window) return;
+    int tbl[PYSET_CAP], tmp[PYSET_CAP];                               // the set-order tables, thread-private
+    if (2 * child < N) pyset_order(lst, child, ord, tbl, tmp);        // (3)
+    else { int m = 0; for (int i = 0; i < N; ++i) if (nm_test(window, i)) ord[m++] = (unsigned char)i; }
+    for (int i = 0; i < child; ++i) pos[ord[i]] = (unsigned char)i;
+    // (4) tensors (generate.py:1778-1822)
+    NMask after;
+    for (int k = 0; k < NW; ++k) after.w[k] = all.w[k] & ~entered.w[k];
+    const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+    const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
+    float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
+    const int rows = 3 * child;
+    int srt_i = 0;
+    for (int v = 0; v < N; ++v) {                                     // sorted position -> node: static's columns
+        if (!nm_test(window, v)) continue;
+        if (a.nodes_out) a.nodes_out[(size_t)inst * child + srt_i] = v;
+        for (int r = 0; r < R; ++r) {
+            const int *p = D == 2 ? perm2[r] : perm3[r];
+            const int col = r * child + srt_i;
+            st[col] = (float)srt_i;
+            for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)a.blocks[((size_t)inst * N + v) * D + p[k]];
+        }
+        ++srt_i;
+    }
+    for (int cm = 0; cm < child; ++cm) {                              // dynamic: cm = sub-graph index
+        const int v = ord[cm];
+        for (int r = 0; r < R; ++r) {
+            const int *p = D == 2 ? perm2[r] : perm3[r];
+            const int col = r * child + cm;
+            int sum[3] = {0, 0, 0};
+            u64 word = 0;
+            for (int sec = 0; sec < 3; ++sec) {
+                int k = 0;                                            // which relation guards this rotation (:1808-1821)
+                if (sec > 0) k = p[D - 1] == 0 ? sec : (D == 3 && p[D - 1] == 1) ? 2 + sec : -1;
+                for (int rm = 0; rm < child; ++rm) {
+                    const int u = ord[rm];
+                    bool bit = false;
+                    if (k == 0) bit = nm_test(window, u) && ((rel0[(size_t)v * NW + (u >> 6)] >> (u & 63)) & 1ull);
+                    else if (k > 0) {
+                        const u64 *sm = side + ((size_t)v * 4 + (k - 1)) * NW;
+                        bit = (sm[u >> 6] >> (u & 63)) & 1ull;        // u is a window node
+                        if (u == v && !bit) {                         // :1690-1705 a blocker outside every window so far
+                            bool out = false;
+                            for (int q = 0; q < NW; ++q) out |= (sm[q] & after.w[q]) != 0;
+                            bit = out;
+                        }
+                    }
+                    dy[(size_t)(sec * child + rm) * nRc + col] = bit ? 1.f : 0.f;
+                    sum[sec] += bit;
+                    if (bit && sec * child + rm < 64) word |= 1ull << (sec * child + rm);
+                }
+                if (a.colsum_out) a.colsum_out[((size_t)inst * 3 + sec) * nRc + col] = (float)sum[sec];
+            }
+            if (a.cur_mask_out) a.cur_mask_out[(size_t)inst * nRc + col] = (sum[1] * sum[2] + sum[0] != 0) ? 0.f : 1.f;
+            if (a.bits_out && rows <= 64) a.bits_out[(size_t)inst * nRc + col] = word;
+        }
+    }
+    (void)pos;
+}
+
 static int roll_check(tap_ctx *ctx, int B, int D, int N, int child)
 {
-    if ((D != 2 && D != 3) || B < 0 || N < 1 || N > 64 || child < 1 || child > N || child > 64)
-        return tap_fail(ctx, TAP_E_INVALID, "bad rolling arguments (total blocks <= 64, window <= total)");
+    if ((D != 2 && D != 3) || B < 0 || N < 1 || N > ROLL_MAX_N || child < 1 || child > N || child > 64)
+        return tap_fail(ctx, TAP_E_INVALID, "bad rolling arguments (total blocks <= %d, window <= min(total, 64))", ROLL_MAX_N);
     if (2 * child < N && child > 76)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "window too large for the set-order table");
     return TAP_OK;
@@ -568,6 +755,14 @@ extern "C" int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t
     a.state = reinterpret_cast<unsigned long long *>(state_out);
     const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
     if (grid == 0) return TAP_OK;
+    if (N > 64) {                                                     // one thread per node, multi-word masks
+        const long threads = (long)B * N;
+        const unsigned g2 = (unsigned)((threads + TAP_BLOCK - 1) / TAP_BLOCK);
+        if (D == 2) hipLaunchKernelGGL(k_rolling_init_big<2>, dim3(g2), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_rolling_init_big<3>, dim3(g2), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        TAP_LAUNCH_CHECK(ctx, "k_rolling_init_big");
+        return TAP_OK;
+    }
     if (D == 2) hipLaunchKernelGGL(k_rolling_init<2>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_rolling_init<3>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
     TAP_LAUNCH_CHECK(ctx, "k_rolling_init");
@@ -594,6 +789,14 @@ extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, 
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bits_out needs 3*child <= 64, (child*R) %% 4 == 0, child*R <= 256");
     const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
     if (grid == 0) return TAP_OK;
+    if (N > 64) {                                                     // one thread per instance
+        if (child > 76) return tap_fail(ctx, TAP_E_UNSUPPORTED, "window too large for the set-order table");
+        const int g2 = (B + 63) / 64;
+        if (D == 2) hipLaunchKernelGGL(k_rolling_window_big<2>, dim3(g2), dim3(64), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_rolling_window_big<3>, dim3(g2), dim3(64), 0, (hipStream_t)stream, a);
+        TAP_LAUNCH_CHECK(ctx, "k_rolling_window_big");
+        return TAP_OK;
+    }
     if (D == 2) hipLaunchKernelGGL(k_rolling_window<2>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_rolling_window<3>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
     TAP_LAUNCH_CHECK(ctx, "k_rolling_window");
@@ -624,6 +827,8 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: LB_GREEDY on containers of at most 64 cells (use tap_env_step_gather + tap_rolling_window)");
     rc = roll_check(ctx, d->B, d->D, N, child);
     if (rc) return rc;
+    if (N > 64)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: at most 64 blocks per instance (use tap_env_step_gather + tap_rolling_window)");
     if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||
         static_cur == static_next)
         return tap_fail(ctx, TAP_E_INVALID, "bad rolling_step arguments (static_cur and static_next must differ)");

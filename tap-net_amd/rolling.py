@@ -13,8 +13,10 @@ from .pack import EnvTransition
 
 
 class RollingWindows(object):
-    """B instances of N <= 64 packed blocks each; ``next(ptr)`` drops the block picked in the
-    previous window and returns the next window's network input."""
+    """B instances of N <= 256 packed blocks each; ``next(ptr)`` drops the block picked in the
+    previous window and returns the next window's network input.  Up to 64 blocks an instance is one
+    wavefront (lane = node, graphs = 64-bit masks) and ``step`` fuses the placement with the next window;
+    above that the same steps run one thread per instance on multi-word masks (``next`` only)."""
 
     def __init__(self, blocks, positions, initial_container_size, child_graph_size=10, arm_size=1):
         self.blocks = blocks.to(torch.int32).contiguous()
@@ -23,8 +25,9 @@ class RollingWindows(object):
         self.B, self.N, self.D = self.blocks.shape
         self.child = int(child_graph_size)
         self.R = 2 if self.D == 2 else 6
-        self.rel = torch.empty(self.B, 5, self.N, dtype=torch.int64, device=self.device)
-        self.state = torch.empty(self.B, 2, dtype=torch.int64, device=self.device)
+        nw = (self.N + 63) // 64                          # mask words per graph: 1 up to 64 blocks, up to 4 for 256
+        self.rel = torch.empty(self.B, 5, self.N * nw, dtype=torch.int64, device=self.device)
+        self.state = torch.empty(self.B, 2 * nw, dtype=torch.int64, device=self.device)
         self.steps_done = 0
         cs = (C.c_int32 * self.D)(*[int(v) for v in initial_container_size])
         self._ctx = _lib.ctx(self.device)
@@ -126,7 +129,7 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
     decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
     ar = torch.arange(B, device=dev)
     tour, picked, feats = [], [], []
-    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY and env.fused_ok
+    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY and env.fused_ok and N <= 64
     ptr, ratio, step = None, None, 0
     win = rw.next(None)
     for _ in range(N - child):                                   # one_step windows
