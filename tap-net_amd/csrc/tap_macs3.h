@@ -40,16 +40,16 @@ constexpr int MACS3_HIST = 2;      // ints per history entry: x | y<<4 | xx<<8 |
 __host__ __device__ constexpr int macs3_hw(int H) { return (H + 63) / 64; }
 
 // LDS words per env group: occ u64[G*HW] | lvm u64[G+2] | hm[G] | ord[G] | lvh[G+2] | lvr[G+2] | ems[CAP] |
-// lrun u8[256] | hist[2 n_max]   (lv*: the distinct levels of the height-map, at most cells + 1 of them;
+// lrun u8[256] | cand[12 G] | hist[2 n_max]   (lv*: the distinct levels of the height-map, at most cells + 1 of them;
 // lrun: longest run of ones of every byte)
 __host__ __device__ constexpr int macs3_group_words(int G, int n_max, int H)
 {
-    return 2 * G * macs3_hw(H) + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + 64 + MACS3_HIST * n_max;
+    return 2 * G * macs3_hw(H) + 2 * (G + 2) + G + G + 2 * (G + 2) + MACS3_EMS_CAP + 64 + 12 * G + MACS3_HIST * n_max;
 }
 
 struct Macs3Lds {
     u64 *occ, *lvm;
-    int *hm, *ord, *lvh, *lvr, *ems, *hist;
+    int *hm, *ord, *lvh, *lvr, *ems, *cand, *hist;
     unsigned char *lrun;
 };
 
@@ -65,7 +65,8 @@ __device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G, int H)
     m.lvr = m.lvh + G + 2;
     m.ems = m.lvr + G + 2;
     m.lrun = reinterpret_cast<unsigned char *>(m.ems + MACS3_EMS_CAP);
-    m.hist = m.ems + MACS3_EMS_CAP + 64;
+    m.cand = m.ems + MACS3_EMS_CAP + 64;     // EMS candidates of one round, in list order (phase 1)
+    m.hist = m.cand + 12 * G;
     return m;
 }
 
@@ -204,171 +205,269 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     }
     int sx1 = 0;          // python's function-scope `x1` (tools.py:2823, 2870, 2901 assign it)
     bool x1def = false;   // ... which :2865 may read before any assignment (UnboundLocalError)
+    const mk below_me = ((mk)1 << cell) - 1;
+    // exclusive prefix sum of v over the group's lanes (and the group's total)
+    auto excl_scan = [&](int v, int &total) -> int {
+        int s_ = v;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            const int t_ = __shfl_up(s_, o, G);
+            if (cell >= o) s_ += t_;
+        }
+        total = __shfl(s_, gl0 + G - 1);
+        return s_ - v;
+    };
+    // the last lane (in list order) that assigned `x1` hands it on
+    auto carry_x1 = [&](bool asg, int asgv) {
+        const mk am = (mk)ballot_g<G>(asg, gl0);
+        const int v_ = __shfl(asgv, gl0 + (am ? m3_fls(am) : 0));
+        if (am) { sx1 = v_; x1def = true; }
+    };
 
     // (a) per-(level, row) free intervals (tools.py:2813-2841); level z is skipped when all its
-    //     lists equal those of z-1 (:2816), i.e. when no cell's F column changes between the two
+    //     lists equal those of z-1 (:2816), i.e. when no cell's F column changes between the two.
+    //     What a (level, row) pair contributes depends on the pair alone, so the pairs are evaluated one per
+    //     lane -- G / rows levels at a time -- into S.cand (8 slots per lane: <= 4 runs x <= 2 spaces) and
+    //     appended in (level, row, run) order with a prefix count.  The level masks come from ballots in a
+    //     short group-uniform loop; each lane keeps those of its own level.
     const int zmax = H - bz;                                                         // :2815
-    for (int w = 0; w < HW && 64 * w <= zmax; ++w) {
-        const u64 Fw = wordF(w), carry = w > 0 ? (wordF(w - 1) >> 63) : 0ull;
-        u64 chg = group_or64<G>(Fw ^ ((Fw << 1) | carry)) | (w == 0 ? 1ull : 0ull);
-        if (zmax - 64 * w < 63) chg &= (2ull << (zmax - 64 * w)) - 1ull;
-        while (chg) {
-            const int z = 64 * w + __ffsll((long long)chg) - 1;
-            chg &= chg - 1ull;
-            const mk Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : (mk)0, Tz = levelT(z);
-            for (int y = 0; y < L; ++y) {
-                if (y + by > L) break;                                               // :2818
-                const unsigned row = rowT(Fz, y), prow = y > 0 ? rowT(Fz, y - 1) : 0u;
-                if (y > 0 && row == prow) continue;                                  // :2819
-                const unsigned brow = z > 0 ? rowT(Fb, y) : 0u;
-                unsigned m = row;
-                while (m) {
-                    const int x1 = __ffs((int)m) - 1;
-                    const int len = __ffs((int)~(m >> x1)) - 1;
-                    const unsigned run = ((1u << len) - 1u) << x1;
-                    const int x2 = x1 + len - 1;
-                    m &= ~run;
-                    sx1 = x1; x1def = true;                                          // :2823
-                    if (x1 + bx > W) break;                                          // :2824
-                    if (y > 0 && m3_has_run(prow, run, x1, x2)) continue;            // :2825-2827
-                    if (z > 0 && m3_has_run(brow, run, x1, x2)) continue;            // :2828-2830
-                    bool xspace = true;                                              // :2831-2840
-                    int y2;
-                    for (y2 = y;; ++y2) {
-                        if (y2 == L - 1) break;
-                        if ((rowT(Tz, y2 + 1) & run) != run) break;
-                        if (xspace) {
-                            const unsigned f = rowT(Fz, y2 + 1);
-                            if (!(m3_inlist(f, x1) && m3_inlist(f, x2))) { xspace = false; M3_PUSH(x1, y, z, x2, y2); }
+    {
+        const int Lp = L - by + 1;                       // rows with y + by <= L (:2818)
+        const int LPR = G / Lp;                          // levels per round
+        const int ls = cell / Lp, yrow = cell - ls * Lp;
+        int slot = 0, myz = -1;
+        mk myF = 0, myB = 0, myT = 0;
+        auto flush = [&]() {
+            int cn = 0, asgv = 0;
+            bool asg = false;
+            if (myz >= 0) {
+                const int y = yrow, z = myz;
+                const unsigned row = rowT(myF, y), prow = y > 0 ? rowT(myF, y - 1) : 0u;
+                if (!(y > 0 && row == prow)) {                                       // :2819
+                    const unsigned brow = z > 0 ? rowT(myB, y) : 0u;
+                    unsigned m = row;
+                    while (m) {
+                        const int x1 = __ffs((int)m) - 1;
+                        const int len = __ffs((int)~(m >> x1)) - 1;
+                        const unsigned run = ((1u << len) - 1u) << x1;
+                        const int x2 = x1 + len - 1;
+                        m &= ~run;
+                        asg = true; asgv = x1;                                       // :2823
+                        if (x1 + bx > W) break;                                      // :2824
+                        if (y > 0 && m3_has_run(prow, run, x1, x2)) continue;        // :2825-2827
+                        if (z > 0 && m3_has_run(brow, run, x1, x2)) continue;        // :2828-2830
+                        bool xspace = true;                                          // :2831-2840
+                        int y2;
+                        for (y2 = y;; ++y2) {
+                            if (y2 == L - 1) break;
+                            if ((rowT(myT, y2 + 1) & run) != run) break;
+                            if (xspace) {
+                                const unsigned f = rowT(myF, y2 + 1);
+                                if (!(m3_inlist(f, x1) && m3_inlist(f, x2))) { xspace = false; S.cand[cell * 8 + cn++] = M3_PACK(x1, y, z, x2, y2); }
+                            }
                         }
+                        S.cand[cell * 8 + cn++] = M3_PACK(x1, y, z, x2, y2);
                     }
-                    M3_PUSH(x1, y, z, x2, y2);
                 }
             }
+            int total;
+            const int off = excl_scan(cn, total);
+            for (int j = 0; j < cn; ++j) {
+                const int at = n_ems + off + j;
+                if (at < MACS3_EMS_CAP) S.ems[at] = S.cand[cell * 8 + j];            // own slots: no hand-off needed
+                else err |= 16;
+            }
+            n_ems = min(MACS3_EMS_CAP, n_ems + total);
+            carry_x1(asg, asgv);
+            slot = 0; myz = -1;
+        };
+        for (int w = 0; w < HW && 64 * w <= zmax; ++w) {
+            const u64 Fw = wordF(w), carry = w > 0 ? (wordF(w - 1) >> 63) : 0ull;
+            u64 chg = group_or64<G>(Fw ^ ((Fw << 1) | carry)) | (w == 0 ? 1ull : 0ull);
+            if (zmax - 64 * w < 63) chg &= (2ull << (zmax - 64 * w)) - 1ull;
+            while (chg) {
+                const int z = 64 * w + __ffsll((long long)chg) - 1;
+                chg &= chg - 1ull;
+                const mk Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : (mk)0, Tz = levelT(z);
+                if (ls == slot) { myF = Fz; myB = Fb; myT = Tz; myz = z; }
+                if (++slot == LPR) flush();
+            }
         }
+        if (slot > 0) flush();
+        tap_wave_lds_sync();                                                         // the list, for (b)'s look-ups
     }
     M3_PROF(0);
     // (b) spaces next to and on top of the blocks placed so far (tools.py:2843-2942); a block that
-    //     could not be placed sits at (0,0,0) in `positions` and is visited all the same
-    for (int bi = 0; bi < step; ++bi) {
-        const int2 hb = reinterpret_cast<const int2 *>(S.hist)[bi];                  // one 8-byte LDS read
+    //     could not be placed sits at (0,0,0) in `positions` and is visited all the same.
+    //     One lane per placed block (chunks of CB blocks that fit S.cand): the spaces beside a block depend on the block and
+    //     the height-map only -- except the stale `x1` of :2865, which is the last assignment of an EARLIER
+    //     block and is handed on through a ballot.  Every lane lays its candidates out in list order
+    //     (S.cand, offsets from a prefix count); "top" candidates carry a flag: the reference appends them
+    //     only when the list does not hold them yet (:2913, :2941), which the ordered compaction below
+    //     reproduces (an equal EARLIER candidate is in the list, or equals an entry that is).  Partly
+    //     covered tops (:2915-2942) need the voxel identities and stay a group-wide computation per block.
+    constexpr int M3_DD = 1 << 30;                       // "append if absent"
+    const int CB = min(G, 12 * G / (4 + cells));         // blocks per chunk: <= 4 + footprint <= 4 + cells candidates each
+    for (int base = 0; base < step; base += CB) {
+        const int nb = min(CB, step - base);
+        const bool valid = cell < nb;
+        const int2 hb = reinterpret_cast<const int2 *>(S.hist)[base + (valid ? cell : 0)];
         const int x = hb.x & 15, y = (hb.x >> 4) & 15, xx = (hb.x >> 8) & 15, yy = (hb.x >> 12) & 15;
         const int z = hb.y & 0xffff, zz = hb.y >> 16;
-        const int xe = x + xx - 1;
-        const mk T = levelT(z);
+        const int xe = x + xx - 1, t = z + zz;
+        mk T = 0, Tt = 0;
+        for (int k = 0; k < nb; ++k) {                                               // group-uniform
+            const int2 hk = reinterpret_cast<const int2 *>(S.hist)[base + k];
+            const int zk = hk.y & 0xffff;
+            const mk Ta = levelT(zk), Tb = levelT(zk + (hk.y >> 16));
+            if (cell == k) { T = Ta; Tt = Tb; }
+        }
         const unsigned spanx = m3_bits(x, xe);
-        if (y + yy < L) {                                                            // :2847 beyond +y
-            const unsigned r = rowT(T, y + yy);
-            int y2;
-            if ((r & spanx) == spanx) {                                              // :2849
-                if ((x > 0 && m3_bit(r, x - 1)) || (x + xx < W && m3_bit(r, x + xx))) {
-                    M3_EXT_UP(T, spanx, y + yy, y2);
-                    M3_PUSH(x, y + yy, z, xe, y2);
-                }
-            } else {
-                if (m3_bit(r, x) && x > 0 && m3_bit(r, x - 1)) {                     // :2858 left part
-                    const int x2 = x + min(__ffs((int)~(r >> x)) - 1, xx) - 1;       // :2860-2862
-                    if (!x1def) err |= 8;
-                    const unsigned sp = m3_bits(sx1, x2);                            // :2865 (sic: stale x1)
-                    M3_EXT_UP(T, sp, y + yy, y2);
-                    M3_PUSH(x, y + yy, z, x2, y2);
-                }
-                if (m3_bit(r, xe) && x + xx < W && m3_bit(r, x + xx)) {              // :2868 right part
-                    const int down = __clz((int)~(r << (31 - xe)));                  // free cells from xe leftwards
-                    const int x1 = xe - min(down, xx) + 1;                           // :2870-2872
-                    sx1 = x1; x1def = true;
-                    const unsigned sp = m3_bits(x1, xe);
-                    M3_EXT_UP(T, sp, y + yy, y2);
-                    M3_PUSH(x1, y + yy, z, xe, y2);
-                }
-            }
-        }
-        if (y > 0) {                                                                 // :2878 beyond -y
-            const unsigned r = rowT(T, y - 1);
-            int y1;
-            if ((r & spanx) == spanx) {
-                if ((x > 0 && m3_bit(r, x - 1)) || (x + xx < W && m3_bit(r, x + xx))) {
-                    M3_EXT_DOWN(T, spanx, y - 1, y1);
-                    M3_PUSH(x, y1, z, xe, y - 1);
-                }
-            } else {
-                if (m3_bit(r, x) && x > 0 && m3_bit(r, x - 1)) {                     // :2889
-                    const int x2 = x + min(__ffs((int)~(r >> x)) - 1, xx) - 1;
-                    const unsigned sp = m3_bits(x, x2);                              // :2896 uses x here
-                    M3_EXT_DOWN(T, sp, y - 1, y1);
-                    M3_PUSH(x, y1, z, x2, y - 1);
-                }
-                if (m3_bit(r, xe) && x + xx < W && m3_bit(r, x + xx)) {              // :2899
-                    const int down = __clz((int)~(r << (31 - xe)));
-                    const int x1 = xe - min(down, xx) + 1;
-                    sx1 = x1; x1def = true;
-                    const unsigned sp = m3_bits(x1, xe);
-                    M3_EXT_DOWN(T, sp, y - 1, y1);
-                    M3_PUSH(x1, y1, z, xe, y - 1);
-                }
-            }
-        }
-        if (z + zz < H) {                                                            // :2909 on top
-            const int t = z + zz;
-            const mk Tt = levelT(t);
-            bool full = true;
-            for (int j = 0; j < yy; ++j) full = full && (rowT(Tt, y + j) & spanx) == spanx;
-            if (full) {                                                              // :2911-2913
-                const int want = M3_PACK(x, y, t, xe, y + yy - 1);
-                int dup = 0;
-                for (int k = cell; k < n_ems; k += G) dup |= S.ems[k] == want;
-                if (!ballot_g<G>(dup != 0, gl0)) M3_PUSH(x, y, t, xe, y + yy - 1);   // one ballot, no shuffle chain
-            } else {
-                // voxel value at level t under this lane's (tx, ty): block index, -1 below a block, 0 free
-                int id = inT ? (hmT > t ? -1 : 0) : 0;
-                for (int k = 0; k < step; ++k) {
-                    const int2 hk = reinterpret_cast<const int2 *>(S.hist)[k];
-                    const int kz = hk.y & 0xffff;
-                    if (!((hk.x >> 16) & 1) || t < kz || t >= kz + (hk.y >> 16)) continue; // group-uniform: not at level t
-                    const int kx = hk.x & 15, ky = (hk.x >> 4) & 15;
-                    if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) id = k + 1;
-                }
-                const int idl = __shfl(id, (wl + 63) & 63);                          // the cell at x-1 (same row)
-                const mk EQ = (mk)ballot_g<G>(inT && tx > 0 && id == idl, gl0);
-                auto hist = [&](int i, int j) -> int {                               // :2915-2922
-                    const unsigned v = (rowT(Tt, y + j) >> (x + i)) & ((1u << (xx - i)) - 1u);
-                    return __ffs((int)~v) - 1;
-                };
-                auto rows_equal = [&](int i, int ja, int jb) -> bool {               // rows x+i, x+i-1 over [ja, jb)
-                    bool eq = true;
-                    for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((y + j) * W + x + i)) & 1);
-                    return eq;
-                };
-                // :2924-2942.  The reference scans the footprint cell by cell; whether cell (i, j) yields a
-                // space, and which, depends on the cell alone, so the cells are evaluated one per lane; the
-                // sequential part that remains is the order of the list (cells in (i, j) order) and its
-                // "not already in the list" test, done with a ballot and a prefix count.
-                int want = -1;
-                if (cell < xx * yy) {
-                    const int i = cell / yy, j = cell - i * yy;
-                    const int hv = hist(i, j);
-                    bool ok = hv != 0 && !(j > 0 && hv == hist(i, j - 1)) && !(i > 0 && rows_equal(i, j, yy)); // :2926-2928
-                    if (ok) {
-                        const int i2 = i + hv - 1;
-                        int j2, j1;
-                        for (j2 = j;; ++j2) { if (j2 == yy - 1) break; if (hist(i, j2 + 1) < hv) break; }
-                        ok = !(i > 0 && rows_equal(i, j, j2));                       // :2934 (empty range is "equal")
-                        for (j1 = j;; --j1) { if (j1 == 0) break; if (hist(i, j1 - 1) < hv) break; }
-                        if (ok) want = M3_PACK(x + i, y + j1, z, x + i2, y + j2);    // :2940 (sic: level z, not z+zz)
+        int a0 = -1, a1 = -1, b0 = -1, b1 = -1, asgv = 0, st_x2 = 0;
+        bool asg = false, need_stale = false;
+        if (valid) {
+            if (y + yy < L) {                                                        // :2847 beyond +y
+                const unsigned r = rowT(T, y + yy);
+                int y2;
+                if ((r & spanx) == spanx) {                                          // :2849
+                    if ((x > 0 && m3_bit(r, x - 1)) || (x + xx < W && m3_bit(r, x + xx))) {
+                        M3_EXT_UP(T, spanx, y + yy, y2);
+                        a0 = M3_PACK(x, y + yy, z, xe, y2);
+                    }
+                } else {
+                    if (m3_bit(r, x) && x > 0 && m3_bit(r, x - 1)) {                 // :2858 left part
+                        need_stale = true;
+                        st_x2 = x + min(__ffs((int)~(r >> x)) - 1, xx) - 1;          // :2860-2862
+                    }
+                    if (m3_bit(r, xe) && x + xx < W && m3_bit(r, x + xx)) {          // :2868 right part
+                        const int down = __clz((int)~(r << (31 - xe)));              // free cells from xe leftwards
+                        const int x1 = xe - min(down, xx) + 1;                       // :2870-2872
+                        asg = true; asgv = x1;
+                        const unsigned sp = m3_bits(x1, xe);
+                        M3_EXT_UP(T, sp, y + yy, y2);
+                        a1 = M3_PACK(x1, y + yy, z, xe, y2);
                     }
                 }
-                S.ord[cell] = want;                                                  // scratch until phase 2
-                tap_wave_lds_sync();
-                bool dup = false;                                                    // no early exit: loads pipeline
-                for (int k = 0; k < n_ems; ++k) dup |= S.ems[k] == want;             // :2941 not in ems_list ...
-                for (int k = 0; k < xx * yy; ++k) dup |= k < cell && S.ord[k] == want; // ... nor added by an earlier cell
-                const bool push = want >= 0 && !dup;
-                const mk pm = (mk)ballot_g<G>(push, gl0);
-                const int at = n_ems + m3_popc((mk)(pm & (((mk)1 << cell) - 1)));
-                if (push) { if (at < MACS3_EMS_CAP) S.ems[at] = want; else err |= 16; }
-                n_ems = min(MACS3_EMS_CAP, n_ems + m3_popc(pm));
-                tap_wave_lds_sync();                                                 // entries written by other lanes
             }
+            if (y > 0) {                                                             // :2878 beyond -y
+                const unsigned r = rowT(T, y - 1);
+                int y1;
+                if ((r & spanx) == spanx) {
+                    if ((x > 0 && m3_bit(r, x - 1)) || (x + xx < W && m3_bit(r, x + xx))) {
+                        M3_EXT_DOWN(T, spanx, y - 1, y1);
+                        b0 = M3_PACK(x, y1, z, xe, y - 1);
+                    }
+                } else {
+                    if (m3_bit(r, x) && x > 0 && m3_bit(r, x - 1)) {                 // :2889
+                        const int x2 = x + min(__ffs((int)~(r >> x)) - 1, xx) - 1;
+                        const unsigned sp = m3_bits(x, x2);                          // :2896 uses x here
+                        M3_EXT_DOWN(T, sp, y - 1, y1);
+                        b0 = M3_PACK(x, y1, z, x2, y - 1);
+                    }
+                    if (m3_bit(r, xe) && x + xx < W && m3_bit(r, x + xx)) {          // :2899
+                        const int down = __clz((int)~(r << (31 - xe)));
+                        const int x1 = xe - min(down, xx) + 1;
+                        asg = true; asgv = x1;
+                        const unsigned sp = m3_bits(x1, xe);
+                        M3_EXT_DOWN(T, sp, y - 1, y1);
+                        b1 = M3_PACK(x1, y1, z, xe, y - 1);
+                    }
+                }
+            }
+        }
+        {   // :2865 reads the `x1` an earlier block (or phase (a)) left behind
+            const mk am = (mk)ballot_g<G>(asg, gl0), earlier = am & below_me;
+            const int v_ = __shfl(asgv, gl0 + (earlier ? m3_fls(earlier) : 0));
+            const int sxl = earlier ? v_ : sx1;
+            if (need_stale) {
+                if (!(earlier || x1def)) err |= 8;
+                const unsigned sp = m3_bits(sxl, st_x2);                             // (sic: stale x1)
+                int y2;
+                M3_EXT_UP(T, sp, y + yy, y2);
+                a0 = M3_PACK(x, y + yy, z, st_x2, y2);
+            }
+            const int vl = __shfl(asgv, gl0 + (am ? m3_fls(am) : 0));
+            if (am) { sx1 = vl; x1def = true; }
+        }
+        const bool has_top = valid && t < H;                                         // :2909 on top
+        bool full = true;
+        for (int j = 0; j < yy; ++j) full = full && (rowT(Tt, y + j) & spanx) == spanx;
+        const int ns = (a0 >= 0) + (a1 >= 0) + (b0 >= 0) + (b1 >= 0);
+        int total;
+        const int off = excl_scan(ns + (has_top ? (full ? 1 : xx * yy) : 0), total);
+        {
+            int j = off;
+            if (a0 >= 0) S.cand[j++] = a0;
+            if (a1 >= 0) S.cand[j++] = a1;
+            if (b0 >= 0) S.cand[j++] = b0;
+            if (b1 >= 0) S.cand[j++] = b1;
+            if (has_top && full) S.cand[j] = M3_PACK(x, y, t, xe, y + yy - 1) | M3_DD; // :2911-2913
+        }
+        mk pm = (mk)ballot_g<G>(has_top && !full, gl0);
+        while (pm) {                                                                 // partly covered tops, one by one
+            const int k = m3_ffs(pm);
+            pm &= pm - 1;
+            const int2 hu = reinterpret_cast<const int2 *>(S.hist)[base + k];        // group-uniform from here on
+            const int ux = hu.x & 15, uy = (hu.x >> 4) & 15, uxx = (hu.x >> 8) & 15, uyy = (hu.x >> 12) & 15;
+            const int uz = hu.y & 0xffff, ut = uz + (hu.y >> 16);
+            const int uoff = __shfl(off + ns, gl0 + k);
+            const mk Tu = levelT(ut);
+            // voxel value at level ut under this lane's (tx, ty): block index, -1 below a block, 0 free
+            int id = inT ? (hmT > ut ? -1 : 0) : 0;
+            for (int q = 0; q < step; ++q) {
+                const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
+                const int kz = hk.y & 0xffff;
+                if (!((hk.x >> 16) & 1) || ut < kz || ut >= kz + (hk.y >> 16)) continue; // group-uniform: not at level ut
+                const int kx = hk.x & 15, ky = (hk.x >> 4) & 15;
+                if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) id = q + 1;
+            }
+            const int idl = __shfl(id, (wl + 63) & 63);                              // the cell at x-1 (same row)
+            const mk EQ = (mk)ballot_g<G>(inT && tx > 0 && id == idl, gl0);
+            auto hist = [&](int i, int j) -> int {                                   // :2915-2922
+                const unsigned v = (rowT(Tu, uy + j) >> (ux + i)) & ((1u << (uxx - i)) - 1u);
+                return __ffs((int)~v) - 1;
+            };
+            auto rows_equal = [&](int i, int ja, int jb) -> bool {                   // rows x+i, x+i-1 over [ja, jb)
+                bool eq = true;
+                for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((uy + j) * W + ux + i)) & 1);
+                return eq;
+            };
+            // :2924-2942.  The reference scans the footprint cell by cell; whether cell (i, j) yields a
+            // space, and which, depends on the cell alone, so the cells are evaluated one per lane
+            if (cell < uxx * uyy) {
+                int want = -1;
+                const int i = cell / uyy, j = cell - i * uyy;
+                const int hv = hist(i, j);
+                bool ok = hv != 0 && !(j > 0 && hv == hist(i, j - 1)) && !(i > 0 && rows_equal(i, j, uyy)); // :2926-2928
+                if (ok) {
+                    const int i2 = i + hv - 1;
+                    int j2, j1;
+                    for (j2 = j;; ++j2) { if (j2 == uyy - 1) break; if (hist(i, j2 + 1) < hv) break; }
+                    ok = !(i > 0 && rows_equal(i, j, j2));                           // :2934 (empty range is "equal")
+                    for (j1 = j;; --j1) { if (j1 == 0) break; if (hist(i, j1 - 1) < hv) break; }
+                    if (ok) want = M3_PACK(ux + i, uy + j1, uz, ux + i2, uy + j2) | M3_DD; // :2940 (sic: level z, not z+zz)
+                }
+                S.cand[uoff + cell] = want;
+            }
+        }
+        tap_wave_lds_sync();
+        // ordered append; flagged candidates only when absent (:2913, :2941)
+        for (int k0 = 0; k0 < total; k0 += G) {
+            const int k = k0 + cell;
+            const int v = k < total ? S.cand[k] : -1;
+            const int val = v & ~M3_DD;
+            bool keep = v >= 0;
+            if (keep && (v & M3_DD)) {
+                bool dup = false;
+                for (int i = 0; i < n_ems; ++i) dup |= S.ems[i] == val;
+                for (int i = k0; i < k; ++i) dup |= (S.cand[i] & ~M3_DD) == val;
+                keep = !dup;
+            }
+            const mk km = (mk)ballot_g<G>(keep, gl0);
+            const int at = n_ems + m3_popc((mk)(km & below_me));
+            if (keep) { if (at < MACS3_EMS_CAP) S.ems[at] = val; else err |= 16; }
+            n_ems = min(MACS3_EMS_CAP, n_ems + m3_popc(km));
+            tap_wave_lds_sync();                                                     // entries written by other lanes
         }
     }
 
