@@ -140,8 +140,8 @@ __device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask, const uns
 
 // -DTAP_PROF: shader-clock deltas per phase of the group in lanes 0..G-1 of each workgroup's first wave
 #ifdef TAP_PROF
-static __device__ unsigned int tap_prof_m3[8192 * 8];
-#define M3_PROF(i) do { const long long t_ = clock64(); if (cell == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 8192) tap_prof_m3[blockIdx.x * 8 + (i)] = (unsigned)(t_ - tp_); tp_ = t_; } while (0)
+static __device__ unsigned int tap_prof_m3[8192 * 16];
+#define M3_PROF(i) do { const long long t_ = clock64(); if (cell == 0 && (threadIdx.x & 63) == 0 && blockIdx.x < 8192) tap_prof_m3[blockIdx.x * 16 + (i)] = (unsigned)(t_ - tp_); tp_ = t_; } while (0)
 #define M3_PROF_BEGIN long long tp_ = clock64()
 #else
 #define M3_PROF(i) do { } while (0)
@@ -389,6 +389,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             const int vl = __shfl(asgv, gl0 + (am ? m3_fls(am) : 0));
             if (am) { sx1 = vl; x1def = true; }
         }
+        M3_PROF(8);
         const bool has_top = valid && t < H;                                         // :2909 on top
         bool full = true;
         for (int j = 0; j < yy; ++j) full = full && (rowT(Tt, y + j) & spanx) == spanx;
@@ -403,40 +404,78 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             if (b1 >= 0) S.cand[j++] = b1;
             if (has_top && full) S.cand[j] = M3_PACK(x, y, t, xe, y + yy - 1) | M3_DD; // :2911-2913
         }
-        mk pm = (mk)ballot_g<G>(has_top && !full, gl0);
-        while (pm) {                                                                 // partly covered tops, one by one
-            const int k = m3_ffs(pm);
-            pm &= pm - 1;
-            const int2 hu = reinterpret_cast<const int2 *>(S.hist)[base + k];        // group-uniform from here on
-            const int ux = hu.x & 15, uy = (hu.x >> 4) & 15, uxx = (hu.x >> 8) & 15, uyy = (hu.x >> 12) & 15;
-            const int uz = hu.y & 0xffff, ut = uz + (hu.y >> 16);
-            const int uoff = __shfl(off + ns, gl0 + k);
-            const mk Tu = levelT(ut);
-            // voxel value at level ut under this lane's (tx, ty): block index, -1 below a block, 0 free
-            int id = inT ? (hmT > ut ? -1 : 0) : 0;
-            for (int q = 0; q < step; ++q) {
-                const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
-                const int kz = hk.y & 0xffff;
-                if (!((hk.x >> 16) & 1) || ut < kz || ut >= kz + (hk.y >> 16)) continue; // group-uniform: not at level ut
-                const int kx = hk.x & 15, ky = (hk.x >> 4) & 15;
-                if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) id = q + 1;
+        M3_PROF(9);
+        const mk pm = (mk)ballot_g<G>(has_top && !full, gl0);
+        if (pm) {
+            // Partly covered tops (:2915-2942).  The reference scans the footprint cell by cell; whether cell
+            // (i, j) yields a space, and which, depends on the cell alone: the block's lane leaves one marker per
+            // footprint cell in its candidate slots, and the markers are then resolved one per lane, across all
+            // the chunk's blocks at once.  What a cell needs of its block: the free mask of the top level (Tt,
+            // parked in lvh/lvr) and, for :2928/:2934, which cells hold the same voxel value as their -x
+            // neighbour at that level (EQ, parked in lvm) -- a value being a block index, -1 below a block, 0 free.
+            if (has_top && !full)
+                for (int q = 0; q < xx * yy; ++q) S.cand[off + ns + q] = -2 - (cell * 64 + q);
+            reinterpret_cast<u64 *>(S.lvh)[cell] = (u64)Tt;
+            // voxel identities from the history: colb = placed blocks over this lane's column (tx, ty),
+            // alive = placed blocks that cross the top level of this lane's BLOCK; one pass for both
+            u64 colb = 0, alive = 0;
+            const bool by_bits = step <= 64;
+            if (by_bits)
+                for (int q = 0; q < step; ++q) {
+                    const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
+                    if (!((hk.x >> 16) & 1)) continue;
+                    const int kz = hk.y & 0xffff, kx = hk.x & 15, ky = (hk.x >> 4) & 15;
+                    if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) colb |= 1ull << q;
+                    if (t >= kz && t < kz + (hk.y >> 16)) alive |= 1ull << q;
+                }
+            auto shfl64 = [](u64 v, int src) -> u64 {
+                return ((u64)(unsigned)__shfl((int)(v >> 32), src) << 32) | (unsigned)__shfl((int)v, src);
+            };
+            const int left = (wl + 63) & 63;                                         // the cell at x-1 (same row)
+            const u64 colbL = shfl64(colb, left);
+            const int hmL = __shfl(hmT, left);
+            for (mk pw = pm; pw; pw &= pw - 1) {                                     // group-uniform
+                const int k = m3_ffs(pw);
+                const int ut = __shfl(t, gl0 + k);
+                bool eq;
+                if (by_bits) {
+                    const u64 al = shfl64(alive, gl0 + k);
+                    const u64 mine = colb & al, theirs = colbL & al;
+                    eq = mine == theirs && (mine != 0 || (hmT > ut) == (hmL > ut));
+                } else {
+                    int id = inT ? (hmT > ut ? -1 : 0) : 0;
+                    for (int q = 0; q < step; ++q) {
+                        const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
+                        const int kz = hk.y & 0xffff;
+                        if (!((hk.x >> 16) & 1) || ut < kz || ut >= kz + (hk.y >> 16)) continue;
+                        const int kx = hk.x & 15, ky = (hk.x >> 4) & 15;
+                        if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) id = q + 1;
+                    }
+                    eq = id == __shfl(id, left);
+                }
+                S.lvm[k] = ballot_g<G>(inT && tx > 0 && eq, gl0);                   // same value from every lane
             }
-            const int idl = __shfl(id, (wl + 63) & 63);                              // the cell at x-1 (same row)
-            const mk EQ = (mk)ballot_g<G>(inT && tx > 0 && id == idl, gl0);
-            auto hist = [&](int i, int j) -> int {                                   // :2915-2922
-                const unsigned v = (rowT(Tu, uy + j) >> (ux + i)) & ((1u << (uxx - i)) - 1u);
-                return __ffs((int)~v) - 1;
-            };
-            auto rows_equal = [&](int i, int ja, int jb) -> bool {                   // rows x+i, x+i-1 over [ja, jb)
-                bool eq = true;
-                for (int j = ja; j < jb; ++j) eq = eq && ((EQ >> ((uy + j) * W + ux + i)) & 1);
-                return eq;
-            };
-            // :2924-2942.  The reference scans the footprint cell by cell; whether cell (i, j) yields a
-            // space, and which, depends on the cell alone, so the cells are evaluated one per lane
-            if (cell < uxx * uyy) {
+            tap_wave_lds_sync();
+            for (int k0 = 0; k0 < total; k0 += G) {
+                const int idx = k0 + cell;
+                const int v = idx < total ? S.cand[idx] : 0;
+                if (v > -2) continue;
+                const int k = (-2 - v) >> 6, fc = (-2 - v) & 63;
+                const int2 hu = reinterpret_cast<const int2 *>(S.hist)[base + k];
+                const int ux = hu.x & 15, uy = (hu.x >> 4) & 15, uxx = (hu.x >> 8) & 15, uyy = (hu.x >> 12) & 15;
+                const int uz = hu.y & 0xffff;
+                const mk EQ = (mk)S.lvm[k], Tu = (mk)reinterpret_cast<const u64 *>(S.lvh)[k];
+                auto hist = [&](int i, int j) -> int {                               // :2915-2922
+                    const unsigned hv_ = (rowT(Tu, uy + j) >> (ux + i)) & ((1u << (uxx - i)) - 1u);
+                    return __ffs((int)~hv_) - 1;
+                };
+                auto rows_equal = [&](int i, int ja, int jb) -> bool {               // rows x+i, x+i-1 over [ja, jb)
+                    bool e_ = true;
+                    for (int j = ja; j < jb; ++j) e_ = e_ && ((EQ >> ((uy + j) * W + ux + i)) & 1);
+                    return e_;
+                };
                 int want = -1;
-                const int i = cell / uyy, j = cell - i * uyy;
+                const int i = fc / uyy, j = fc - i * uyy;
                 const int hv = hist(i, j);
                 bool ok = hv != 0 && !(j > 0 && hv == hist(i, j - 1)) && !(i > 0 && rows_equal(i, j, uyy)); // :2926-2928
                 if (ok) {
@@ -447,10 +486,11 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                     for (j1 = j;; --j1) { if (j1 == 0) break; if (hist(i, j1 - 1) < hv) break; }
                     if (ok) want = M3_PACK(ux + i, uy + j1, uz, ux + i2, uy + j2) | M3_DD; // :2940 (sic: level z, not z+zz)
                 }
-                S.cand[uoff + cell] = want;
+                S.cand[idx] = want;
             }
         }
         tap_wave_lds_sync();
+        M3_PROF(10);
         // ordered append; flagged candidates only when absent (:2913, :2941)
         for (int k0 = 0; k0 < total; k0 += G) {
             const int k = k0 + cell;
