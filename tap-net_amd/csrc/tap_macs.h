@@ -59,12 +59,6 @@ __device__ __forceinline__ MacsLds macs_lds(int *base, int G, int H, int ems_cap
     return m;
 }
 
-template <int G> __device__ __forceinline__ int group_sum(int v)
-{
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
-    return v;
-}
 
 // usable-space tie-break score of the candidate map (hm with columns [xs, xs+bx) raised to `top`):
 // sum_{h < m} longest free run (length - 1) at level h (tools.py:2667-2678), minus m (W - 1)
@@ -262,9 +256,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         const double r = eval_slot(s, xs, Z, sum, stab);
         if (r > my_r) { my_r = r; my_slot = s; } // slots come in increasing order: first maximum kept
     }
-    double rmax = my_r;
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, G));
+    const double rmax = group_fmax<G>(my_r);
     // winner (:2713-2736): the first slot reaching rmax, or -- with the 'mcs' tie-break -- the first
     // one among them with the largest usable-space score
     int win = INT_MAX;
@@ -282,11 +274,10 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
                 const int adj = macs_adj<G>(hmr, W, xs, bx, Z + bz, max(gmax, Z + bz));
                 if (adj > best_adj) { best_adj = adj; best_s = s; }
             }
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) { // lexicographic (adj desc, order asc)
-                const int a2 = __shfl_xor(best_adj, o, G), s2 = __shfl_xor(best_s, o, G);
+            group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) { // lexicographic (adj desc, order asc)
+                const int a2 = get(best_adj), s2 = get(best_s);
                 if (a2 > best_adj || (a2 == best_adj && s2 < best_s)) { best_adj = a2; best_s = s2; }
-            }
+            });
             win = best_s;
             // the reference only scores usable space when more than one entry ties (:2718), and then
             // indexes levels up to max_height: IndexError once any settled slot reaches above H

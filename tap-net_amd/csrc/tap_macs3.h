@@ -78,12 +78,9 @@ template <int G> __device__ __forceinline__ u64 ballot_g(bool p, int gl0)
 
 template <int G> __device__ __forceinline__ u64 group_or64(u64 v)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) {
-        const unsigned lo = __shfl_xor((unsigned)v, o, G), hi = __shfl_xor((unsigned)(v >> 32), o, G);
-        v |= ((u64)hi << 32) | lo;
-    }
-    return v;
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) { lo |= (unsigned)get((int)lo); hi |= (unsigned)get((int)hi); });
+    return ((u64)hi << 32) | lo;
 }
 
 // cell / position masks: 32-bit arithmetic when the container has at most 32 cells (variable 64-bit
@@ -125,13 +122,19 @@ __device__ __forceinline__ int m3_longest_run(unsigned v)
 // lrun: the group's 256-entry table of m3_longest_run in LDS (one read instead of a data-dependent loop)
 __device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask, const unsigned char *lrun)
 {
+    // every (first row, last row) pair, no early exits: the table look-ups are independent of each other and
+    // go out back to back (a pruned loop waits one LDS round trip per pair); rows beyond W are empty
+    unsigned row[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) row[i] = i < W ? (unsigned)(fm >> (i * L)) & lmask : 0u;
     int best = 0;
-    for (int i1 = 0; i1 < W; ++i1) {
+#pragma unroll
+    for (int i1 = 0; i1 < 8; ++i1) {
+        if (i1 >= W) break;                                  // group-uniform
         unsigned acc = lmask;
-        for (int i2 = i1; i2 < W; ++i2) {
-            acc &= (unsigned)(fm >> (i2 * L)) & lmask;
-            if (!acc) break;
-            if ((i2 - i1 + 1) * __popc(acc) <= best) continue;      // cannot beat the best even if contiguous
+#pragma unroll
+        for (int i2 = i1; i2 < 8; ++i2) {
+            acc &= row[i2];
             best = max(best, (i2 - i1 + 1) * (int)lrun[acc]);
         }
     }
@@ -181,7 +184,6 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     for (int y = 0; y < L; ++y) colsel |= (mk)1 << (y * W);
 
     auto rowT = [&](mk m, int y) -> unsigned { return (unsigned)(m >> (y * W)) & wmask; };
-    auto levelF = [&](int z) -> mk { return (mk)ballot_g<G>((wordF(z >> 6) >> (z & 63)) & 1ull, gl0); };
     auto levelT = [&](int z) -> mk { return (mk)ballot_g<G>(hmT <= z, gl0); }; // container[.., z] == 0
 
     // ---- phase 1: EMS list (identical on every lane of the group) -------------------------------
@@ -283,12 +285,14 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         };
         for (int w = 0; w < HW && 64 * w <= zmax; ++w) {
             const u64 Fw = wordF(w), carry = w > 0 ? (wordF(w - 1) >> 63) : 0ull;
-            u64 chg = group_or64<G>(Fw ^ ((Fw << 1) | carry)) | (w == 0 ? 1ull : 0ull);
+            const u64 Fw1 = (Fw << 1) | carry;                                       // bit zb: F at level 64w + zb - 1
+            u64 chg = group_or64<G>(Fw ^ Fw1) | (w == 0 ? 1ull : 0ull);
             if (zmax - 64 * w < 63) chg &= (2ull << (zmax - 64 * w)) - 1ull;
             while (chg) {
-                const int z = 64 * w + __ffsll((long long)chg) - 1;
+                const int zb = __ffsll((long long)chg) - 1, z = 64 * w + zb;
                 chg &= chg - 1ull;
-                const mk Fz = levelF(z), Fb = z > 0 ? levelF(z - 1) : (mk)0, Tz = levelT(z);
+                const mk Fz = (mk)ballot_g<G>((Fw >> zb) & 1ull, gl0);               // from registers: no LDS in this loop
+                const mk Fb = z > 0 ? (mk)ballot_g<G>((Fw1 >> zb) & 1ull, gl0) : (mk)0, Tz = levelT(z);
                 if (ls == slot) { myF = Fz; myB = Fb; myT = Tz; myz = z; }
                 if (++slot == LPR) flush();
             }
@@ -421,12 +425,15 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             u64 colb = 0, alive = 0;
             const bool by_bits = step <= 64;
             if (by_bits)
-                for (int q = 0; q < step; ++q) {
+#pragma unroll 4
+                for (int q = 0; q < step; ++q) {                                     // no branches: the reads pipeline
                     const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
-                    if (!((hk.x >> 16) & 1)) continue;
+                    const bool placed = (hk.x >> 16) & 1;
                     const int kz = hk.y & 0xffff, kx = hk.x & 15, ky = (hk.x >> 4) & 15;
-                    if (tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15)) colb |= 1ull << q;
-                    if (t >= kz && t < kz + (hk.y >> 16)) alive |= 1ull << q;
+                    const bool over = tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15);
+                    const bool cross = t >= kz && t < kz + (hk.y >> 16);
+                    colb |= (u64)(placed && over) << q;
+                    alive |= (u64)(placed && cross) << q;
                 }
             auto shfl64 = [](u64 v, int src) -> u64 {
                 return ((u64)(unsigned)__shfl((int)(v >> 32), src) << 32) | (unsigned)__shfl((int)v, src);
@@ -523,59 +530,82 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     }
     const bool okp = posv && (stab_p || !hard);                                      // :2963-2965
     const int X = W - bx + 1, Y = L - by + 1;
-    mk taken = 0;
-    int n_slots = 0;
+    // The walk order is sequential (a position settled for one space is skipped by the later ones), but what a
+    // space contributes apart from that is not: one lane per space builds the set of positions that settle at
+    // the space's level inside each of its four search rectangles -- in row-major bit order for the walks that
+    // go by rows, in column-major order for those that go by columns, so that every walk is ONE find-first /
+    // find-last on mask & ~taken -- and the sequential pass only reads those masks back.
+    S.lvr[cell] = okp ? mp : -1;                         // position -> settling level (lvr is idle until the tie-break)
     S.ord[cell] = -1;
-    auto rect = [&](int xa, int xb, int ya, int yb) -> mk { // [xa, xb) x [ya, yb), y-major
+    tap_wave_lds_sync();
+    mk taken = 0, takenx = 0;                            // settled positions: bit y*W + x / bit x*L + y
+    int n_slots = 0;
+    mk colselx = 0;                                      // bit x*L for every column
+    for (int xq = 0; xq < W; ++xq) colselx |= (mk)1 << (xq * L);
+    auto rect = [&](int xa, int xb, int ya, int yb) -> mk { // [xa, xb) x [ya, yb), bit y*W + x
         const mk rows = colsel & ((yb >= L ? ~(mk)0 : (((mk)1 << (yb * W)) - 1)) & ~(((mk)1 << (ya * W)) - 1));
         return (mk)m3_bits(xa, xb - 1) * rows;
     };
-    auto fold = [&](mk m) -> unsigned {
-        unsigned f = 0;
-        for (int y = 0; y < L; ++y) f |= rowT(m, y);
-        return f;
+    auto rectx = [&](int xa, int xb, int ya, int yb) -> mk { // the same, bit x*L + y
+        const mk cols = colselx & ((xb >= W ? ~(mk)0 : (((mk)1 << (xb * L)) - 1)) & ~(((mk)1 << (xa * L)) - 1));
+        return (mk)m3_bits(ya, yb - 1) * cols;
     };
+    const int invW = (256 + W - 1) / W, invL = (256 + L - 1) / L;   // p / W == (p * invW) >> 8 for p < 64, W <= 8
     auto settle = [&](int px, int py) {
         const int p = py * W + px;
         taken |= (mk)1 << p;
+        takenx |= (mk)1 << (px * L + py);
         S.ord[p] = n_slots++; // same value from every lane of the group
     };
-    for (int e = 0; e < n_ems; ++e) {
-        const int pk = S.ems[e];
-        const int X1 = pk & 15, Y1 = (pk >> 4) & 15, X2 = (pk >> 8) & 15, Y2 = (pk >> 12) & 15, Z = pk >> 16;
-        const mk gm = (mk)ballot_g<G>(okp && mp == Z, gl0);
-        if (!(gm & ~taken)) continue;
-        const int xr = X2 - bx + 2, yr = Y2 - by + 2;
-        if (X1 < X && Y1 < Y) {                                                      // :3085 x up, then y up
-            const mk m = gm & ~taken & rect(X1, X, Y1, Y);
-            if (m) {
-                const int px = __ffs((int)fold(m)) - 1;
-                const int py = m3_ffs((mk)((m >> px) & colsel)) / W;
-                settle(px, py);
+    mk *wm = reinterpret_cast<mk *>(S.cand);             // 5 masks per space of the round
+    for (int e0 = 0; e0 < n_ems; e0 += G) {
+        mk U = 0, M1 = 0, M2 = 0, M3 = 0, M4 = 0;
+        if (e0 + cell < n_ems) {
+            const int pk = S.ems[e0 + cell];
+            const int X1 = pk & 15, Y1 = (pk >> 4) & 15, X2 = (pk >> 8) & 15, Y2 = (pk >> 12) & 15, Z = pk >> 16;
+            const int xr = X2 - bx + 2, yr = Y2 - by + 2;
+            mk gy = 0, gx = 0;                           // positions that settle at Z, both bit orders
+            for (int py = 0; py < Y; ++py)
+                for (int px = 0; px < X; ++px) {
+                    const bool hit = S.lvr[py * W + px] == Z;
+                    gy |= (mk)hit << (py * W + px);
+                    gx |= (mk)hit << (px * L + py);
+                }
+            if (X1 < X && Y1 < Y) { M1 = gx & rectx(X1, X, Y1, Y); U |= gy & rect(X1, X, Y1, Y); }   // :3085 x up, then y up
+            if (xr > 0 && Y1 < Y) { M2 = gy & rect(0, xr, Y1, Y); U |= M2; }                          // :3093 y up, then x down
+            if (xr > 0 && yr > 0) { M3 = gx & rectx(0, xr, 0, yr); U |= gy & rect(0, xr, 0, yr); }    // :3101 x down, then y down
+            if (X1 < X && yr > 0) { M4 = gy & rect(X1, X, 0, yr); U |= M4; }                          // :3109 y down, then x up
+        }
+        wm[cell * 5] = U; wm[cell * 5 + 1] = M1; wm[cell * 5 + 2] = M2; wm[cell * 5 + 3] = M3; wm[cell * 5 + 4] = M4;
+        tap_wave_lds_sync();
+        const int nk = min(G, n_ems - e0);
+        mk Un = wm[0];
+        for (int k = 0; k < nk; ++k) {
+            const mk Uk = Un;
+            Un = wm[(k + 1 < nk ? k + 1 : k) * 5];                                   // next space's mask, in flight
+            if (!(Uk & ~taken)) continue;
+            const mk m1 = wm[k * 5 + 1] & ~takenx;
+            if (m1) {
+                const int q = m3_ffs(m1), px = (q * invL) >> 8;
+                settle(px, q - px * L);
+            }
+            const mk m2 = wm[k * 5 + 2] & ~taken;
+            if (m2) {
+                const int py = (m3_ffs(m2) * invW) >> 8;
+                settle(31 - __clz((int)rowT(m2, py)), py);
+            }
+            const mk m3 = wm[k * 5 + 3] & ~takenx;
+            if (m3) {
+                const int q = m3_fls(m3), px = (q * invL) >> 8;
+                settle(px, q - px * L);
+            }
+            const mk m4 = wm[k * 5 + 4] & ~taken;
+            if (m4) {
+                const int py = (m3_fls(m4) * invW) >> 8;
+                settle(__ffs((int)rowT(m4, py)) - 1, py);
             }
         }
-        if (xr > 0 && Y1 < Y) {                                                      // :3093 y up, then x down
-            const mk m = gm & ~taken & rect(0, xr, Y1, Y);
-            if (m) {
-                const int py = m3_ffs(m) / W;
-                settle(31 - __clz((int)rowT(m, py)), py);
-            }
-        }
-        if (xr > 0 && yr > 0) {                                                      // :3101 x down, then y down
-            const mk m = gm & ~taken & rect(0, xr, 0, yr);
-            if (m) {
-                const int px = 31 - __clz((int)fold(m));
-                const int py = m3_fls((mk)((m >> px) & colsel)) / W;
-                settle(px, py);
-            }
-        }
-        if (X1 < X && yr > 0) {                                                      // :3109 y down, then x up
-            const mk m = gm & ~taken & rect(X1, X, 0, yr);
-            if (m) {
-                const int py = m3_fls(m) / W;
-                settle(__ffs((int)rowT(m, py)) - 1, py);
-            }
-        }
+        tap_wave_lds_sync();                                                         // the masks are replaced next round
     }
     tap_wave_lds_sync();
     const int ord = S.ord[cell];
@@ -598,9 +628,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             r = (C + P) + S_;
         }
     }
-    double rmax = r;
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, o, G));
+    const double rmax = group_fmax<G>(r);
     int win = -1; // y-major position of the winner
     M3_PROF(5);
     if (n_slots > 0) {
@@ -618,16 +646,29 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             // its top, so every tied lane then sums its own candidate serially from that table.
             const int max_height = max(gmax, group_max<G>(settled ? mp + bz : 0));   // :3133
             if (max_height > H) err |= 1;                                            // container[:, :, h] IndexError
-            const int hx = cell < cells ? hm : INT_MAX;                              // x-major: own cell
-            int nl = 0;
-            for (int h = 0;;) {
-                S.lvh[nl] = h;                                                       // same value from every lane
-                S.lvm[nl] = ballot_g<G>(hx <= h, gl0);
-                ++nl;
-                const int nxt = group_min<G>(hx > h ? hx : INT_MAX);
-                if (nxt == INT_MAX) break;
-                h = nxt;
+            // levels = 0 and the distinct heights above 0, ascending.  Each cell compares its height with every
+            // other cell's (independent LDS reads): the cells at or below it ARE its level's free mask, and its
+            // slot in the table is the number of distinct lower levels -- no level-by-level minimum search.
+            const bool own = cell < cells;
+            const int hx = own ? hm : INT_MAX;                                       // x-major: own cell
+            mk le = 0, eq = 0;
+            for (int j = 0; j < cells; ++j) {
+                const int hj = S.hm[j];
+                le |= (mk)(hj <= hx) << j;
+                eq |= (mk)(hj == hx) << j;
             }
+            const mk ground = (mk)ballot_g<G>(hx <= 0, gl0);                         // level 0's mask
+            const bool rep = own && hx > 0 && m3_ffs(eq) == cell;                    // first cell of its height
+            const mk reps = (mk)ballot_g<G>(rep, gl0);
+            const int nl = 1 + m3_popc(reps);
+            S.lvh[0] = 0;                                                            // same values from every lane
+            S.lvm[0] = (u64)ground;
+            if (rep) {
+                const int k = 1 + m3_popc((mk)(le & ~eq & ~ground & reps));              // distinct levels in (0, hx)
+                S.lvh[k] = hx;
+                S.lvm[k] = (u64)le;
+            }
+            tap_wave_lds_sync();
             for (int k = cell; k < nl; k += G) S.lvr[k] = m3_maxrect(S.lvm[k], W, L, lmask, S.lrun);
             tap_wave_lds_sync();
             M3_PROF(6);
@@ -651,11 +692,10 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             }
             M3_PROF(7);
             int best_ord = (settled && r == rmax) ? ord : INT_MAX;
-#pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1) { // lexicographic (adj desc, order asc)
-                const int a2 = __shfl_xor(adj, o, G), o2 = __shfl_xor(best_ord, o, G);
+            group_butterfly<G>(wl, [&](auto get) { // lexicographic (adj desc, order asc)
+                const int a2 = get(adj), o2 = get(best_ord);
                 if (a2 > adj || (a2 == adj && o2 < best_ord)) { adj = a2; best_ord = o2; }
-            }
+            });
             win = __ffsll((long long)ballot_g<G>(settled && ord == best_ord, gl0)) - 1;
         }
     }

@@ -37,22 +37,59 @@ struct Placement {
 };
 
 // ---- cross-lane helpers (all lanes of the group must be active) ----------------------------
+// A group-wide combine never goes through the LDS crossbar (ds_bpermute, what __shfl_xor compiles to: an LDS
+// round trip per step): inside a 16-lane row the partner's value arrives by a DPP-modified move (quad
+// permutes, then the half-row and row mirrors -- each step merges two disjoint lane sets, which is all a
+// commutative combine needs), and once a row is uniform, rows are combined through v_readlane of their first
+// lanes.  group_butterfly<G>(lane, f) calls f(get) once per step; get(v) is the partner's v (an int).
+template <int CTRL> __device__ __forceinline__ int tap_dpp(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+}
+template <int G, typename F> __device__ __forceinline__ void group_butterfly(int lane /* 0..63 in the wave */, F f)
+{
+    static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lane groups are 8, 16, 32 or 64 wide");
+    f([](int v) { return tap_dpp<0xB1>(v); });                       // quad_perm [1,0,3,2]
+    f([](int v) { return tap_dpp<0x4E>(v); });                       // quad_perm [2,3,0,1]
+    f([](int v) { return tap_dpp<0x141>(v); });                      // row_half_mirror: the other quad of the 8
+    if (G >= 16) f([](int v) { return tap_dpp<0x140>(v); });         // row_mirror: the other half of the row
+    if (G >= 32)                                                      // the neighbouring row (rows are uniform by now)
+        f([lane](int v) {
+            const int r0 = __builtin_amdgcn_readlane(v, 0), r1 = __builtin_amdgcn_readlane(v, 16),
+                      r2 = __builtin_amdgcn_readlane(v, 32), r3 = __builtin_amdgcn_readlane(v, 48);
+            return lane < 32 ? (lane < 16 ? r1 : r0) : (lane < 48 ? r3 : r2);
+        });
+    if (G == 64)                                                      // the other half of the wave
+        f([lane](int v) {
+            const int r0 = __builtin_amdgcn_readlane(v, 0), r2 = __builtin_amdgcn_readlane(v, 32);
+            return lane < 32 ? r2 : r0;
+        });
+}
 template <int G> __device__ __forceinline__ int group_max(int v)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, G));
+    group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) { v = max(v, get(v)); });
     return v;
 }
 template <int G> __device__ __forceinline__ int group_min(int v)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, G));
+    group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) { v = min(v, get(v)); });
     return v;
 }
 template <int G> __device__ __forceinline__ int group_or(int v)
 {
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v |= __shfl_xor(v, o, G);
+    group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) { v |= get(v); });
+    return v;
+}
+template <int G> __device__ __forceinline__ int group_sum(int v)
+{
+    group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) { v += get(v); });
+    return v;
+}
+template <int G> __device__ __forceinline__ double group_fmax(double v)
+{
+    group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) {
+        v = fmax(v, __hiloint2double(get(__double2hiint(v)), get(__double2loint(v))));
+    });
     return v;
 }
 
@@ -275,20 +312,19 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
             ratio = tap_score(c, cnt, vol, gmax, z, bz, emp, stab);
             key = ((z * L + y) * 3 + cls) * W + x;                // sort order (z, y, class, x)
         }
-        int wl = (int)(threadIdx.x & 63);
-#pragma unroll
-        for (int o = G / 2; o > 0; o >>= 1) {
-            const double r2 = __shfl_xor(ratio, o, G);
-            const int k2 = __shfl_xor(key, o, G);
-            const int w2 = __shfl_xor(wl, o, G);
-            if (r2 > ratio || (r2 == ratio && k2 < key)) { ratio = r2; key = k2; wl = w2; }
-        }
+        // argmax over the group with the winner's placement riding along (keys of candidates are unique)
+        int pxy = x | (y << 8) | (stab << 16);
+        group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) {
+            const double r2 = __hiloint2double(get(__double2hiint(ratio)), get(__double2loint(ratio)));
+            const int k2 = get(key), p2 = get(pxy), z2 = get(z), e2 = get(emp);
+            if (r2 > ratio || (r2 == ratio && k2 < key)) { ratio = r2; key = k2; pxy = p2; z = z2; emp = e2; }
+        });
         res.placed = ratio > 0.0;
-        res.x = __shfl(x, wl);
-        res.y = __shfl(y, wl);
-        res.z = __shfl(z, wl);
-        res.stab = __shfl(stab, wl);
-        emp_w = __shfl(emp, wl);
+        res.x = pxy & 255;
+        res.y = (pxy >> 8) & 255;
+        res.z = z;
+        res.stab = pxy >> 16;
+        emp_w = emp;
     } else {
         // hard: the reference walks the sorted corner list sequentially with a shared `visited`
         // set, sliding each block until it is supported, free and stable (tools.py:2100-2121,
