@@ -181,17 +181,49 @@ __device__ __forceinline__ int pyset_probe_mask(u64 occ, int mask, int key)
 __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsigned char *order, int lane)
 {
     const int mykey = lane < n ? (int)keys[lane] : 0;   // one LDS read; the loops then read lanes, not memory
+    // OR over lanes 0..17 (n <= 18: one 16-lane row and two lanes of the next) without a loop over the keys:
+    // DPP steps inside the rows, then the two rows' first lanes
+    auto or_keys = [&](unsigned v) -> unsigned {
+        v |= (unsigned)tap_dpp<0xB1>((int)v);
+        v |= (unsigned)tap_dpp<0x4E>((int)v);
+        v |= (unsigned)tap_dpp<0x141>((int)v);
+        v |= (unsigned)tap_dpp<0x140>((int)v);
+        return (unsigned)__builtin_amdgcn_readlane((int)v, 0) | (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+    };
+    const int fsize = n < 5 ? 8 : 32;   // n <= 18: the table grows once, 8 -> 32 slots, at the fifth key
+    const int home = mykey & (fsize - 1);
     {
-        // Fast path.  Small ints hash to themselves; a key whose home slot (key & mask) is free goes
+        // Closed form.  Small ints hash to themselves; a key whose home slot (key & mask) is free goes
         // there, and a key is only ever displaced by a key that shares its home.  So when all keys
         // have distinct homes in the FINAL table (its size depends on n alone), every key sits at its
         // home whatever the insertion and resize history was, and the iteration order is the order of
-        // the homes.  Only sets with two keys congruent modulo the table size need the emulation.
-        const int fsize = n < 5 ? 8 : 32;   // n <= 18: the table grows once, 8 -> 32 slots, at the fifth key
-        u64 homes = 0;
-        for (int k = 0; k < n; ++k) homes |= 1ull << (__builtin_amdgcn_readlane(mykey, k) & (fsize - 1));
-        if (__popcll(homes) == n) {
-            if (lane < n) order[__popcll(homes & ((1ull << (mykey & (fsize - 1))) - 1ull))] = (unsigned char)mykey;
+        // the homes.  Only sets with two keys congruent modulo the table size need more.
+        const unsigned homes = or_keys(lane < n ? 1u << home : 0u);
+        if (__popc(homes) == n) {
+            if (lane < n) order[__popc(homes & ((1u << home) - 1u))] = (unsigned char)mykey;
+            return;
+        }
+    }
+    if (n >= 5) {
+        // Half-closed form.  The first five keys go through the 8-slot table and are re-inserted, in ITS slot
+        // order, into the empty 32-slot table: if their homes there are distinct they end at home whatever that
+        // order was, and only the remaining keys need the probe sequence, in list order.
+        const unsigned h5 = or_keys(lane < 5 ? 1u << home : 0u);
+        if (__popc(h5) == 5) {
+            int val = -1;
+            u64 occ = h5;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int key = __builtin_amdgcn_readlane(mykey, k);
+                if (lane == (key & 31)) val = key;
+            }
+            for (int k = 5; k < n; ++k) {
+                const int key = __builtin_amdgcn_readlane(mykey, k);
+                const int slot = pyset_probe_mask(occ, 31, key);
+                if (lane == slot) val = key;
+                occ |= 1ull << slot;
+            }
+            if ((occ >> lane) & 1ull) order[__popcll(occ & ((1ull << lane) - 1ull))] = (unsigned char)val;
             return;
         }
     }
@@ -498,6 +530,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     if (short_window) return;
     PROF(2);
     rolling_emit_wave<D>(a, inst, v, S, entered, window, nd);
+    PROF(3);
 }
 
 // 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
