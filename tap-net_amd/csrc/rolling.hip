@@ -211,7 +211,7 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
         const unsigned h5 = or_keys(lane < 5 ? 1u << home : 0u);
         if (__popc(h5) == 5) {
             int val = -1;
-            u64 occ = h5;
+            unsigned occ = h5;                           // 32 slots: 32-bit occupancy
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
                 const int key = __builtin_amdgcn_readlane(mykey, k);
@@ -219,11 +219,12 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
             }
             for (int k = 5; k < n; ++k) {
                 const int key = __builtin_amdgcn_readlane(mykey, k);
-                const int slot = pyset_probe_mask(occ, 31, key);
+                int slot = key & 31;
+                if ((occ >> slot) & 1u) slot = pyset_probe_mask((u64)occ, 31, key);   // home taken: the probe sequence
                 if (lane == slot) val = key;
-                occ |= 1ull << slot;
+                occ |= 1u << slot;
             }
-            if ((occ >> lane) & 1ull) order[__popcll(occ & ((1ull << lane) - 1ull))] = (unsigned char)val;
+            if (lane < 32 && ((occ >> lane) & 1u)) order[__popc(occ & ((1u << lane) - 1u))] = (unsigned char)val;
             return;
         }
     }
