@@ -790,13 +790,74 @@ def load_traffic(key):
     return None
 
 
+def variants_rolling(cfg, hp, dev, use_graph, trace):
+    """c5's two other readings: (a) cold -- the passes rotate over enough instance sets (relation masks, blocks,
+    window and container buffers per set) to exceed the Infinity Cache; (b) rolling.validate's loop with a policy
+    between the steps: run_rolling_episode, RandomFeasiblePolicy, eager launches."""
+    name, D, cs, n, B, reward, strategy = cfg
+    out = {}
+    skip = os.environ.get("TAP_BENCH_SKIP", "").split(",")
+    trace("cold")
+    try:
+        if "cold" in skip:
+            raise RuntimeError("skipped")
+        per_slot = sum(t.numel() * t.element_size() for t in ([hp.rw.rel, hp.rw.blocks, hp.static, hp.static2, hp.cur, hp.feat]
+                                                              + hp.dyn + hp.maskb + [b for b in hp.bitb if b is not None]))
+        slots = min(12, max(3, int(np.ceil(1.2e9 / per_slot))))
+        hps = [hp] + [RollingHotPath(cfg, B, 0, dev, seed=777 + 1000 * k, window=hp.nw, fused_rolling=hp.fused_rolling, mix=hp.mix)
+                      for k in range(1, slots)]
+        steps = slots * 3
+        dt, _ = time_passes(hps, steps, slots, use_graph, 1)
+        for h in hps:
+            h.env.check()
+        out["cold"] = dict(value=B * n * steps / dt, unit="env-steps/s", slots=slots,
+                           working_set_MB=round(per_slot * slots / 1e6, 1), steps=steps,
+                           what="pass i runs on instance set i %% %d (own relation masks, blocks, window and container "
+                                "buffers); the working set is several times the 256 MB Infinity Cache" % slots)
+        del hps
+    except Exception as ex:                                  # pragma: no cover
+        out["cold"] = dict(error=str(ex))
+    trace("policy_in_loop")
+    try:
+        if "eager" in skip:
+            raise RuntimeError("skipped")
+        g = torch.Generator(device=dev)
+        g.manual_seed(4242)
+        pol = T.RandomFeasiblePolicy(g)
+        blocks = hp.rw.blocks
+        positions = torch.as_tensor(hp.positions_h, device=dev)
+
+        def run():
+            return T.run_rolling_episode(blocks, positions, hp.init, pol, cs[0], cs[-1], child_graph_size=hp.nw,
+                                         reward_type=reward)
+        r = run()
+        torch.cuda.synchronize(dev)
+        steps = 5
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = run()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        r["env"].check(); r["windows"].check()
+        out["policy_in_loop"] = dict(value=B * n * steps / dt, unit="env-steps/s", steps=steps,
+                                     what="rollout.run_rolling_episode (relation masks rebuilt per episode, one fused "
+                                          "tap_rolling_step per window, then the last window's episode), "
+                                          "RandomFeasiblePolicy (torch.multinomial on current_mask) between the steps, "
+                                          "eager launches, fresh output tensors every step")
+    except Exception as ex:                                  # pragma: no cover
+        out["policy_in_loop"] = dict(error=str(ex))
+    return out
+
+
 def variants(cfg, args, hp, rank, world, dev, use_graph):
     """Two more readings of the same workload (single GPU, rank 0's line only)."""
     name, D, cs, n, B, reward, strategy = cfg
     out = {}
-    if hp.kind != "transition" or world != 1:
+    if hp.kind not in ("transition", "rolling") or world != 1:
         return out
     trace = (lambda m: print("variants: " + m, file=sys.stderr, flush=True)) if os.environ.get("TAP_BENCH_TRACE") else (lambda m: None)
+    if hp.kind == "rolling":
+        return variants_rolling(cfg, hp, dev, use_graph, trace)
     # (a) cold: rotate over enough instance batches (inputs AND output buffers per slot) that the working set
     #     exceeds the 256 MB Infinity Cache several times over -- nothing a pass reads is cache-resident
     per_slot = sum(t.numel() * t.element_size() for t in (hp.dynamic0 + hp.static + hp.dyn + [hp.cur] + hp.maskb))
