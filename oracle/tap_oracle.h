@@ -187,6 +187,20 @@ int orc_generate_blocks_with_gt(orc_rng *rng, int n, const int32_t *gt_size, con
                                 int arm_size, int min_size, int max_size, int input_simple, int allow_rot,
                                 int64_t max_bpp, int32_t *blocks_out, int32_t *positions_out, int64_t *stats);
 /* the pieces as the HIP kernels key their counter streams (tap_ppsg_gt / tap_ppsg_order) */
+int orc_ppsg_try_layout_d(int D, int n, const int32_t *init_size, int arm_size, const int32_t *blocks, int input_simple,
+                          int32_t *positions_out);
+/* 2D (generate.py:392-484 BPP_Generator_2D_easy; gauss: the caller's numpy-built split table, see the .c file) */
+int orc_bpp2d_easy(orc_rng *rng, int n, const int32_t *gt_size, int min_size, int max_size,
+                   const double *gauss, int gauss_stride, int gauss_rows, int32_t *blocks, int32_t *positions);
+int orc_generate_blocks_with_gt_2d(orc_rng *rng, int n, const int32_t *gt_size, const int32_t *init_size,
+                                   int arm_size, int min_size, int max_size, int input_simple, int allow_rot,
+                                   int64_t max_bpp, const double *gauss, int gauss_stride, int gauss_rows,
+                                   int32_t *blocks_out, int32_t *positions_out, int64_t *stats);
+int64_t orc_ppsg_gt2d(uint64_t seed, int64_t instance, int gen, int n, int W, int H, int min_size, int max_size,
+                      int64_t max_attempts, const double *gauss, int gauss_stride, int gauss_rows,
+                      int32_t *gt_blocks, int32_t *gt_positions);
+int orc_ppsg_order_2d(uint64_t seed, int64_t instance, int gen, int trial, int n, const int32_t *gt_size,
+                      const int32_t *gt_blocks, const int32_t *gt_positions, int32_t *blocks_out);
 int64_t orc_ppsg_gt(uint64_t seed, int64_t instance, int gen, int S, int ns, int W, const int32_t *heights,
                     int min_size, int max_size, int64_t max_attempts, int32_t *gt_blocks, int32_t *gt_positions);
 int orc_ppsg_order(uint64_t seed, int64_t instance, int gen, int trial, int n, const int32_t *gt_size,

@@ -17,6 +17,7 @@ Fixtures:
   kat.npz                            hand-checkable known answers
   rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
   ppsg3d.npz                         generate.BPP_Generator_3D / generate_blocks_with_GT (3D) under recorded seeds
+  ppsg2d.npz                         generate.BPP_Generator_2D_easy / generate_blocks_with_GT (2D) under recorded seeds
   ppsg_2d.npz                        (--only ppsg) 64 instances of the reference's PPSG generator + MACS traces over them
 """
 import argparse
@@ -346,6 +347,46 @@ def make_ppsg3d(pack, generate):
     save("ppsg3d.npz", **out)
 
 
+def make_ppsg2d(generate):
+    """The reference's 2D perfect-packing generator under recorded seeds (what generate_blocks_with_GT calls for
+    block_dim 2, generate.py:72-73):
+
+    * `bpp_*`: single calls of generate.BPP_Generator_2D_easy(n, [W, H], [1, 5]) after np.random.seed(seed) --
+      volume-weighted block choice among the too-large (else the splittable) blocks, the axis rule with its
+      position-for-size slip (:447), uniform and Gaussian split positions -- accepted or not;
+    * `gt_*`: whole generate.generate_blocks_with_GT(n, [7, H], [7, 50], 1, [1, 5], 'bot', 0) runs -> blocks /
+      positions in layout order (rotation 0).
+    Seeds, parameters and outputs only; the oracle is driven by the same MT19937 word stream (ppsg3d above)."""
+    out = {}
+    bpp = []
+    k = 0
+    for n, gt in ((2, [5, 3]), (5, [7, 6]), (10, [7, 9]), (10, [7, 12]), (20, [7, 16]), (20, [7, 20]), (20, [7, 30]),
+                  (30, [9, 40]), (50, [7, 60])):
+        for seed in range(30):
+            np.random.seed(5000 * n + seed)
+            blocks, positions, _ = generate.BPP_Generator_2D_easy(n, list(gt), [1, 5])
+            out["bpp%d_blocks" % k] = blocks.astype(np.int16)
+            out["bpp%d_positions" % k] = positions.astype(np.int16)
+            bpp.append((n, gt[0], gt[1], 5000 * n + seed))
+            k += 1
+    out["bpp_cases"] = np.asarray(bpp, dtype=np.int64)
+    full = []
+    k = 0
+    for n, gt in ((6, [7, 5]), (8, [7, 7]), (10, [7, 9]), (12, [7, 10])):
+        for seed in range(5):
+            sd = 88000 + 100 * n + seed
+            np.random.seed(sd)
+            rb, pos, dm, small, large = generate.generate_blocks_with_GT(n, list(gt), [7, 50], 1, [1, 5], "bot", 0)
+            out["gt%d_blocks" % k] = np.asarray(rb[0]).reshape(2, n).T.astype(np.int16)     # rotation 0, layout order
+            out["gt%d_positions" % k] = np.asarray(pos).reshape(2, n).T.astype(np.int16)
+            out["gt%d_dep_move" % k] = np.asarray(dm).astype(np.int8)
+            full.append((n, gt[0], gt[1], sd))
+            k += 1
+            print("ppsg2d gt case", k, n, gt, flush=True)
+    out["gt_cases"] = np.asarray(full, dtype=np.int64)
+    save("ppsg2d.npz", **out)
+
+
 def make_masks(pack, D, static, dynamic):
     """Random feasible action tapes through the reference's update_dynamic / update_mask."""
     import torch
@@ -518,6 +559,7 @@ def main():
     if want("macs3d"): make_macs3d(tools)
     if args.only and "ppsg" in args.only: make_ppsg(tools, pack, args.ppsg_dir)   # slow: only on request
     if want("ppsg3d"): make_ppsg3d(pack, generate)
+    if want("ppsg2d"): make_ppsg2d(generate)
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)

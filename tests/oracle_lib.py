@@ -90,6 +90,17 @@ def lib():
         L.orc_ppsg_try_layout.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.orc_generate_blocks_with_gt.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                                   C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ppsg_try_layout_d.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_bpp2d_easy.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p]
+        L.orc_generate_blocks_with_gt_2d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                                     C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_ppsg_gt2d.restype = C.c_int64
+        L.orc_ppsg_gt2d.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_ppsg_order_2d.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]
         L.orc_ppsg_gt.restype = C.c_int64
         L.orc_ppsg_gt.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                   C.c_int64, C.c_void_p, C.c_void_p]
@@ -403,11 +414,61 @@ def bpp3d(rng, n, gt_size, size_range=(1, 5)):
 
 def ppsg_try_layout(blocks, init_size, arm_size=1, input_simple=False):
     blocks = np.ascontiguousarray(blocks, dtype=np.int32)
-    n = blocks.shape[0]
+    n, D = blocks.shape
     cs = np.ascontiguousarray(init_size, dtype=np.int32)
-    pos = np.zeros((n, 3), np.int32)
-    rc = lib().orc_ppsg_try_layout(n, _p(cs), arm_size, _p(blocks), int(input_simple), _p(pos))
+    pos = np.zeros((n, D), np.int32)
+    rc = lib().orc_ppsg_try_layout_d(D, n, _p(cs), arm_size, _p(blocks), int(input_simple), _p(pos))
     return rc, pos
+
+
+def gauss_split_cdf(max_len, size_range=(1, 5)):
+    """The table BPP_Generator_2D_easy's Gaussian split draws from (generate.py:463-469), made with numpy itself:
+    row L (2*max_size - 1 <= L <= max_len) = the normalised cumulative sum np.random.choice builds of
+    prob / np.sum(prob).  -> float64 (max_len + 1, max_len)."""
+    mn, mx = int(size_range[0]), int(size_range[1])
+    tab = np.zeros((max_len + 1, max(1, max_len)), np.float64)
+    mu, sigma = 0.5, 0.16
+    for L in range(2 * mx - 1, max_len + 1):
+        m = L - 2 * mn
+        if m < 1:
+            continue
+        prob_x = np.linspace(mu - 3 * sigma, mu + 3 * sigma, m)
+        prob = np.exp(-(prob_x - mu) ** 2 / (2 * sigma ** 2)) / (np.sqrt(2 * np.pi) * sigma)
+        prob = prob / np.sum(prob)
+        cdf = prob.cumsum()
+        cdf /= cdf[-1]
+        tab[L, :m] = cdf
+    return tab
+
+
+def bpp2d_easy(rng, n, gt_size, size_range=(1, 5), gauss=None):
+    gt = np.ascontiguousarray(gt_size, dtype=np.int32)
+    g = gauss_split_cdf(int(max(gt)), size_range) if gauss is None else gauss
+    blocks, pos = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)
+    rc = lib().orc_bpp2d_easy(rng._h, n, _p(gt), int(size_range[0]), int(size_range[1]), _p(g), g.shape[1], g.shape[0],
+                              _p(blocks), _p(pos))
+    return rc, blocks, pos
+
+
+def generate_blocks_with_gt_2d(rng, n, gt_size, init_size, arm_size=1, size_range=(1, 5), input_simple=False,
+                               allow_rot=True, max_bpp=10 ** 7):
+    gt = np.ascontiguousarray(gt_size, dtype=np.int32)
+    cs = np.ascontiguousarray(init_size, dtype=np.int32)
+    g = gauss_split_cdf(int(max(gt)), size_range)
+    blocks, pos = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)
+    stats = np.zeros(2, np.int64)
+    rc = lib().orc_generate_blocks_with_gt_2d(rng._h, n, _p(gt), _p(cs), arm_size, int(size_range[0]), int(size_range[1]),
+                                              int(input_simple), int(allow_rot), int(max_bpp), _p(g), g.shape[1], g.shape[0],
+                                              _p(blocks), _p(pos), _p(stats))
+    return rc, blocks, pos, stats
+
+
+def ppsg_gt2d(seed, instance, gen, n, W, H, size_range=(1, 5), max_attempts=10 ** 7, gauss=None):
+    g = gauss_split_cdf(int(max(W, H)), size_range) if gauss is None else gauss
+    blocks, pos = np.zeros((n, 2), np.int32), np.zeros((n, 2), np.int32)
+    used = lib().orc_ppsg_gt2d(int(seed), int(instance), int(gen), n, W, H, int(size_range[0]), int(size_range[1]),
+                               int(max_attempts), _p(g), g.shape[1], g.shape[0], _p(blocks), _p(pos))
+    return used, blocks, pos
 
 
 def generate_blocks_with_gt(rng, n, gt_size, init_size, arm_size=1, size_range=(1, 5), input_simple=False,
@@ -434,5 +495,6 @@ def ppsg_order(seed, instance, gen, trial, gt_size, gt_blocks, gt_positions):
     gp = np.ascontiguousarray(gt_positions, dtype=np.int32)
     gs = np.ascontiguousarray(gt_size, dtype=np.int32)
     out = np.zeros_like(gb)
-    rc = lib().orc_ppsg_order(int(seed), int(instance), int(gen), int(trial), gb.shape[0], _p(gs), _p(gb), _p(gp), _p(out))
+    fn = lib().orc_ppsg_order if gb.shape[1] == 3 else lib().orc_ppsg_order_2d
+    rc = fn(int(seed), int(instance), int(gen), int(trial), gb.shape[0], _p(gs), _p(gb), _p(gp), _p(out))
     return rc, out

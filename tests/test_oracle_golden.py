@@ -237,3 +237,39 @@ def test_generate_blocks_with_gt_draw_for_draw():
         assert np.array_equal(st, z["gt%d_static" % k].astype(np.float32))
         assert np.array_equal(dyn, z["gt%d_dynamic" % k].astype(np.float32))
     assert len(z["gt_cases"]) == 24
+
+
+def test_bpp_generator_2d_easy_draw_for_draw():
+    """generate.BPP_Generator_2D_easy (generate.py:392-484), the 2D generator generate_blocks_with_GT calls: fed
+    numpy's MT19937 words the restatement makes the reference's cuts draw for draw -- the weighted block and axis
+    choices, the axis rule that compares a size with a POSITION (:447), uniform and Gaussian split positions (the
+    Gaussian table is built by numpy on both sides)."""
+    z = G.load("ppsg2d.npz")
+    naccepted = 0
+    for k, (n, gx, gz, seed) in enumerate(z["bpp_cases"]):
+        rng = O.Rng(words=O.numpy_mt_words(seed, 4096))
+        rc, blocks, pos = O.bpp2d_easy(rng, int(n), [int(gx), int(gz)])
+        assert rc >= 0 and not rng.exhausted
+        assert np.array_equal(blocks, z["bpp%d_blocks" % k]), (k, n, seed)
+        assert np.array_equal(pos, z["bpp%d_positions" % k]), (k, n, seed)
+        want_ok = bool(((z["bpp%d_blocks" % k] >= 1) & (z["bpp%d_blocks" % k] < 5)).all())
+        assert bool(rc) == want_ok
+        naccepted += rc
+    assert len(z["bpp_cases"]) == 270 and naccepted > 20
+
+
+def test_generate_blocks_with_gt_2d_draw_for_draw():
+    """generate.generate_blocks_with_GT for block_dim 2: same word stream in, the reference's instance out."""
+    z = G.load("ppsg2d.npz")
+    for k, (n, gx, gz, seed) in enumerate(z["gt_cases"]):
+        n = int(n)
+        rng = O.Rng(words=O.numpy_mt_words(seed, 4_000_000))
+        rc, blocks, pos, stats = O.generate_blocks_with_gt_2d(rng, n, [int(gx), int(gz)], [7, 50])
+        assert rc == 1 and not rng.exhausted, (k, rc)
+        assert np.array_equal(blocks, z["gt%d_blocks" % k]), (k, stats)
+        assert np.array_equal(pos, z["gt%d_positions" % k]), (k, stats)
+        ok, pos2, st, dyn = O.instance_from_blocks(blocks, [7, 50], 1)
+        assert ok == 1 and np.array_equal(pos2, pos)
+        # the function's own deps_move (row = blocked block); PACKDataset's tensor holds it transposed
+        assert np.array_equal(dyn[:n, :n].T.reshape(-1), z["gt%d_dep_move" % k].astype(np.float32))
+    assert len(z["gt_cases"]) == 20
