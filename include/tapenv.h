@@ -214,6 +214,26 @@ int tap_ppsg_order(tap_ctx *ctx, int B, int n, const int32_t *gt_blocks, const i
                    uint64_t seed, const int64_t *ids, int64_t instance0, int gen, int trial,
                    int32_t *blocks_out, void *stream);
 
+/* The 2D forms (generate_blocks_with_GT with block_dim 2, generate.py:72-73): tap_ppsg_gt2d = generate.
+ * BPP_Generator_2D_easy (generate.py:392-484) for B instances -- n - 1 guillotine cuts of a W x heights[b] box
+ * (volume-weighted choice among the blocks with a side >= max_size, else among the splittable ones; the axis
+ * rule of :446-454; uniform split positions for short sides, Gaussian ones from `gauss` for sides
+ * >= 2*max_size - 1), re-drawn (stream key(seed, id, gen, attempt)) until every side is in [min_size, max_size).
+ * gauss (gauss_rows, gauss_stride) f64, device: row L = the normalised cumulative sum np.random.choice makes
+ * of the reference's Gaussian weights over the L - 2*min_size split positions of a side of length L (the
+ * caller builds it with numpy, tap-net_amd/generate.py gauss_split_table; rows below 2*max_size - 1 unused).
+ * gt_blocks_out / gt_positions_out (B, n, 2) i32; attempts_out (B,) i32 nullable, -1 = cap reached.
+ * tap_ppsg_order2d = tap_ppsg_order on (B, n, 2) arrays with calc_dependent's 2D movement rule
+ * (generate.py:575-647) and the two 2D rotations.  The layout test is tap_ppsg_check on the relations of the
+ * 2D layout (forward / backward masks are empty there). */
+int tap_ppsg_gt2d(tap_ctx *ctx, int B, int n, int W, const int32_t *heights, int min_size, int max_size,
+                  const double *gauss, int gauss_stride, int gauss_rows, uint64_t seed, const int64_t *ids,
+                  int64_t instance0, int gen, int64_t max_attempts, int32_t *gt_blocks_out,
+                  int32_t *gt_positions_out, int32_t *attempts_out, void *stream);
+int tap_ppsg_order2d(tap_ctx *ctx, int B, int n, const int32_t *gt_blocks, const int32_t *gt_positions,
+                     uint64_t seed, const int64_t *ids, int64_t instance0, int gen, int trial,
+                     int32_t *blocks_out, void *stream);
+
 /* generate.py:110-156: accept a packed layout iff every block is stable (stable (B, n) u8 of
  * tap_pack_blocks) and the blocks can be taken out again last-packed-first (rel (B, 5, n) u64 of
  * tap_rolling_init: nothing on top, one free side per horizontal axis; input_simple != 0 ignores the

@@ -63,6 +63,9 @@ _PROTOS = {
     "tap_precedence": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_ppsg_gt": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, C.c_uint64, _vp, C.c_int64, _i, C.c_int64, _vp, _vp, _vp, _vp]),
     "tap_ppsg_order": (_i, [_vp, _i, _i, _vp, _vp, C.c_uint64, _vp, C.c_int64, _i, _i, _vp, _vp]),
+    "tap_ppsg_order2d": (_i, [_vp, _i, _i, _vp, _vp, C.c_uint64, _vp, C.c_int64, _i, _i, _vp, _vp]),
+    "tap_ppsg_gt2d": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, C.c_uint64, _vp, C.c_int64, _i, C.c_int64,
+                           _vp, _vp, _vp, _vp]),
     "tap_ppsg_check": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "tap_rolling_init": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_rolling_window": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -134,6 +134,114 @@ def height_distribution(block_dim, blocks_num, size_range, initial_container_wid
     return counts.to(torch.float64) / counts.sum(), keys
 
 
+def gauss_split_table(max_len, size_range=(1, 5), device='cuda'):
+    """The table BPP_Generator_2D_easy's Gaussian split draws from (generate.py:463-469), built with numpy as the
+    reference builds it -- linspace, exp, the normalisation, and the cumulative sum np.random.choice makes of the
+    weights -- one row per side length L >= 2*max_size - 1.  -> float64 (max_len + 1, max_len) on ``device``."""
+    import numpy as np
+    mn, mx = int(size_range[0]), int(size_range[1])
+    tab = np.zeros((max_len + 1, max(1, max_len)), np.float64)
+    mu, sigma = 0.5, 0.16
+    for side in range(2 * mx - 1, max_len + 1):
+        m = side - 2 * mn
+        if m < 1:
+            continue
+        prob_x = np.linspace(mu - 3 * sigma, mu + 3 * sigma, m)
+        prob = np.exp(-(prob_x - mu) ** 2 / (2 * sigma ** 2)) / (np.sqrt(2 * np.pi) * sigma)
+        prob = prob / np.sum(prob)
+        cdf = prob.cumsum()
+        tab[side, :m] = cdf / cdf[-1]
+    return torch.as_tensor(tab, device=device)
+
+
+def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7, initial_container_height=50,
+                               target_container_width=7, size_range=(1, 5), seed=12345, start=0, heights=None,
+                               device='cuda', max_generations=2000, return_stats=False, input_type='bot'):
+    """B perfect-packing instances (2D) as generate.generate_blocks_with_GT builds them for block_dim 2
+    (generate.py:57-161 with BPP_Generator_2D_easy, :392-484): a guillotine-cut perfect packing of a
+    target_width x H box, a random take-apart order with random rotations, packed in that order into the initial
+    container with hard LB_GREEDY, accepted when all blocks are stable and can be taken out again in reverse;
+    up to 20 orders per perfect packing, then a new one.  -> (blocks, positions) (B, n, 2) int32, layout order.
+    Instances are keyed by global index ``start + i``.  ``heights`` (B,) overrides the heights drawn from
+    height_distribution().  The acceptance test is selective (measured on the reference: about one layout in a
+    thousand at 20 blocks), hence the large default ``max_generations``; each generation costs five launches
+    over the instances still missing."""
+    dev = _lib.resolve_device(device)
+    n, B, W = int(blocks_num), int(batch_size), int(target_container_width)
+    if n > 64:
+        raise ValueError("blocks_num <= 64")
+    ids = torch.arange(start, start + B, dtype=torch.int64, device=dev)
+    if heights is None:
+        prob, keys = height_distribution(2, n, size_range, initial_container_width, W, seed=seed, device=dev)
+        g = torch.Generator(device='cpu')
+        rows = []
+        for i in range(B):                               # keyed per instance id so shards agree
+            g.manual_seed((int(seed) * 1000003 + start + i) % (2 ** 63))
+            rows.append(torch.multinomial(prob.cpu().float(), 1, replacement=True, generator=g))
+        heights = keys.cpu()[torch.cat(rows)]
+    heights = heights.to(device=dev, dtype=torch.int32).contiguous().view(-1)
+    if int(heights.numel()) != B:
+        raise ValueError("heights must hold %d values" % B)
+    lim = int(size_range[1]) - 1
+    need = (-(-W // lim)) * ((heights + lim - 1) // lim)
+    if bool(((need > n) | (heights < 1) | (W * heights < n)).any()):
+        raise ValueError("a height cannot be cut into %d blocks with sides < %d" % (n, int(size_range[1])))
+    gauss = gauss_split_table(int(max(W, int(heights.max().item()))), size_range, dev)
+    cs = initial_container(2, initial_container_width, initial_container_height)
+    c, L = _lib.ctx(dev), _lib.lib()
+    out_blocks = torch.zeros(B, n, 2, dtype=torch.int32, device=dev)
+    out_pos = torch.zeros(B, n, 2, dtype=torch.int32, device=dev)
+    done = torch.zeros(B, dtype=torch.bool, device=dev)
+    stats = dict(generations=0, layouts=0)
+    from .rolling import RollingWindows
+    for gen in range(max_generations):
+        todo = (~done).nonzero().squeeze(1)
+        m = int(todo.numel())
+        if m == 0:
+            break
+        stats['generations'] = gen + 1
+        tid, th = ids[todo].contiguous(), heights[todo].contiguous()
+        gtb = torch.empty(m, n, 2, dtype=torch.int32, device=dev)
+        gtp = torch.empty(m, n, 2, dtype=torch.int32, device=dev)
+        att = torch.empty(m, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.tap_ppsg_gt2d(c, m, n, W, _lib.ptr(th), int(size_range[0]), int(size_range[1]), _lib.ptr(gauss),
+                                       int(gauss.shape[1]), int(gauss.shape[0]), int(seed), _lib.ptr(tid), 0, gen, 1 << 20,
+                                       _lib.ptr(gtb), _lib.ptr(gtp), _lib.ptr(att), _lib.stream_of(dev)), c)
+        if bool((att < 0).any()):
+            raise _lib.TapError(_lib.TAP_E_INVALID, "a perfect packing was not found within the attempt cap")
+        alive = torch.ones(m, dtype=torch.bool, device=dev)
+        for trial in range(20):                                                     # generate.py:83-87
+            sel = alive.nonzero().squeeze(1)
+            k = int(sel.numel())
+            if k == 0:
+                break
+            stats['layouts'] += k
+            blocks = torch.empty(k, n, 2, dtype=torch.int32, device=dev)
+            sb, sp, si = gtb[sel].contiguous(), gtp[sel].contiguous(), tid[sel].contiguous()   # named: see the 3D form
+            with torch.cuda.device(dev):
+                _lib.check(L.tap_ppsg_order2d(c, k, n, _lib.ptr(sb), _lib.ptr(sp), int(seed), _lib.ptr(si), 0, gen, trial,
+                                              _lib.ptr(blocks), _lib.stream_of(dev)), c)
+            pos, stable, rew = pack_blocks(blocks, cs)                               # generate.py:108
+            rw = RollingWindows(blocks, pos, cs, child_graph_size=1)                # the relations (:111-112)
+            ok = torch.empty(k, dtype=torch.uint8, device=dev)
+            st8 = stable.to(torch.uint8).contiguous()
+            with torch.cuda.device(dev):
+                _lib.check(L.tap_ppsg_check(c, k, n, 1 if input_type == 'simple' else 0, _lib.ptr(rw.rel), _lib.ptr(st8),
+                                            _lib.ptr(ok), _lib.stream_of(dev)), c)
+            good = ok.bool() & ~torch.isnan(rew)
+            hit = sel[good]
+            out_blocks[todo[hit]] = blocks[good]
+            out_pos[todo[hit]] = pos[good]
+            done[todo[hit]] = True
+            alive[hit] = False
+    if not bool(done.all()):
+        raise _lib.TapError(_lib.TAP_E_INVALID, "%d PPSG instances not found in %d generations" % (int((~done).sum()), max_generations))
+    if return_stats:
+        return out_blocks, out_pos, stats
+    return out_blocks, out_pos
+
+
 def generate_ppsg_instances(batch_size, blocks_num, initial_container_width=7, initial_container_height=50,
                             target_container_width=5, size_range=(1, 5), seed=12345, start=0, slab_blocks=10,
                             heights=None, device='cuda', max_generations=50, return_stats=False, input_type='bot'):
@@ -243,12 +351,15 @@ def generate_mix_instances(batch_size, blocks_num, block_dim=3, initial_containe
     blocks, 'simple' above (where 'bot' accepts nothing)."""
     if input_type is None:
         input_type = 'bot' if int(blocks_num) <= 10 else 'simple'
-    if block_dim != 3:
-        raise ValueError("the device PPSG generator is 3D (BPP_Generator_3D)")
     half = int(batch_size) // 2
-    pb, pp = generate_ppsg_instances(half, blocks_num, initial_container_width, initial_container_height,
-                                     target_container_width, size_range, seed=seed, start=start, device=device,
-                                     input_type=input_type)
+    if block_dim == 2:
+        pb, pp = generate_ppsg_instances_2d(half, blocks_num, initial_container_width, initial_container_height,
+                                            target_container_width, size_range, seed=seed, start=start, device=device,
+                                            input_type=input_type)
+    else:
+        pb, pp = generate_ppsg_instances(half, blocks_num, initial_container_width, initial_container_height,
+                                         target_container_width, size_range, seed=seed, start=start, device=device,
+                                         input_type=input_type)
     _, _, rb, rp = generate_instances(int(batch_size) - half, blocks_num, block_dim, initial_container_width,
                                       initial_container_height, 1, size_range, seed=seed, device=device, return_aux=True)
     return torch.cat([pb, rb]).contiguous(), torch.cat([pp, rp]).contiguous()
