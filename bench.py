@@ -130,7 +130,13 @@ class HotPath(object):
                 self.tape.append(tile_from.tape[w].repeat(1, k).contiguous())
                 self.cs0.append(T.pack.dynamic_colsum(self.dynamic0[-1], self.nw).clone() if not bits else None)
                 continue
-            if instances == "generate":                             # RAND instances of the device-side generator (f1)
+            if instances == "ppsg2d":                               # PPSG instances of the device-side generator
+                t0 = time.perf_counter()
+                static, dynamic = synth.device_ppsg_instances(B, self.nw, D, seed=seed + 100 * w, start=start, device=device,
+                                                              target_container_width=cs[0])
+                torch.cuda.synchronize(device)
+                self.generate_s = time.perf_counter() - t0
+            elif instances == "generate":                           # RAND instances of the device-side generator (f1)
                 static, dynamic = synth.device_rand_instances(B, self.nw, D, seed=seed + 100 * w, start=start, device=device)
                 static, dynamic = static.cpu(), dynamic.cpu()
             elif instances is not None:                             # real instances from a committed fixture, tiled
@@ -1048,6 +1054,9 @@ def main():
     ap.add_argument("--approx-windows", action="store_true",
                     help="c5: consecutive independent 10-node windows instead of true rolling windows")
     ap.add_argument("--rand-only", action="store_true", help="c5: RAND instances only instead of the MIX series")
+    ap.add_argument("--ppsg-fixture", action="store_true",
+                    help="c4: the 64 instances the reference's own generator wrote (tests/golden/ppsg_2d.npz) tiled, instead "
+                         "of instances from the device-side perfect-packing generator")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1090,7 +1099,11 @@ def main():
         instances = None
         if args.config in ("c2", "c3") and not args.synthetic_precedence:
             instances = "generate"
-        if args.config == "c4" and not args.rand_blocks:
+        if args.config == "c4" and not args.rand_blocks and not args.ppsg_fixture:
+            instances = "ppsg2d"                                    # device-side perfect-packing generator
+            name = name.replace("RAND-marginal blocks", "device-generated PPSG instances")
+            cfg = (name, D, cs, n, B, reward, strategy)
+        elif args.config == "c4" and not args.rand_blocks:
             fx = os.path.join(ROOT, "tests", "golden", "ppsg_2d.npz")
             if os.path.exists(fx):                                  # 64 PPSG instances written by the reference
                 z = np.load(fx)                                     # (tests/golden/make_golden.py --only ppsg)
@@ -1161,6 +1174,12 @@ def main():
                     "BPP_Generator_3D packings with the 'simple' take-apart test: the reference's own loop cannot reach "
                     "50 blocks (its acceptance test passes < 2e-8 of 50-block cuts and 0 of 200 layouts)" if hp.mix else
                     "device-generated 50-block RAND instances (generate.generate_instances), initial container 7 wide")
+        elif getattr(hp, "instances", None) == "ppsg2d":
+            inst = ("perfect-packing (PPSG) instances of the device-side generator (generate_blocks_with_GT's steps: "
+                    "BPP_Generator_2D_easy cuts of a 7 x H box, random take-apart order and rotations, hard LB_GREEDY layout "
+                    "in the 7 x 50 initial container, the reference's 'bot' acceptance test), H drawn per instance from "
+                    "generate_height_prob's distribution restricted to 14..24 (90 %% of it: outside, the acceptance loop needs "
+                    "1e4 .. 1e5 layouts per instance); generated in %.1f s" % getattr(hp, "generate_s", 0.0))
         elif getattr(hp, "instances", None) == "generate":
             inst = ("RAND instances of the device-side generator (generate_blocks semantics: random blocks packed into "
                     "the 7-wide initial container, real precedence)")

@@ -156,16 +156,22 @@ def gauss_split_table(max_len, size_range=(1, 5), device='cuda'):
 
 def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7, initial_container_height=50,
                                target_container_width=7, size_range=(1, 5), seed=12345, start=0, heights=None,
-                               device='cuda', max_generations=2000, return_stats=False, input_type='bot'):
+                               device='cuda', max_generations=4000, return_stats=False, input_type='bot',
+                               mean_block_area=(4.9, 8.4)):
     """B perfect-packing instances (2D) as generate.generate_blocks_with_GT builds them for block_dim 2
     (generate.py:57-161 with BPP_Generator_2D_easy, :392-484): a guillotine-cut perfect packing of a
     target_width x H box, a random take-apart order with random rotations, packed in that order into the initial
     container with hard LB_GREEDY, accepted when all blocks are stable and can be taken out again in reverse;
     up to 20 orders per perfect packing, then a new one.  -> (blocks, positions) (B, n, 2) int32, layout order.
     Instances are keyed by global index ``start + i``.  ``heights`` (B,) overrides the heights drawn from
-    height_distribution().  The acceptance test is selective (measured on the reference: about one layout in a
-    thousand at 20 blocks), hence the large default ``max_generations``; each generation costs five launches
-    over the instances still missing."""
+    height_distribution().
+
+    The acceptance test is selective and its rate depends on the height (measured with these kernels, 20 blocks,
+    W = 7, 'bot': one layout in 2.4e-5 .. 8e-5 accepted at H = 10 .. 12, 3e-4 .. 5e-4 at 14 .. 16, 2e-3 .. 5e-3 at
+    20 .. 24; from H = 27 the cut generator itself accepts fewer than 1e-3 of its draws) -- the reference's own loop
+    simply runs that long.  When the heights are drawn here, the distribution is therefore restricted to those
+    with ``mean_block_area[0] <= W*H/n <= mean_block_area[1]`` (H = 14 .. 24 at 20 blocks: 90 % of the reference's
+    distribution) and re-normalised; pass ``mean_block_area=None`` for all of it."""
     dev = _lib.resolve_device(device)
     n, B, W = int(blocks_num), int(batch_size), int(target_container_width)
     if n > 64:
@@ -173,6 +179,12 @@ def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7
     ids = torch.arange(start, start + B, dtype=torch.int64, device=dev)
     if heights is None:
         prob, keys = height_distribution(2, n, size_range, initial_container_width, W, seed=seed, device=dev)
+        if mean_block_area is not None:
+            area = keys.to(torch.float64) * W / n
+            keep = (area >= mean_block_area[0]) & (area <= mean_block_area[1])
+            if not bool(keep.any()):
+                raise ValueError("no height of the distribution has a mean block area in %r" % (mean_block_area,))
+            prob, keys = prob[keep] / prob[keep].sum(), keys[keep]
         g = torch.Generator(device='cpu')
         rows = []
         for i in range(B):                               # keyed per instance id so shards agree

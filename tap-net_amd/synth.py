@@ -97,6 +97,22 @@ def device_rand_instances(batch, n, block_dim, seed=12345, start=0, device='cuda
     return torch.cat(statics).contiguous(), torch.cat(dynamics).contiguous()
 
 
+def device_ppsg_instances(batch, n, block_dim=2, seed=12345, start=0, device='cuda', initial_container_width=7,
+                          initial_container_height=50, target_container_width=7, input_type='bot'):
+    """Perfect-packing (PPSG) instances from the device-side generator (generate.generate_ppsg_instances_2d = the
+    reference's generate_blocks_with_GT: guillotine-cut perfect packing, random take-apart order and rotations,
+    hard LB_GREEDY layout in the initial container, stability and take-apart acceptance) in PACKDataset layout;
+    keyed by global instance id, so any sharding sees the same data.  -> (static, dynamic) on ``device``."""
+    from . import generate
+    if block_dim != 2:
+        raise ValueError("2D only (the 3D series is generate.generate_ppsg_instances)")
+    cs = generate.initial_container(2, initial_container_width, initial_container_height)
+    blocks, positions = generate.generate_ppsg_instances_2d(batch, n, initial_container_width, initial_container_height,
+                                                            target_container_width, seed=seed, start=start, device=device,
+                                                            input_type=input_type)
+    return generate.precedence_tensors(blocks, positions, cs)
+
+
 def tiled_instances(static_fix, dynamic_fix, batch, start=0):
     """``batch`` instances taken cyclically from a fixture of real instances (numpy or torch, PACKDataset
     layout): env ``start + i`` gets fixture instance ``(start + i) % len(fixture)``, so shards see what
