@@ -175,9 +175,9 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_ppsg_order(PpsgOrderArgs a)
     // :89 (all deps are gone once every block is chosen).  A draw hits an unchosen candidate with probability
     // >= 1/n, so the guard only ever ends the loop on corrupt input (relations with a cycle); the rest is
     // then appended in index order instead of spinning on the GPU.
+    u64 cand = 0;                                            // :91 rows of my_deps that sum to 0, ascending; the set only
+    for (int j = 0; j < n; ++j) if (on[j] == 0) cand |= 1ull << j;   // changes when a block is chosen (:98)
     for (int guard = 0; cnt < n && guard < (1 << 20); ++guard) {
-        u64 cand = 0;                                        // :91 rows of my_deps that sum to 0, ascending
-        for (int j = 0; j < n; ++j) if ((on[j] & ~chosen) == 0) cand |= 1ull << j;
         const int nc = __popcll(cand);
         if (nc == 0) break;                                  // cannot happen: a packing always has a top block
         int k = (int)r.randint(0, nc);                       // :93 np.random.choice(candidate_idx)
@@ -187,6 +187,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_ppsg_order(PpsgOrderArgs a)
         if ((chosen >> idx) & 1ull) continue;                // :94-95
         chosen |= 1ull << idx;                               // :97-98
         order[cnt++] = idx;
+        for (int j = 0; j < n; ++j) if ((on[j] & ~chosen) == 0) cand |= 1ull << j;
     }
     for (int j = 0; j < n && cnt < n; ++j) if (!((chosen >> j) & 1ull)) { chosen |= 1ull << j; order[cnt++] = j; }
     const int perms3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
