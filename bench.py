@@ -874,8 +874,14 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
     try:
         if "cold" in skip:
             raise RuntimeError("skipped")
+        def slot_instances(k):
+            if hp.instances != "ppsg2d":
+                return hp.instances
+            # the perfect-packing generator takes ~30 s per 8 192 instances: the other slots hold this run's
+            # instances in another order (own buffers, own tape) -- the variant is about residency, not diversity
+            return (hp.static[0].roll(977 * k, 0).cpu().numpy(), hp.dynamic0[0].roll(977 * k, 0).cpu().numpy())
         hps = [hp] + [HotPath(cfg, B, 0, dev, seed=777 + 1000 * k, fused=hp.fused, window=hp.nw if hp.windows > 1 else None,
-                              bits=hp.bits, instances=hp.instances) for k in range(1, slots)]
+                              bits=hp.bits, instances=slot_instances(k)) for k in range(1, slots)]
         steps = max(slots * 4, 40)
         dt, _ = time_passes(hps, steps, slots, use_graph, 1)
         for h in hps:
