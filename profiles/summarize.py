@@ -26,8 +26,23 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, cfg = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out")
-shutil.copy(os.path.join(src, "prof_%s" % tag, "%s_kernel_stats.csv" % cfg),
-            os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))
+# the --stats summary, our kernels row by row, everything else (torch / rocprim / runtime copy and fill kernels of the
+# set-up code) summed in one line
+rows = list(csv.DictReader(open(os.path.join(src, "prof_%s" % tag, "%s_kernel_stats.csv" % cfg))))
+import re
+ours = [r for r in rows if re.match(r"^(void )?k_", r["Name"])]
+rest = [r for r in rows if r not in ours]
+with open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)), "w") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+    w.writeheader()
+    for r in ours:
+        w.writerow(r)
+    if rest:
+        tot = sum(float(r["TotalDurationNs"]) for r in rest)
+        calls = sum(int(r["Calls"]) for r in rest)
+        w.writerow({"Name": "(other: %d torch / rocprim / runtime kernels of the set-up code)" % len(rest), "Calls": calls,
+                    "TotalDurationNs": int(tot), "AverageNs": tot / max(calls, 1),
+                    "Percentage": round(sum(float(r["Percentage"]) for r in rest), 4), "MinNs": "", "MaxNs": "", "StdDev": ""})
 means = collections.defaultdict(dict)
 for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
     path = os.path.join(src, "prof_%s_%s" % (tag, kind), "%s_counter_collection.csv" % cfg)
