@@ -320,6 +320,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
     const bool inwin = (window & bit) != 0;
     const u64 (&rel)[5] = nd.rel;
     const int (&bdim)[3] = nd.bdim;
+    PROF_BEGIN;
     if (v < child) S.pos[S.ord[v]] = (unsigned char)v;
     tap_wave_lds_sync();
 
@@ -336,6 +337,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + __popcll(window & below)] = v;
     }
     tap_wave_lds_sync();
+    PROF(4);
     
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
@@ -371,6 +373,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
         if (on5) iw[v] = w;
         tap_wave_lds_sync();
     }
+    PROF(5);
     // lane = column (r, cm): static, column sums, initial mask, and the column's word of `dynamic`.  When the
     // tensor fits the bit-shadow form (3*child <= 64 rows, nRc % 4 == 0, nRc <= 256) the words go through LDS
     // and the fp32 tensor is expanded from them as in stream_wave_bits (tap_masks.h): a store instruction
@@ -439,6 +442,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
     
     if (!packed) return;
     tap_wave_lds_sync();
+    PROF(6);
     const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
     if (rsub < RP) {
         // rows rsub, rsub + RP, ...: the words are shifted down by rsub once, so that row i*RP sits at the
@@ -455,7 +459,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
                                                             (float)((h2 >> s5) & 1u), (float)((h3 >> s5) & 1u)));
         }
     }
-    
+    PROF(7);
 }
 
 template <int D>
