@@ -109,8 +109,9 @@ int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream
 
 /* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy
  * 2027-2351, is_stable_2d 839-868, is_stable 710-765; with strategy TAP_MACS ->
- * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (3D: H <= 512 and block
- * sides <= container sides, else error bit 4); model.py:451-465 is the loop it replaces).
+ * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 64, H <= 256;
+ * 3D: W, L <= 8, H <= 512 and block sides <= container sides, else error bit 4); model.py:451-465 is
+ * the loop it replaces).
  *   blocks      (B, D) TAP_DT_F32 | TAP_DT_I32, one block per env; f32 is truncated like
  *               block.astype(int) (tools.py:3689)
  *   active      (B,) uint8 or NULL: envs with 0 are not stepped and only report their feature
@@ -355,7 +356,7 @@ enum {
  * tap_mask_step + tap_env_step_gather fused, so the placement's latency hides under the HBM-bound
  * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
  * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
- * LB_GREEDY (2D/3D) and MACS/MUL (2D; 3D with H <= 512).  feature_out nullable; ratio_out (B,) f32 required with
+ * LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D with H <= 512).  feature_out nullable; ratio_out (B,) f32 required with
  * TAP_T_RATIO. */
 int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                    int update_rows, const float *dyn_in, const float *static_, int static_rows,

@@ -294,6 +294,8 @@ static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, i
     if (d->strategy == TAP_LB || tap_is_big(d))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "no fused step for the legacy LB strategy or containers above 64 cells: use tap_mask_step + tap_env_step_gather");
     if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
+    if (d->strategy == TAP_MACS && d->D == 2 && d->W > 16)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "no fused step for MACS containers above 16 columns: use tap_mask_step + tap_env_step_gather");
     if (!state || !static_ || !ptr || !mask_in || !current_out || !mask_out || n < 1 || R < 1 || rows < 1 ||
         static_rows < 1 + d->D || update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");

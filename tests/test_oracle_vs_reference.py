@@ -68,6 +68,10 @@ def test_lb_legacy(ref, reward):
 def test_macs2d(ref, reward):
     _diff(ref[0], [7, 100], 20, reward, "diff", "MACS", 25, 31)
     _diff(ref[0], [5, 50], 10, reward, "diff", "MACS", 40, 32)
+    # wide containers (the kernels' 32- and 64-lane form, tap_macs_wide.h), blocks up to 8 wide
+    _diff(ref[0], [20, 60], 24, reward, "diff", "MACS", 4, 33, 1, 7)
+    _diff(ref[0], [40, 40], 30, reward, "full", "MACS", 2, 34, 1, 9)
+    _diff(ref[0], [64, 30], 24, reward, "zero", "MACS", 2, 35, 1, 9)
 
 
 @pytest.mark.parametrize("reward", ["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft"])
