@@ -10,6 +10,7 @@ mutated: the trainer re-uses it for the critic, trainer.py:214).
 """
 import itertools
 import math
+import os
 import weakref
 
 import numpy as np
@@ -608,6 +609,93 @@ class PACKDataset(Dataset):
 
     def __getitem__(self, idx):
         return (self.static[idx], self.dynamic[idx], self.decoder_static[idx], self.decoder_dynamic[idx])
+
+
+# ---- dataset creation (pack.py:475-667): the entry points trainer.py calls before it builds PACKDataset ---------
+
+def _dataset_dirs(kind, blocks_num, train_size, valid_size, obj_dim, initial_container_width, size_range):
+    def one(split, size):
+        return './data/%s_%dd/pack-%s-%d-%d-%d-%d-%d/' % (kind, obj_dim, split, blocks_num, size, initial_container_width,
+                                                          size_range[0], size_range[1])
+    return one('train', train_size), one('valid', valid_size)
+
+
+def _have(data_dir):
+    return os.path.exists(data_dir + 'blocks.txt')
+
+
+def create_dataset(blocks_num, train_size, valid_size, obj_dim, initial_container_width, initial_container_height,
+                   arm_size, size_range, seed=None, device='cuda'):
+    """pack.create_dataset (pack.py:580-667): RAND instances -- random blocks packed into the initial container
+    with hard LB_GREEDY, kept when every block is stable, precedence extracted from the packing
+    (generate.generate_blocks) -- written as the reference's six text files under the reference's directory
+    names; existing directories are reused.  -> (train_dir, valid_dir).  The instances come from the device-side
+    generator (generate.generate_instances), the files from datafiles.write_dataset.
+    ``initial_container_width`` <= -1 (the reference's container-free random-dependency sets,
+    generate.generate_deps_prob) is not provided."""
+    from . import generate, datafiles
+    blocks_num = int(blocks_num)
+    if initial_container_width <= -1:
+        raise NotImplementedError("random-dependency data sets without an initial container (generate_deps_prob)")
+    if seed is None:
+        seed = np.random.randint(123456789)
+    train_dir, valid_dir = _dataset_dirs('rand', blocks_num, train_size, valid_size, obj_dim, initial_container_width, size_range)
+    for k, (data_dir, size) in enumerate(((train_dir, train_size), (valid_dir, valid_size))):
+        if _have(data_dir):
+            continue
+        static, dynamic, _, positions = generate.generate_instances(
+            int(size), blocks_num, obj_dim, initial_container_width, initial_container_height, arm_size, tuple(size_range),
+            seed=(int(seed) + 7919 * k) % (2 ** 31), device=device, return_aux=True)
+        ids = np.random.RandomState((int(seed) + k) % (2 ** 31)).randint(0, 2, size=(int(size), blocks_num))  # pack.py:652
+        datafiles.write_dataset(data_dir, static, dynamic, positions, container_ids=ids)
+    return train_dir, valid_dir
+
+
+def create_dataset_gt(blocks_num, train_size, valid_size, obj_dim, target_container_width, target_container_height,
+                      initial_container_width, initial_container_height, input_type, arm_size, size_range, seed=None,
+                      device='cuda'):
+    """pack.create_dataset_gt (pack.py:475-566): perfect-packing (PPSG) instances -- generate_blocks_with_GT with
+    the height of the perfect packing drawn per sample from generate_height_prob's distribution -- as the six text
+    files under the reference's directory names.  -> (train_dir, valid_dir).  Device generators:
+    generate.generate_ppsg_instances_2d / generate_ppsg_instances (see their notes on which heights and block
+    counts the reference's acceptance loops can reach).  One container-id vector per data set, half zeros, shuffled
+    (pack.py:516-518)."""
+    from . import generate, datafiles
+    blocks_num = int(blocks_num)
+    if int(arm_size) != 1:
+        raise NotImplementedError("perfect-packing instances are generated for arm_size 1 (the reference's default)")
+    if seed is None:
+        seed = np.random.randint(123456789)
+    train_dir, valid_dir = _dataset_dirs('gt', blocks_num, train_size, valid_size, obj_dim, initial_container_width, size_range)
+    rs = np.random.RandomState(int(seed) % (2 ** 31))
+    for k, (data_dir, size) in enumerate(((train_dir, train_size), (valid_dir, valid_size))):
+        ids = np.ones(blocks_num, dtype=np.int64)
+        ids[:blocks_num // 2] = 0
+        rs.shuffle(ids)
+        if _have(data_dir):
+            continue
+        kw = dict(seed=(int(seed) + 7919 * k) % (2 ** 31), device=device, input_type=input_type)
+        if obj_dim == 2:
+            blocks, positions = generate.generate_ppsg_instances_2d(int(size), blocks_num, initial_container_width,
+                                                                    initial_container_height, target_container_width,
+                                                                    tuple(size_range), **kw)
+        else:
+            blocks, positions = generate.generate_ppsg_instances(int(size), blocks_num, initial_container_width,
+                                                                 initial_container_height, target_container_width,
+                                                                 tuple(size_range), **kw)
+        cs = generate.initial_container(obj_dim, initial_container_width, initial_container_height)
+        static, dynamic = generate.precedence_tensors(blocks, positions, cs, arm_size)
+        datafiles.write_dataset(data_dir, static, dynamic, positions, container_ids=np.tile(ids, (int(size), 1)))
+    return train_dir, valid_dir
+
+
+def get_mix_dataset(blocks_num, train_size, valid_size, obj_dim, initial_container_width, size_range, seed=None):
+    """pack.get_mix_dataset (pack.py:568-578): the directory names of the PPSG and RAND sets a MIX run reads --
+    names only, nothing is generated.  (sic) the reference returns the 2D directories for obj_dim 3 as well."""
+    blocks_num = int(blocks_num)
+    g = _dataset_dirs('gt', blocks_num, train_size, valid_size, 2, initial_container_width, size_range)
+    r = _dataset_dirs('rand', blocks_num, train_size, valid_size, 2, initial_container_width, size_range)
+    return g[0], r[0], g[1], r[1]
 
 
 def rotation_permutations(block_dim):

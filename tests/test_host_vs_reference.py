@@ -59,3 +59,23 @@ def test_no_precedence_and_unit(dirs):
     mine = T.PACKDataset(d, 10, N, 3, "bot", "diff", True, 5, unit=0.5, no_precedence=True)
     assert torch.equal(ref.static, mine.static) and torch.equal(ref.dynamic, mine.dynamic)
     assert ref.decoder_dynamic.shape == mine.decoder_dynamic.shape
+
+
+def test_dataset_directory_names_match_reference(tmp_path, monkeypatch):
+    """create_dataset / create_dataset_gt / get_mix_dataset name their directories as the reference does
+    (pack.py:475-505, 568-608): with the directories already present both sides return without generating."""
+    import os
+    from tap_net_amd import pack as tpack
+    _, rpack, _ = ref_loader.load()
+    monkeypatch.chdir(tmp_path)
+    for D in (2, 3):
+        for n, tr, va, iw, sr in ((10, 1000, 100, 7, [1, 5]), (20, 64, 8, 5, [2, 6])):
+            for kind in ("rand", "gt"):
+                for split, size in (("train", tr), ("valid", va)):
+                    d = "./data/%s_%dd/pack-%s-%d-%d-%d-%d-%d/" % (kind, D, split, n, size, iw, sr[0], sr[1])
+                    os.makedirs(d, exist_ok=True)
+                    open(d + "blocks.txt", "w").write("0\n")
+            assert tpack.create_dataset(n, tr, va, D, iw, 50, 1, sr, seed=3) == rpack.create_dataset(n, tr, va, D, iw, 50, 1, sr, seed=3)
+            assert tpack.create_dataset_gt(n, tr, va, D, 5, 50, iw, 50, "bot", 1, sr, seed=3) == \
+                rpack.create_dataset_gt(n, tr, va, D, 5, 50, iw, 50, "bot", 1, sr, seed=3)
+            assert tpack.get_mix_dataset(n, tr, va, D, iw, sr, seed=3) == rpack.get_mix_dataset(n, tr, va, D, iw, sr, seed=3)
