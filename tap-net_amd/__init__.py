@@ -11,7 +11,7 @@ from .env import BatchedContainer, Container                   # noqa: F401
 from .generate import generate_instances                       # noqa: F401
 from .pack import (EnvTransition, MaskStepper, PACKDataset, initial_mask, reward,   # noqa: F401
                    update_dynamic, update_mask)
-from .rolling import RollingWindows, run_rolling_episode            # noqa: F401
+from .rolling import RollingDataset, RollingWindows, run_rolling_episode            # noqa: F401
 from .rollout import RandomFeasiblePolicy, TapePolicy, UniformPickPolicy, run_episode   # noqa: F401
 
 __all__ = ["BatchedContainer", "Container", "MaskStepper", "EnvTransition", "PACKDataset", "initial_mask", "reward",

@@ -109,6 +109,61 @@ class RollingWindows(object):
             raise _lib.TapError(_lib.TAP_E_INVALID, "a precedence window could not be filled")
 
 
+class RollingDataset(object):
+    """rolling.RollingDataset (rolling.py:462-536): the reference's data files of ``total_blocks_num``-block
+    instances -> the initial containers ``rolling.validate`` rolls over, here ONE batched ``RollingWindows``
+    (``.windows``, windows of ``net_blocks_num`` nodes) instead of a list of per-sample ``InitialContainer``s, plus
+    the zero decoder inputs with the reference's shapes.  ``.blocks`` / ``.positions`` (N, total, D) int32 are
+    rotation 0 of every block, as the reference hands them to ``InitialContainer``."""
+
+    def __init__(self, data_file, total_blocks_num, net_blocks_num, num_samples, block_dim, seed, input_type,
+                 heightmap_type, allow_rot, container_width, initial_container_width, initial_container_height,
+                 mix_data_file=None, unit=1, device='cuda'):
+        import numpy as np
+        if seed is None:
+            seed = np.random.randint(123456)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        N, n, D = int(num_samples), int(total_blocks_num), int(block_dim)
+        blocks, positions = self.read_instances(data_file, n, D, N)
+        self.blocks = torch.as_tensor(np.ascontiguousarray(blocks), dtype=torch.int32, device=device)
+        self.positions = torch.as_tensor(np.ascontiguousarray(positions), dtype=torch.int32, device=device)
+        init = ([initial_container_width, initial_container_height] if D == 2 else
+                [initial_container_width, initial_container_width, initial_container_height])       # rolling.py:494-497
+        self.initial_container_size = init
+        self.windows = RollingWindows(self.blocks, self.positions, init, child_graph_size=int(net_blocks_num))
+        static_dim, maps = D, 1                                                          # rolling.py:506-527
+        if heightmap_type == 'diff':
+            width = container_width * unit - 1 if D == 2 else container_width * unit
+            maps = 1 if D == 2 else 2
+        else:
+            width = container_width * unit
+        if input_type in ('mul', 'mul-with'):
+            if D == 2:
+                width *= 2
+            else:
+                maps *= 2
+        if input_type == 'mul-with':
+            static_dim += 1
+        self.decoder_static = torch.zeros(1, static_dim, 1, device=device)               # rolling.py:529-534
+        self.decoder_dynamic = (torch.zeros(1, width, 1, device=device) if D == 2 else
+                                torch.zeros(1, maps, width, width, device=device))
+        self.num_samples = N
+
+    @staticmethod
+    def read_instances(data_file, total_blocks_num, block_dim, num_samples):
+        """blocks.txt / pos.txt -> (blocks, positions) (N, total, D) int64, rotation 0 (rolling.py:475-491)."""
+        import numpy as np
+        n, D = int(total_blocks_num), int(block_dim)
+        blocks = np.loadtxt(data_file + 'blocks.txt', ndmin=2).astype('int64')
+        positions = np.loadtxt(data_file + 'pos.txt', ndmin=2).astype('int64')
+        R = 2 if D == 2 else 6
+        data_size = len(blocks) // R
+        blocks = blocks.reshape(data_size, -1, D, n).transpose(0, 1, 3, 2).reshape(data_size, -1, D)
+        positions = positions.reshape(len(positions), -1, n).transpose(0, 2, 1)
+        return blocks[:num_samples, :n], positions[:num_samples]
+
+
 def run_rolling_episode(blocks, positions, initial_container_size, policy, container_width, container_height,
                         child_graph_size=10, reward_type='C+P+S-lb-soft', heightmap_type='diff',
                         packing_strategy='LB_GREEDY', record=False, fused=True):

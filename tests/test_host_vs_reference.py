@@ -79,3 +79,26 @@ def test_dataset_directory_names_match_reference(tmp_path, monkeypatch):
             assert tpack.create_dataset_gt(n, tr, va, D, 5, 50, iw, 50, "bot", 1, sr, seed=3) == \
                 rpack.create_dataset_gt(n, tr, va, D, 5, 50, iw, 50, "bot", 1, sr, seed=3)
             assert tpack.get_mix_dataset(n, tr, va, D, iw, sr, seed=3) == rpack.get_mix_dataset(n, tr, va, D, iw, sr, seed=3)
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_rolling_dataset_reads_what_the_reference_reads(dirs, D):
+    """rolling.RollingDataset (rolling.py:462-536): the blocks / positions our reader hands to RollingWindows are
+    the arrays the reference hands to each InitialContainer, and the zero decoder inputs have its shapes."""
+    import importlib, sys
+    from tap_net_amd.rolling import RollingDataset
+    ref_loader.load()
+    sys.path.insert(0, ref_loader.REFERENCE_DIR)
+    try:
+        rrolling = importlib.import_module("rolling")
+    finally:
+        sys.path.remove(ref_loader.REFERENCE_DIR)
+    d, _, N = dirs[D]
+    M = 6
+    ref = rrolling.RollingDataset(d, 10, 5, M, D, 3, "bot", "diff", True, 5, 7, 50)
+    blocks, positions = RollingDataset.read_instances(d, 10, D, M)
+    for i in range(M):
+        ic = ref.initial_containers[i]
+        assert np.array_equal(np.asarray(ic.blocks)[:10], blocks[i]) and np.array_equal(np.asarray(ic.positions), positions[i])
+    assert tuple(ref.decoder_static.shape) == (1, D, 1)
+    assert tuple(ref.decoder_dynamic.shape) == ((1, 4, 1) if D == 2 else (1, 2, 5, 5))
