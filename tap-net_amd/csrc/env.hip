@@ -193,13 +193,32 @@ extern "C" int tap_env_feature_len(const tap_env_desc *d)
     return d->W * d->L;
 }
 
+// clear_container as a KERNEL, not hipMemsetAsync: a memset captured into a hipGraph becomes a memset node, and
+// on this ROCm stack (7.2) such a node was observed to run out of order with the kernel nodes around it when the
+// graph is replayed (rolling passes replayed from a graph started some episodes on a half-cleared container);
+// a kernel node keeps stream order.
+__global__ void __launch_bounds__(TAP_BLOCK) k_zero16(uint4 *p, size_t n16)
+{
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t i = (size_t)blockIdx.x * TAP_BLOCK + threadIdx.x; i < n16; i += (size_t)gridDim.x * TAP_BLOCK) p[i] = z;
+}
+
 extern "C" int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream)
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
-    TAP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, tap_env_layout(d, nullptr, nullptr), (hipStream_t)stream));
+    const size_t bytes = tap_env_layout(d, nullptr, nullptr);
+    if ((reinterpret_cast<uintptr_t>(state) | bytes) % 16) {      // torch allocations are 256-byte aligned; any other caller
+        TAP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, bytes, (hipStream_t)stream));
+        return TAP_OK;
+    }
+    const size_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)((n16 + TAP_BLOCK - 1) / TAP_BLOCK < 2048 ? (n16 + TAP_BLOCK - 1) / TAP_BLOCK : 2048);
+    hipLaunchKernelGGL(k_zero16, dim3(grid ? grid : 1), dim3(TAP_BLOCK), 0, (hipStream_t)stream,
+                       reinterpret_cast<uint4 *>(state), n16);
+    TAP_LAUNCH_CHECK(ctx, "k_zero16");
     return TAP_OK;
 }
 

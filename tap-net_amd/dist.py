@@ -20,7 +20,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    # TAP_DIST_FORCE_INIT=1: a 1-rank process group (the only way to exercise RCCL on a 1-GPU box)
+    if (world > 1 or os.environ.get('TAP_DIST_FORCE_INIT') == '1') and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:   # TAP_DIST_BACKEND=gloo lets several ranks share one GPU (testing only)
