@@ -555,6 +555,8 @@ def time_passes(hps, steps, warmup, use_graph, world):
                 group[cnt] = capture(hp, cnt)
         if rows_on:
             hp.reward = acc[0]                                  # graphs[0] (event timing, verification) writes row 0
+        if single and GATHER_EVERY in group:
+            hp.group_graph = (group[GATHER_EVERY], GATHER_EVERY)
 
     def run(npasses):
         if single:
@@ -622,10 +624,14 @@ def kernel_event_times(hp, steps, graph=None):
         # whole passes without per-launch events: (pass time) / launches = per-launch time incl. the
         # inter-kernel gap, free of the event-pair overhead
         hp.hook = None
-        for _ in range(steps):
+        grp = getattr(hp, "group_graph", None) if graph is not None else None   # (graph of cnt passes, cnt): the timed loop's unit
+        per = grp[1] if grp else 1
+        for _ in range(max(2, steps // per)):
             a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
             a.record()
-            if graph is not None:
+            if grp:
+                grp[0].replay()
+            elif graph is not None:
                 graph.replay()
             else:
                 hp.episode()
@@ -645,7 +651,7 @@ def kernel_event_times(hp, steps, graph=None):
         us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
         out[name] = dict(launches=len(us), avg_us=float(us.mean()), med_us=float(np.median(us)),
                          total_us=float(us.sum()))
-    pass_us = float(np.median([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3)
+    pass_us = float(np.median([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3) / per
     return out, empty_us, pass_us
 
 
@@ -1195,7 +1201,8 @@ def main():
         if hp.kind == "transition" and hp.fused:
             other = sum(max(kt[k]["med_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
             dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
-            how = "(graph-replayed pass - the other kernels' event time) / launches; includes the inter-kernel gap"
+            how = ("(graph-replayed pass - the other kernels' event time) / launches, passes replayed %d per graph launch as "
+                   "in the timed loop; includes the inter-kernel gap" % GATHER_EVERY)
         elif hp.kind == "episode":
             dom_us, how = pass_us, "event-bracketed pass (one launch)"
         else:
@@ -1270,7 +1277,7 @@ def main():
                           spawned_by_bench=os.environ.get("TAP_BENCH_SPAWNED") == "1"),
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy, "instances": inst, "pass": pas,
-                       "launch": "hipGraph replay" if use_graph else "eager"},
+                       "launch": ("hipGraph replay, %d passes per graph launch" % GATHER_EVERY) if use_graph else "eager"},
             "roofline": roof,
             "kernels": kernels,
         }
