@@ -485,7 +485,23 @@ class RollingHotPath(HotPath):
         return out
 
 
-GATHER_EVERY = 8   # passes whose (B,) reward vectors share one RCCL all-gather (fewer, larger collectives)
+GATHER_EVERY = 8   # least number of passes per graph launch / reward vectors per RCCL all-gather (passes_per_graph)
+
+
+def passes_per_graph(hp):
+    """Passes replayed per graph launch (= reward vectors per all-gather): 8 for passes of 0.4 ms and more, up to 64
+    for the shortest, so that a graph launch (~5 us) and, with N > 1, an all-gather launch (~60 us between two
+    graph launches, measured on a 1-rank RCCL group) stay small against the work they bracket.  The estimate is an
+    eager pass, timed once."""
+    for _ in range(2):
+        hp.episode()
+    torch.cuda.synchronize(hp.device)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        hp.episode()
+    torch.cuda.synchronize(hp.device)
+    t = (time.perf_counter() - t0) / 3
+    return GATHER_EVERY if t >= 400e-6 else 2 * GATHER_EVERY if t >= 200e-6 else 4 * GATHER_EVERY if t >= 100e-6 else 8 * GATHER_EVERY
 
 
 def time_passes(hps, steps, warmup, use_graph, world):
@@ -500,15 +516,17 @@ def time_passes(hps, steps, warmup, use_graph, world):
     # process group: the only way to time its overhead on a 1-GPU box
     gather = world > 1 or (os.environ.get("TAP_BENCH_FORCE_GATHER") == "1" and tdd.is_available() and tdd.is_initialized())
     nranks = tdd.get_world_size() if gather else 1
-    # With a gather, pass i writes its (B,) reward vector straight into row i % GATHER_EVERY of `acc` (the pass's
+    # With a gather, pass i writes its (B,) reward vector straight into row i % ge of `acc` (the pass's
     # ratio_out IS that row) -- no copy kernel (measured: ~15 us per pass as an eager launch between two replays,
-    # ~7 us as an extra graph node), and GATHER_EVERY passes share one all-gather.
+    # ~7 us as an extra graph node), and ge passes share one all-gather.
     single = len(hps) == 1
+    ge = passes_per_graph(hp) if single else GATHER_EVERY
+    hp.passes_per_graph = ge
     # (a single instance set files its passes' rewards into the rows without a gather too: the rows of the last
     #  group are compared with each other afterwards -- the tape is the same every pass, so they must be identical;
     #  this is what caught a hipGraph memset node running out of order in the rolling pass)
     rows_on = gather or single
-    acc = torch.full((GATHER_EVERY, hp.B), float("nan"), dtype=torch.float32, device=dev) if rows_on else None
+    acc = torch.full((ge, hp.B), float("nan"), dtype=torch.float32, device=dev) if rows_on else None
     if gather and not single:
         raise ValueError("the gather path times one instance set")
     state = {"i": 0, "pass": 0}
@@ -549,20 +567,20 @@ def time_passes(hps, steps, warmup, use_graph, world):
             warm(h)
         graphs = [capture(h, 1) for h in hps]                   # one pass each: event timing, the cold rotation
         if single:
-            # the timed loop of one instance set replays GATHER_EVERY passes per graph launch (and one shorter
+            # the timed loop of one instance set replays ge passes per graph launch (and one shorter
             # graph for the remainder): the launch-bound inner loop is what a hipGraph is for
-            for cnt in sorted({GATHER_EVERY, warmup % GATHER_EVERY, steps % GATHER_EVERY} - {0}):
+            for cnt in sorted({ge, warmup % ge, steps % ge} - {0}):
                 group[cnt] = capture(hp, cnt)
         if rows_on:
             hp.reward = acc[0]                                  # graphs[0] (event timing, verification) writes row 0
-        if single and GATHER_EVERY in group:
-            hp.group_graph = (group[GATHER_EVERY], GATHER_EVERY)
+        if single and ge in group:
+            hp.group_graph = (group[ge], ge)
 
     def run(npasses):
         if single:
             done = 0
             while done < npasses:
-                cnt = min(GATHER_EVERY, npasses - done)
+                cnt = min(ge, npasses - done)
                 if graphs is not None:
                     group[cnt].replay()
                 else:
@@ -595,7 +613,7 @@ def time_passes(hps, steps, warmup, use_graph, world):
         hp.reward = acc[0]
         # every pass of the last group(s) against row 0 (NaN = a row no timed pass wrote; NaN rewards of flagged
         # containers compare equal to themselves here)
-        written = [j for j in range(GATHER_EVERY) if j < min(steps, GATHER_EVERY)]
+        written = [j for j in range(ge) if j < min(steps, ge)]
         same = all(bool(torch.equal(torch.nan_to_num(acc[j], nan=-7.0), torch.nan_to_num(acc[0], nan=-7.0))) for j in written)
         hp.passes_identical = dict(passes_compared=len(written), identical=same)
     return tdist.max_over_ranks(dt, dev), graphs
@@ -1202,7 +1220,7 @@ def main():
             other = sum(max(kt[k]["med_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
             dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
             how = ("(graph-replayed pass - the other kernels' event time) / launches, passes replayed %d per graph launch as "
-                   "in the timed loop; includes the inter-kernel gap" % GATHER_EVERY)
+                   "in the timed loop; includes the inter-kernel gap" % getattr(hp, "passes_per_graph", GATHER_EVERY))
         elif hp.kind == "episode":
             dom_us, how = pass_us, "event-bracketed pass (one launch)"
         else:
@@ -1277,7 +1295,7 @@ def main():
                           spawned_by_bench=os.environ.get("TAP_BENCH_SPAWNED") == "1"),
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy, "instances": inst, "pass": pas,
-                       "launch": ("hipGraph replay, %d passes per graph launch" % GATHER_EVERY) if use_graph else "eager"},
+                       "launch": ("hipGraph replay, %d passes per graph launch" % getattr(hp, "passes_per_graph", GATHER_EVERY)) if use_graph else "eager"},
             "roofline": roof,
             "kernels": kernels,
         }
