@@ -633,11 +633,38 @@ def kernel_event_times(hp, steps, graph=None):
         b.record()
         recs.setdefault(name, []).append((a, b))
 
+    # second form: ONE event pair around each run of consecutive launches of the same kernel (the 40 rolling steps of
+    # a pass ...): elapsed / launches = per-launch time incl. the gap between launches, with the event overhead
+    # spread over the run -- a single launch between two events reads 2-4 us long, and subtracting an empty pair
+    # (5-7 us) over-corrects
+    runs, cur = {}, {"name": None, "start": None, "n": 0}
+
+    def close_run():
+        if cur["name"] is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            runs.setdefault(cur["name"], []).append((cur["start"], e, cur["n"]))
+        cur["name"], cur["start"], cur["n"] = None, None, 0
+
+    def run_hook(name, launch):
+        if name != cur["name"]:
+            close_run()
+            cur["name"] = name
+            cur["start"] = torch.cuda.Event(enable_timing=True)
+            cur["start"].record()
+        launch()
+        cur["n"] += 1
+
     pass_pairs = []
     hp.hook = hook
     try:
         for _ in range(steps):
             hp.episode()
+        torch.cuda.synchronize(hp.device)
+        hp.hook = run_hook
+        for _ in range(steps):
+            hp.episode()
+            close_run()
         torch.cuda.synchronize(hp.device)
         # whole passes without per-launch events: (pass time) / launches = per-launch time incl. the
         # inter-kernel gap, free of the event-pair overhead
@@ -669,6 +696,11 @@ def kernel_event_times(hp, steps, graph=None):
         us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
         out[name] = dict(launches=len(us), avg_us=float(us.mean()), med_us=float(np.median(us)),
                          total_us=float(us.sum()))
+        rr = runs.get(name, [])
+        if rr:
+            per_launch_us = np.array([a.elapsed_time(b) * 1e3 / n for a, b, n in rr])
+            out[name]["run_us"] = float(np.median(per_launch_us))
+            out[name]["run_len"] = int(np.median([n for _, _, n in rr]))
     pass_us = float(np.median([a.elapsed_time(b) for a, b in pass_pairs]) * 1e3) / per
     return out, empty_us, pass_us
 
@@ -1223,14 +1255,21 @@ def main():
                    "in the timed loop; includes the inter-kernel gap" % getattr(hp, "passes_per_graph", GATHER_EVERY))
         elif hp.kind == "episode":
             dom_us, how = pass_us, "event-bracketed pass (one launch)"
+        elif kt[dom].get("run_len", 1) >= 8:
+            dom_us = kt[dom]["run_us"]
+            how = ("one event pair around each run of %d consecutive launches of the kernel, per launch (median over the "
+                   "passes); includes the gap between launches" % kt[dom]["run_len"])
         else:
-            dom_us = max(kt[dom]["med_us"] - empty_us, 1e-3)
-            how = "median event-bracketed launch minus an empty event pair"
+            dom_us = kt[dom]["med_us"]
+            how = ("median event-bracketed launch, uncorrected: reads about 2 us longer than the kernel (an empty event pair "
+                   "takes %.1f us, but most of that overlaps a kernel placed between the two records)" % empty_us)
         ach = per_launch[dom] / (dom_us * 1e-6) / 1e9
         kernels = {}
         for k in names:
             kernels[k] = dict(med_us_event_pair=round(kt[k]["med_us"], 3), avg_us_event_pair=round(kt[k]["avg_us"], 3),
                               launches_per_pass=kt[k]["launches"] // npass)
+            if "run_us" in kt[k]:
+                kernels[k]["us_per_launch_in_runs"] = round(kt[k]["run_us"], 3)
             if k in per_launch:
                 kernels[k]["alg_bytes_per_launch"] = per_launch[k]
         tkey = args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")
