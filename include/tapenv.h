@@ -104,7 +104,9 @@ size_t tap_env_state_bytes(const tap_env_desc *d);
 /* floats per env returned by step/feature: W*L (full/zero), W-1 (2D diff), 2*W*L (3D diff) */
 int tap_env_feature_len(const tap_env_desc *d);
 
-/* tools.Container.__init__ state / clear_container (tools.py:3629-3655, 3858-3885) */
+/* tools.Container.__init__ state / clear_container (tools.py:3629-3655, 3858-3885).  The blob is cleared by a
+ * kernel, not hipMemsetAsync: the call may be captured into a hipGraph (a captured memset becomes a graph memset
+ * node, which was observed to run out of order with the neighbouring kernel nodes on replay). */
 int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream);
 
 /* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy
