@@ -560,9 +560,25 @@ struct RollStepArgs {
 constexpr int ROLL_EPB = 2;   // instances per workgroup of the fused step (2: 3-wave workgroups pack a CU's 28 wave slots
                               // better than 6-wave ones: 9 x 3 = 27 against 4 x 6 = 24)
 
+template <int D, int G, bool SOFT>
+__device__ __forceinline__ void rolling_step_body(const RollStepArgs &a);
+
+template <int D, int G>
+__global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_rolling_step_soft(RollStepArgs a)
+{
+    rolling_step_body<D, G, true>(a);
+}
+
 template <int D, int G>
 __global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_rolling_step(RollStepArgs a)
+{
+    rolling_step_body<D, G, false>(a);
+}
+
+template <int D, int G, bool SOFT>
+__device__ __forceinline__ void rolling_step_body(const RollStepArgs &a)
 {
     constexpr int EPB = ROLL_EPB;                           // instances per workgroup
     constexpr int ENV_WAVES = (EPB * G + 63) / 64;
@@ -576,7 +592,7 @@ k_rolling_step(RollStepArgs a)
         const int cell = tid % G, grp = tid / G;
         // groups beyond EPB (when EPB*G is not a multiple of 64) idle on an out-of-range env
         const int env = grp < EPB ? base + grp : a.s.d.B;
-        tap_lb_place_wave<D, G>(a.s, 0, nullptr, env, cell, lane, s_old + (tid - cell), s_new + (tid - cell));
+        tap_lb_place_wave<D, G, !SOFT>(a.s, 0, nullptr, env, cell, lane, s_old + (tid - cell), s_new + (tid - cell));
         return;
     }
     rolling_window_wave<D>(a.r, base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
@@ -846,7 +862,8 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
     constexpr int EPB = ROLL_EPB, ENV_WAVES = (EPB * G + 63) / 64, THREADS = 64 * (ENV_WAVES + EPB);
     const int grid = (a.r.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
-    hipLaunchKernelGGL((k_rolling_step<D, G>), dim3(grid), dim3(THREADS), 0, st, a);
+    if (a.s.d.flags & TAP_F_HARD) hipLaunchKernelGGL((k_rolling_step<D, G>), dim3(grid), dim3(THREADS), 0, st, a);
+    else hipLaunchKernelGGL((k_rolling_step_soft<D, G>), dim3(grid), dim3(THREADS), 0, st, a);   // soft rewards: no hard-mode walk compiled in
     TAP_LAUNCH_CHECK(ctx, "k_rolling_step");
     return TAP_OK;
 }

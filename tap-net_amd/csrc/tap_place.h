@@ -254,7 +254,9 @@ __device__ __forceinline__ double tap_score(const PlaceCfg &c, const Counters &c
 // cell     : lane index inside the group; hm : this lane's cell height (updated on commit)
 // do_step  : group-uniform; false leaves the env untouched
 // err      : per-lane error bits, OR-reduced by the caller (1 = height overflow)
-template <int D, int G>
+// HARDOK = false compiles the soft form only (the caller has checked that TAP_F_HARD is not set): the hard-mode
+// walk is what drives the register count (3D: 106 VGPRs with it, 58 without).
+template <int D, int G, bool HARDOK = true>
 __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell, int &hm,
                                       Counters &cnt, int &err, int bx, int by, int bz,
                                       bool do_step)
@@ -298,7 +300,7 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
     Placement res = {0, 0, 0, 0, 0};
     int emp_w = 0;
 
-    if (!hard) {
+    if (!HARDOK || !hard) {
         // soft: every in-bounds corner settles on itself (z = max of its footprint)
         double ratio = -1.0;
         int key = INT_MAX, z = 0, stab = 0, emp = 0;

@@ -10,7 +10,7 @@
 
 // env: this group's container; cell / lane: lane index inside the group / the wave;
 // g_old, g_new: the group's two G-int LDS slices.  Every lane of the wave must call this.
-template <int D, int G>
+template <int D, int G, bool HARDOK = true>
 __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, float *ratio_out,
                                                   int env, int cell, int lane, int *g_old, int *g_new)
 {
@@ -50,7 +50,7 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
     tap_wave_lds_sync();
     const PlaceCfg cfg = {W, L, s.d.H, s.d.flags, s.lut};
     const int step = cnt.count;
-    const Placement pl = tap_place<D, G>(cfg, g_old, cell, hm, cnt, err, bx, by, bz, do_step);
+    const Placement pl = tap_place<D, G, HARDOK>(cfg, g_old, cell, hm, cnt, err, bx, by, bz, do_step);
     err = group_or<G>(err);
     g_new[cell] = hm;
     tap_wave_lds_sync();
