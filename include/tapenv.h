@@ -167,12 +167,32 @@ int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const 
                        int static_rows, int nR, const int64_t *tour, float *reward_out,
                        int32_t *positions_out, uint8_t *stable_out, void *stream);
 
+/* tools.calc_positions_lb_greedy (tools.py:2393-2449) / tools.calc_positions_mcs (tools.py:3213-3315) per env,
+ * as pack.render calls them for its metric files (pack.py:743-792; caller trainer.py:132, 493): the whole
+ * episode in one launch with every strategy tap_env_step has except the legacy 'LB' (render never uses it,
+ * pack.py:741), containers up to 64 cells.  static_ / tour as tap_episode_reward.
+ *   target_sel   -1: every tour entry.  0 | 1: the two-container input types ('mul', 'mul-with', pack.py:755-790):
+ *                only the entries whose target id -- the LAST row of static_ -- equals it, in tour order.
+ *   ratio64_out  (B,) f64: the function's `ratio` (tools.py:2442-2445 C+P+S; tools.py:3279-3308 by reward type,
+ *                d->ratio_mode without Container.calc_ratio's division); 0 for an empty list (pack.py:760-769);
+ *                NaN when the container raised an error bit
+ *   scores_out   (B, 5) int64: valid_size, box_size, empty_size, stable_num, max(heightmap) (tools.py:2447, 3311);
+ *                zeros for an empty list
+ *   err_out      (B,) int32: the sticky error bits tap_env_check reports (1 overflow, 4 bad block / index, 8 / 16 MACS)
+ * every output is nullable; positions_out (B, n, D) / stable_out (B, n) are indexed by tour position (entries of
+ * the other container stay 0). */
+int tap_episode_scores(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const float *static_,
+                       int static_rows, int nR, const int64_t *tour, int target_sel, double *ratio64_out,
+                       int64_t *scores_out, int32_t *positions_out, uint8_t *stable_out, int32_t *err_out,
+                       void *stream);
+
 /* ---- instance generation (generate.py:773-971) ---------------------------------------- */
 
 /* tools.calc_positions_lb_greedy (tools.py:2393-2449) for B explicit block lists: blocks (B, n, D)
  * int32 in placement order, one launch.  This is what generate.generate_blocks calls with
  * 'C+P+S-lb-hard' on the initial container (generate.py:908); an instance is accepted when every
- * stable_out flag is 1 (generate.py:909-910).  reward_out (B,) f32 = -(C+P+S), positions_out
+ * stable_out flag is 1 (generate.py:909-910).  With strategy TAP_MACS: tools.calc_positions_mcs
+ * (tools.py:3213-3315).  reward_out (B,) f32 = -(C+P+S), positions_out
  * (B, n, D) i32, stable_out (B, n) u8, score64_out (B,) f64 = C+P+S -- each nullable.
  * A block with a side < 1 is not part of its list (lists of different length in one batch: the
  * two-container reward of pack.py:451-466 packs the blocks of each target id separately); S is

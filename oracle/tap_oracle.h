@@ -125,6 +125,19 @@ int orc_calc_positions_lb_greedy(const orc_desc *d, int n, const int32_t *blocks
                                  int32_t *positions, uint8_t *stable, double *ratio,
                                  int64_t scores[5]);
 
+/* tools.calc_positions_mcs (tools.py:3213-3315): one episode with the MACS / MUL per-block function; `ratio` by
+ * the reward type (d->ratio_mode, un-normalised), scores as above. */
+int orc_calc_positions_mcs(const orc_desc *d, int n, const int32_t *blocks, int32_t *positions,
+                           uint8_t *stable, double *ratio, int64_t scores[5]);
+
+/* the figures pack.render (pack.py:670-807) writes per sample: ratio_out (B,), scores_out (B,5) fp64 =
+ * valid_size, box_size, empty_size, stable_num, packing_height.  mul != 0: the two-container input types
+ * (pack.py:754-790): each target id's blocks into its own container described by d_mul (3D: height =
+ * initial_container_height, pack.py:720), all six figures averaged.  Returns the number of samples with an error. */
+int orc_render_scores(const orc_desc *d, const orc_desc *d_mul, int B, int n, int nR, int static_rows,
+                      const float *static_, const int64_t *tour, int mul, double *ratio_out,
+                      double *scores_out, int32_t *errs);
+
 /* pack.reward (pack.py:378-473): gather blocks by tour, full episode per env, -(C+P+S) as fp32.
  * static_ (B, static_rows, nR) fp32; tour (B, n) int64; reward_out (B,) fp32. */
 int orc_reward(const orc_desc *d, int B, int n, int nR, int static_rows, const float *static_,

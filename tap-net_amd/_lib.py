@@ -59,6 +59,7 @@ _PROTOS = {
     "tap_stable3d_eval": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "tap_env_check": (_i, [_vp, C.POINTER(EnvDesc), _vp, C.POINTER(C.c_int32), _vp]),
     "tap_episode_reward": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "tap_episode_scores": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_pack_blocks": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_precedence": (_i, [_vp, _i, _i, _i, C.POINTER(C.c_int32), _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_ppsg_gt": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, C.c_uint64, _vp, C.c_int64, _i, C.c_int64, _vp, _vp, _vp, _vp]),

@@ -1,5 +1,5 @@
 // env.hip -- tools.Container for B containers in lock-step: context, descriptor, reset, step,
-// feature, ratio, export, check, and the whole-episode reward kernel.  gfx950 only.
+// feature, ratio, export, check (the whole-episode kernels are episode.hip).  gfx950 only.
 #include "tap_common.h"
 #include "tap_place.h"
 #include "tap_waves.h"
@@ -248,21 +248,6 @@ template <int D, int G> static int launch_step(tap_ctx *ctx, const StepArgs &a, 
     return TAP_OK;
 }
 
-#define TAP_DISPATCH_DG(fn, d, ...)                                                          \
-    do {                                                                                     \
-        const int G_ = tap_group_size(d);                                                    \
-        if ((d)->D == 2) {                                                                   \
-            if (G_ == 8) return fn<2, 8>(__VA_ARGS__);                                       \
-            if (G_ == 16) return fn<2, 16>(__VA_ARGS__);                                     \
-            if (G_ == 32) return fn<2, 32>(__VA_ARGS__);                                     \
-            return fn<2, 64>(__VA_ARGS__);                                                   \
-        } else {                                                                             \
-            if (G_ == 8) return fn<3, 8>(__VA_ARGS__);                                       \
-            if (G_ == 16) return fn<3, 16>(__VA_ARGS__);                                     \
-            if (G_ == 32) return fn<3, 32>(__VA_ARGS__);                                     \
-            return fn<3, 64>(__VA_ARGS__);                                                   \
-        }                                                                                    \
-    } while (0)
 
 int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st); // macs.hip
 int tap_lb_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st); // lb.hip
@@ -471,119 +456,4 @@ extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *st
     if (bits & 8) return tap_fail(ctx, TAP_E_OVERFLOW, "%d container(s) reached a state in which the reference's MACS code raises (tools.py:2550 IndexError / :2865 UnboundLocalError)", bad);
     if (bits & 16) return tap_fail(ctx, TAP_E_UNSUPPORTED, "%d container(s) exceeded the MACS candidate-list capacity", bad);
     return TAP_OK;
-}
-
-// =============================================================================================
-// K6: whole episode per env in one launch -- pack.reward / tools.calc_positions_lb_greedy
-// =============================================================================================
-
-struct EpisodeArgs {
-    tap_env_desc d;
-    int B, n;
-    const float *static_;
-    int static_rows, nR;
-    const int64_t *tour;
-    const int32_t *blocks; // (B, n, D) explicit block lists when static_ is null (tap_pack_blocks)
-    const uint32_t *lut;
-    float *reward_out;
-    int32_t *pos_out;
-    uint8_t *stable_out;
-    double *score64_out; // C+P+S as fp64, 0 for an empty list (pack.py:462-470 averages two of them)
-};
-
-template <int D, int G>
-__global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
-{
-    __shared__ int s[TAP_BLOCK];
-    const int tid = threadIdx.x, grp = tid / G, cell = tid % G;
-    const int env = blockIdx.x * (TAP_BLOCK / G) + grp;
-    const int W = a.d.W, L = a.d.L, n = a.n;
-    const bool ev = env < a.B, incell = cell < W * L;
-    const PlaceCfg cfg = {W, L, a.d.H, a.d.flags, a.lut};
-    int hm = 0, err = 0;
-    Counters cnt = {0, 0, 0, 0};
-    for (int t = 0; t < n; ++t) {
-        int dims[3] = {1, 1, 1};
-        if (ev && a.static_) { // pack.py:441-444 gather by tour, :454-455 rows 1..D, tools.py:2415 astype('int')
-            bool badp;
-            const long p = tap_col((long)a.tour[(size_t)env * n + t], a.nR, badp);
-            if (badp) err |= 4;                                   // the reference's gather raises
-            for (int k = 0; k < D; ++k) {
-                const float v = a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
-                dims[k] = badp ? 0 : (int)v;
-            }
-        } else if (ev) {
-            for (int k = 0; k < D; ++k) dims[k] = a.blocks[((size_t)env * n + t) * D + k];
-        }
-        const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
-        const bool ok = ev && bx >= 1 && by >= 1 && bz >= 1;
-        s[tid] = hm;
-        __syncthreads();
-        const Placement pl = tap_place<D, G>(cfg, s + grp * G, cell, hm, cnt, err, bx, by, bz, ok);
-        __syncthreads();
-        if (ev && cell == 0) {
-            if (a.pos_out) {
-                int32_t *pp = a.pos_out + ((size_t)env * n + t) * D;
-                pp[0] = pl.x;
-                if (D == 3) { pp[1] = pl.y; pp[2] = pl.z; } else pp[1] = pl.z;
-            }
-            if (a.stable_out) a.stable_out[(size_t)env * n + t] = (uint8_t)pl.stab;
-        }
-    }
-    const int gmax = group_max<G>(incell ? hm : 0);
-    err = group_or<G>(err);
-    if (ev && cell == 0) {
-        // tools.py:2434-2445: un-normalised C + P + S, S over blocks_num; pack.py:471-473 fp32, negated
-        const long long box = (long long)gmax * W * L;
-        const double C = (double)cnt.valid / (double)box;
-        const double P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
-        // S over blocks_num = len(blocks) (tools.py:2440): entries with a side < 1 are not part of the
-        // list (pack.py:455-457 filters by target id; the host marks the other container's blocks so)
-        const double S = (double)cnt.nstable / (double)cnt.count;
-        const double score = cnt.count ? (C + P) + S : 0.0;                          // pack.py:459-466
-        // the reference raises on a height overflow; here the reward becomes NaN
-        if (a.reward_out) a.reward_out[env] = err ? __int_as_float(0x7fc00000) : -(float)score;
-        if (a.score64_out) a.score64_out[env] = err ? __longlong_as_double(0x7ff8000000000000ll) : score;
-    }
-}
-
-template <int D, int G> static int launch_episode(tap_ctx *ctx, const EpisodeArgs &a, hipStream_t st)
-{
-    const int epb = TAP_BLOCK / G, grid = (a.B + epb - 1) / epb;
-    if (grid == 0) return TAP_OK;
-    hipLaunchKernelGGL((k_episode<D, G>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
-    TAP_LAUNCH_CHECK(ctx, "k_episode");
-    return TAP_OK;
-}
-
-extern "C" int tap_episode_reward(tap_ctx *ctx, const tap_env_desc *d, int B, int n,
-                                  const float *static_, int static_rows, int nR,
-                                  const int64_t *tour, float *reward_out, int32_t *positions_out,
-                                  uint8_t *stable_out, void *stream)
-{
-    int rc = tap_desc_validate(ctx, d);
-    if (rc) return rc;
-    if (B == 0) return TAP_OK; // an empty batch has no buffers to check (d->B is ignored here)
-    if (d->strategy != TAP_LB_GREEDY)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: the reference only defines LB_GREEDY here (pack.py:431 names a missing function)");
-    if (tap_is_big(d))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "episode reward: containers above 64 cells are stepped with tap_env_step_gather");
-    if (!static_ || !tour || !reward_out || B < 0 || n < 1 || static_rows < 1 + d->D || nR < 1)
-        return tap_fail(ctx, TAP_E_INVALID, "bad episode arguments");
-    EpisodeArgs a = {*d, B, n, static_, static_rows, nR, tour, nullptr, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, nullptr};
-    TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
-}
-
-extern "C" int tap_pack_blocks(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const int32_t *blocks,
-                               float *reward_out, int32_t *positions_out, uint8_t *stable_out,
-                               double *score64_out, void *stream)
-{
-    int rc = tap_desc_validate(ctx, d);
-    if (rc) return rc;
-    if (B == 0) return TAP_OK; // an empty batch has no buffers to check (d->B is ignored here)
-    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "pack_blocks: LB_GREEDY on containers of at most 64 cells");
-    if (!blocks || B < 0 || n < 1) return tap_fail(ctx, TAP_E_INVALID, "bad pack_blocks arguments");
-    EpisodeArgs a = {*d, B, n, nullptr, 0, 0, nullptr, blocks, ctx ? ctx->stab_lut : nullptr, reward_out, positions_out, stable_out, score64_out};
-    TAP_DISPATCH_DG(launch_episode, d, ctx, a, (hipStream_t)stream);
 }

@@ -142,3 +142,20 @@ inline int tap_group_size(const tap_env_desc *d)
 }
 int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st);                                      // big.hip
 int tap_big_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, int flen, hipStream_t st);   // big.hip
+
+// dispatch on (D, lanes per container) for the lane-per-cell kernels
+#define TAP_DISPATCH_DG(fn, d, ...)                                                          \
+    do {                                                                                     \
+        const int G_ = tap_group_size(d);                                                    \
+        if ((d)->D == 2) {                                                                   \
+            if (G_ == 8) return fn<2, 8>(__VA_ARGS__);                                       \
+            if (G_ == 16) return fn<2, 16>(__VA_ARGS__);                                     \
+            if (G_ == 32) return fn<2, 32>(__VA_ARGS__);                                     \
+            return fn<2, 64>(__VA_ARGS__);                                                   \
+        } else {                                                                             \
+            if (G_ == 8) return fn<3, 8>(__VA_ARGS__);                                       \
+            if (G_ == 16) return fn<3, 16>(__VA_ARGS__);                                     \
+            if (G_ == 32) return fn<3, 32>(__VA_ARGS__);                                     \
+            return fn<3, 64>(__VA_ARGS__);                                                   \
+        }                                                                                    \
+    } while (0)

@@ -402,6 +402,14 @@ class EnvTransition(MaskStepper):
         import ctypes as C
         ptr = ptr.to(device=self.dynamic.device, dtype=torch.int64).contiguous()
         self._check_step_args(ptr, dyn_out)
+        if not self.env.fused_ok:
+            # strategies / shapes without a fused step (legacy 'LB', LB_GREEDY above 64 cells or a 3D side above 8,
+            # MACS 2D above 16 columns): the same step as two launches
+            if fresh:
+                self.env.reset()
+            out, cur, new = MaskStepper.step(self, ptr, dyn_out)
+            feat = self.env.add_new_blocks_gather(self.static, ptr, want_feature=want_feature)
+            return out, cur, new, feat, (self.env.calc_ratios() if want_ratio else None)
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
@@ -509,6 +517,135 @@ def reward(static, tour_indices, reward_type, input_type, allow_rot, container_w
                                                  _lib.ptr(tour), _lib.ptr(out), None, None,
                                                  _lib.stream_of(st.device)), c)
     return out
+
+
+# ---- pack.render (pack.py:670-977): the metric files of a test run ---------------------------------------------
+
+_LBG_RATIO_TYPES = ('C+P-lb-soft', 'C+P-lb-hard', 'C+P+S-lb-soft', 'C+P+S-lb-hard')                # tools.py:2442-2445
+_MCS_RATIO_TYPES = ('comp', 'soft', 'hard', 'pyrm', 'pyrm-soft', 'pyrm-hard', 'mcs-soft', 'mcs-hard',  # tools.py:3285-3306
+                    'pyrm-soft-sum', 'pyrm-soft-SUM', 'pyrm-hard-sum', 'pyrm-hard-SUM', 'CPS',
+                    'C+P-mul-soft', 'C+P-mul-hard', 'C+P-mcs-soft', 'C+P-mcs-hard',
+                    'C+P+S-mul-soft', 'C+P+S-mul-hard', 'C+P+S-mcs-soft', 'C+P+S-mcs-hard')
+_NET_REWARD_TYPES = ('C+P+S-SL-soft', 'C+P+S-RL-soft', 'C+P+S-G-soft', 'C+P+S-LG-soft')             # pack.py:728-730
+RENDER_FILES = ('ratio', 'valid_size', 'box_size', 'empty_size', 'stable_num', 'packing_height', 'time', 'ids')
+
+
+def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target):
+    """The whole-episode figures for shapes the one-launch kernels do not take (LB_GREEDY above 64 cells): the same
+    episode as n placement launches on a state blob, ``active`` selecting one container's blocks."""
+    from .env import BatchedContainer
+    B = st.shape[0]
+    env = BatchedContainer(B, container_size, n, reward_type, 'full', packing_strategy=strategy, device=st.device)
+    for t in range(n):
+        col = tour[:, t].contiguous()
+        act = None
+        if target is not None:
+            act = torch.gather(st[:, -1, :], 1, col.unsqueeze(1)).squeeze(1) == float(target)
+        env.add_new_blocks_gather(st, col, active=act, want_feature=False)
+    env.check()
+    cnt = env.counters.to(torch.int64)
+    max_h = env.heightmap.reshape(B, -1).max(dim=1).values.to(torch.int64)
+    box = max_h * int(np.prod(container_size[:-1]))
+    valid, empty, nst, count = (cnt[:, k] for k in range(4))
+    C = valid.double() / box.double()
+    P = valid.double() / (empty + valid).double()
+    S = nst.double() / count.double()
+    live = count > 0
+    ratio = torch.where(live, (C + P) + S, torch.zeros_like(C))
+    scores = torch.stack((valid, torch.where(live, box, torch.zeros_like(box)), empty, nst, max_h), 1)
+    return ratio, scores
+
+
+def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, container_size, packing_strategy='LB_GREEDY',
+                   target=None, check=True):
+    """tools.calc_positions_lb_greedy (tools.py:2393-2449) / tools.calc_positions_mcs (tools.py:3213-3315) for
+    every sample of a batch in one launch: blocks in tour order into an empty container.
+    -> (ratio (B,) float64, scores (B, 5) int64 = valid_size, box_size, empty_size, stable_num, max height).
+    ``target`` 0 | 1: only the blocks whose target id (last row of ``static``, the two-container input types) equals
+    it; an empty list scores zeros (pack.py:760-769).  ``check``: raise like the reference when a container
+    overflowed (one host read of the error words)."""
+    import ctypes as C
+    block_dim = _block_dim(static, input_type)
+    R = _rotate_types(block_dim, allow_rot)
+    st = _f32c(static)
+    B, rows, nR = st.shape
+    n = nR // R
+    tour = tour_indices.to(device=st.device, dtype=torch.int64)
+    if tour.shape[1] < n:
+        raise ValueError("tour shorter than blocks_num")
+    tour = tour[:, :n].contiguous()                                                # pack.py:693 [:,:,:blocks_num]
+    mcs = packing_strategy in ('MACS', 'MUL')
+    if reward_type not in (_MCS_RATIO_TYPES if mcs else _LBG_RATIO_TYPES):
+        # tools.py:2446 / :3308 print 'Unknown reward type' and fall into `return ... ratio` with ratio unbound
+        raise UnboundLocalError("local variable 'ratio' referenced before assignment (reward_type %r is not one %s "
+                                "scores)" % (reward_type, 'calc_positions_mcs' if mcs else 'calc_positions_lb_greedy'))
+    strategy = 'MACS' if mcs else 'LB_GREEDY'
+    desc = _lib.make_desc(B, container_size, n, reward_type, 'full', strategy)
+    if (not mcs) and (desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))):
+        return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target)
+    ratio = torch.empty(B, dtype=torch.float64, device=st.device)
+    scores = torch.empty(B, 5, dtype=torch.int64, device=st.device)
+    err = torch.empty(B, dtype=torch.int32, device=st.device)
+    c = _lib.ctx(st.device)
+    with torch.cuda.device(st.device):
+        _lib.check(_lib.lib().tap_episode_scores(c, C.byref(desc), B, n, _lib.ptr(st), rows, nR, _lib.ptr(tour),
+                                                 -1 if target is None else int(target), _lib.ptr(ratio), _lib.ptr(scores),
+                                                 None, None, _lib.ptr(err), _lib.stream_of(st.device)), c)
+    if check:
+        bits = int(torch.bitwise_or(err, 0).max().item()) if B else 0
+        if bits:
+            bad = int((err != 0).sum().item())
+            if int((err & 1).max().item()):
+                raise _lib.TapOverflowError(_lib.TAP_E_OVERFLOW, "%d container(s) exceeded height H=%d" % (bad, desc.H))
+            raise _lib.TapError(_lib.TAP_E_INVALID, "%d container(s) raised error bits 0x%x (tapenv.h: tap_env_check)" % (bad, int(err.max().item())))
+    return ratio, scores
+
+
+def render(static, tour_indices, save_path, dynamic, valid_time, **kwargs):
+    """pack.render (pack.py:670-977), the ``render_fn`` of a test run (trainer.py:493, called by validate,
+    trainer.py:132): re-pack every sample in tour order with the whole-episode function of the packing strategy
+    (pack.py:726-734, 792) and write the eight metric files next to ``save_path`` (pack.py:967-977; the drawing
+    code of the reference is commented out, its only other effect is an empty matplotlib figure per sample).  One
+    launch per container list instead of a Python loop over samples; the two-container input types pack the blocks of
+    each target id into their own container and average the six figures (pack.py:754-776).  Values and file bytes
+    equal the reference's (np.savetxt of float64).  ``dynamic`` is unused, as in the reference."""
+    input_type = kwargs['input_type']
+    if input_type not in _UPDATE_ROWS:
+        print('Render OHHHH')                                                       # pack.py:688 (then NameError)
+        raise NameError("name 'block_dim' is not defined")
+    block_dim = _block_dim(static, input_type)
+    mul = input_type in ('mul', 'mul-with')
+    unit = kwargs['unit']
+    container_width = int(np.ceil(kwargs['container_width'] * unit))                # pack.py:703-711
+    container_height = int(np.ceil(kwargs['container_height'] * unit))
+    initial_container_height = int(np.ceil(kwargs['initial_container_height'] * unit))
+    if block_dim == 3:
+        container_size = [container_width, container_width, container_height]
+        container_size_ab = [container_width, container_width, initial_container_height]   # pack.py:718-721 (sic)
+    else:
+        container_size = [container_width, container_height]
+        container_size_ab = [container_width, container_height]
+    strategy = kwargs['packing_strategy']
+    reward_type = kwargs['reward_type']
+    if strategy not in ('MACS', 'MUL') and reward_type in _NET_REWARD_TYPES:
+        raise NotImplementedError("tools.calc_positions_net (the pack-net back-ends) is outside this package")
+    args = (static, tour_indices, reward_type, input_type, kwargs['allow_rot'])
+    if mul:
+        ra, sa = episode_scores(*args, container_size_ab, strategy, target=0)
+        rb, sb = episode_scores(*args, container_size_ab, strategy, target=1)
+        ratio = (ra + rb) / 2                                                       # pack.py:771-776
+        scores = (sa.double() + sb.double()) / 2
+    else:
+        ratio, scores = episode_scores(*args, container_size, strategy)
+        scores = scores.double()
+    ratio = ratio.cpu().numpy()
+    scores = scores.cpu().numpy()
+    stem = save_path[:-13]                                                          # pack.py:967 (sic)
+    np.savetxt(stem + '-ratio.txt', ratio)
+    for k, name in enumerate(('valid_size', 'box_size', 'empty_size', 'stable_num', 'packing_height')):
+        np.savetxt(stem + '-%s.txt' % name, scores[:, k])
+    np.savetxt(stem + '-time.txt', np.array([valid_time]))
+    np.savetxt(stem + '-ids.txt', tour_indices.cpu().numpy())
 
 
 class PACKDataset(Dataset):

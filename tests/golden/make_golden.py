@@ -16,6 +16,7 @@ Fixtures:
   reward_tour.npz                    pack.reward on those tours
   kat.npz                            hand-checkable known answers
   rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
+  render.npz                         pack.render's eight metric files (LB_GREEDY / MACS / MUL, 2D / 3D, two-container types)
   ppsg3d.npz                         generate.BPP_Generator_3D / generate_blocks_with_GT (3D) under recorded seeds
   ppsg2d.npz                         generate.BPP_Generator_2D_easy / generate_blocks_with_GT (2D) under recorded seeds
   ppsg_2d.npz                        (--only ppsg) 64 instances of the reference's PPSG generator + MACS traces over them
@@ -476,6 +477,45 @@ def make_reward_tour(pack, tours, statics):
     save("reward_tour.npz", **out)
 
 
+RENDER_SUFFIXES = ("ratio", "valid_size", "box_size", "empty_size", "stable_num", "packing_height", "time", "ids")
+
+
+def make_render(pack):
+    """pack.render (pack.py:670-807) -- what every `--task=test` run calls through validate (trainer.py:132, 493):
+    the eight metric files it writes, for the committed data sets and the pretrained actors' tours, over
+    LB_GREEDY / MACS / MUL, 2D and 3D, and the two-container input types.  Stored: the files' text."""
+    import torch
+    out, meta = {}, []
+    rs = np.random.RandomState(77)
+    for D in (2, 3):
+        static = torch.from_numpy(np.load(os.path.join(HERE, "dataset_%dd.npz" % D))["static"].astype(np.float32))
+        tour = torch.from_numpy(np.load(os.path.join(HERE, "episode_%dd.npz" % D))["tour_idx"].astype(np.int64))
+        B, n = tour.shape
+        ids = torch.from_numpy(rs.randint(0, 2, size=(B, 1, n)).astype(np.float32)).repeat(1, 1, static.shape[2] // n)
+        ids[0] = 0.0                                   # one sample with an empty second container (pack.py:765)
+        static_mul = torch.cat((static, ids), 1)
+        out["target_ids_%dd" % D] = ids[:, 0, :n].numpy().astype(np.uint8)
+        cases = [("bot", "LB_GREEDY", "C+P+S-lb-soft", 5, 50, 50), ("bot", "LB_GREEDY", "C+P-lb-hard", 5, 50, 50),
+                 ("bot", "MACS", "C+P+S-mcs-soft", 5, 50, 50), ("bot", "MUL", "C+P+S-mul-hard", 5, 50, 50),
+                 ("bot", "MACS", "mcs-soft", 5, 50, 50), ("bot", "MACS", "C+P-mcs-hard", 6, 60, 60),
+                 ("mul", "LB_GREEDY", "C+P+S-lb-soft", 5, 50, 44), ("mul-with", "MACS", "C+P+S-mcs-soft", 5, 50, 44)]
+        for k, (input_type, strategy, reward, W, H, H0) in enumerate(cases):
+            cnt = B if D == 2 or strategy == "LB_GREEDY" else 24     # the reference's MACS 3D takes seconds per sample
+            st = (static_mul if input_type.startswith("mul") else static)[:cnt]
+            with tempfile.TemporaryDirectory() as tmp:
+                path = os.path.join(tmp, "batch0_-1.2345.png")      # trainer.py:129-130
+                pack.render(st, tour[:cnt], path, None, 0.125 + k, input_type=input_type, allow_rot=True,
+                            container_width=W, container_height=H, initial_container_width=7,
+                            initial_container_height=H0, unit=1.0, packing_strategy=strategy, reward_type=reward)
+                names = sorted(os.listdir(tmp))
+                assert names == sorted("batch-%s.txt" % s for s in RENDER_SUFFIXES), names
+                for suf in RENDER_SUFFIXES:
+                    with open(os.path.join(tmp, "batch-%s.txt" % suf), "rb") as f:
+                        out["c%d_%dd_%s" % (k, D, suf)] = np.frombuffer(f.read(), dtype=np.uint8)
+            meta.append("%d|%d|%s|%s|%s|%d|%d|%d|%d|%g" % (k, D, input_type, strategy, reward, W, H, H0, cnt, 0.125 + k))
+    save("render.npz", meta=np.array(meta), **out)
+
+
 def make_kat(tools):
     """Appendix-G style known answers, incl. calc_positions_lb_greedy's un-normalised ratio."""
     out = {}
@@ -563,6 +603,7 @@ def main():
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)
+    if want("render"): make_render(pack)
     if want("data"):
         with tempfile.TemporaryDirectory() as tmp:
             statics, dynamics, tours = {}, {}, {}

@@ -68,6 +68,9 @@ def lib():
         L.orc_is_stable_3d_mask.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.orc_run_episodes.argtypes = [C.POINTER(Desc), C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.c_int]
         L.orc_calc_positions_lb_greedy.argtypes = [C.POINTER(Desc), C.c_int] + [C.c_void_p] * 5
+        L.orc_calc_positions_mcs.argtypes = [C.POINTER(Desc), C.c_int] + [C.c_void_p] * 5
+        L.orc_render_scores.argtypes = [C.POINTER(Desc), C.POINTER(Desc), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_reward.argtypes = [C.POINTER(Desc), C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_instance_from_blocks.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
@@ -250,6 +253,44 @@ def calc_positions_lb_greedy(blocks, container_size, reward_type):
     rc = lib().orc_calc_positions_lb_greedy(C.byref(desc), n, _p(blocks), _p(pos), _p(st),
                                             C.byref(ratio), _p(scores))
     return rc, pos, st.astype(bool), ratio.value, scores
+
+
+def calc_positions_mcs(blocks, container_size, reward_type):
+    """tools.calc_positions_mcs (tools.py:3213-3315)."""
+    blocks = np.ascontiguousarray(blocks, dtype=np.int32)
+    n, D = blocks.shape
+    desc = make_desc(container_size, n, reward_type, "full", "MACS")
+    pos = np.zeros((n, D), np.int32)
+    st = np.zeros(n, np.uint8)
+    ratio = C.c_double()
+    scores = np.zeros(5, np.int64)
+    rc = lib().orc_calc_positions_mcs(C.byref(desc), n, _p(blocks), _p(pos), _p(st), C.byref(ratio), _p(scores))
+    return rc, pos, st.astype(bool), ratio.value, scores
+
+
+def render_scores(static, tour, reward_type, input_type, allow_rot, container_width, container_height,
+                  packing_strategy, initial_container_height=None):
+    """The per-sample figures pack.render writes (pack.py:670-807): -> (ratio (B,), scores (B,5) fp64, errs)."""
+    static = np.ascontiguousarray(static, dtype=np.float32)
+    tour = np.ascontiguousarray(tour, dtype=np.int64)
+    B, rows, nR = static.shape
+    mul = input_type in ("mul", "mul-with")
+    D = rows - (2 if mul else 1)
+    R = [1, 1, 2, 6][D] if allow_rot else 1
+    n = nR // R
+    tour = np.ascontiguousarray(tour[:, :n])
+    cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+    cs_mul = cs if D == 2 else [container_width, container_width, initial_container_height]   # pack.py:718-724
+    strat = "MACS" if packing_strategy in ("MACS", "MUL") else "LB_GREEDY"
+    desc = make_desc(cs, n, reward_type, "full", strat)
+    desc_mul = make_desc(cs_mul, n, reward_type, "full", strat) if mul else desc
+    ratio = np.zeros(B, np.float64)
+    scores = np.zeros((B, 5), np.float64)
+    errs = np.zeros(B, np.int32)
+    nerr = lib().orc_render_scores(C.byref(desc), C.byref(desc_mul), B, n, nR, rows, _p(static), _p(tour), int(mul),
+                                   _p(ratio), _p(scores), _p(errs))
+    assert nerr >= 0
+    return ratio, scores, errs
 
 
 def reward_mul(static, tour, reward_type, container_width, container_height, R):

@@ -163,6 +163,26 @@ def test_reward_tour():
         assert nerr == 0 and np.array_equal(r, rt["reward_%dd" % D])
 
 
+def test_render_metric_files():
+    """pack.render's eight files (pack.py:967-977) as the reference wrote them: the oracle's whole-episode figures
+    (calc_positions_lb_greedy / calc_positions_mcs, two-container averaging) re-written with np.savetxt are the same
+    bytes."""
+    import io
+    ncases = 0
+    for meta, static, tour, files in G.render_cases():
+        ratio, scores, errs = O.render_scores(static, tour, meta["reward"], meta["input_type"], True, meta["W"], meta["H"],
+                                              meta["strategy"], initial_container_height=meta["H0"])
+        assert not errs.any(), meta
+        cols = dict(ratio=ratio, valid_size=scores[:, 0], box_size=scores[:, 1], empty_size=scores[:, 2],
+                    stable_num=scores[:, 3], packing_height=scores[:, 4], time=np.array([meta["valid_time"]]), ids=tour)
+        for suf, want in files.items():
+            buf = io.BytesIO()
+            np.savetxt(buf, cols[suf])
+            assert buf.getvalue() == want, (meta, suf)
+        ncases += 1
+    assert ncases == 16
+
+
 @pytest.mark.parametrize("D", [2, 3])
 def test_instance_generation_from_reference_datasets(D):
     """generate.generate_blocks + calc_dependent + PACKDataset layout: re-derive positions, static
