@@ -28,6 +28,7 @@ import json
 import os
 import socket
 import sys
+import statistics
 import time
 
 import numpy as np
@@ -56,7 +57,7 @@ def _oracle():
     return oracle_lib
 
 
-HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0    # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md; measured ceilings: load_calibration()
 VERIFY_ENVS = 512        # envs of the last replayed pass compared with the oracle after the timed region
 
 # nodes of one precedence window (rolling.py feeds the actor 10-node sub-graphs)
@@ -93,6 +94,52 @@ def algorithmic_bytes(D, cs, n):
     nR = n * R
     mask = (3 * n * nR * 4 + nR * 4 + 8) + (3 * n * nR * 4 + 2 * nR * 4)
     return env, mask
+
+
+def compulsory_bytes(kind, D, cs, n, bits=True, static_rows=None):
+    """Bytes ONE launch of the implemented kernel must move per env, whatever the cache does:
+    what it reads that it has not produced itself plus what it writes.  This is what roofline.achieved prices;
+    SURVEY's per-env-step figure (which prices an fp32 read of `dynamic` the bit-shadow step never performs) is
+    kept beside it as frac_alg_survey."""
+    cells = int(np.prod(cs[:-1]))
+    R = 2 if D == 2 else 6
+    nR, rows = n * R, 3 * n
+    flen = cs[0] - 1 if D == 2 else 2 * cells
+    # container: hm + 4 counters in and out, position + stable flag out, feature out, the block's D sides in
+    env = 2 * (cells * 4 + 16) + D * 4 + 1 + flen * 4 + D * 4
+    # precedence update on the bit shadow: ptr, row 0 of static (block id), mask in; shadow in + out; fp32 tensor
+    # out; both masks out
+    shadow = 8 + nR * 4 + nR * 4 + 2 * nR * 8 + rows * nR * 4 + 2 * nR * 4
+    copy = 8 + nR * 4 + nR * 4 + 2 * 3 * nR * 4 + 2 * rows * nR * 4 + 2 * nR * 4     # column-sum shadow in + out, tensor in + out
+    if kind == "mask_step":
+        return shadow if bits else copy
+    if kind == "env_step":
+        return env
+    if kind == "transition":
+        return env + (shadow if bits else copy)
+    if kind == "transition_first":                  # reads the fresh fp32 tensor once, no shadow in
+        return env + shadow - nR * 8 + rows * nR * 4
+    if kind == "dyn_bits":
+        return rows * nR * 4 + nR * 8
+    if kind in ("rolling_window", "rolling_step"):
+        # in: the window nodes' five relation masks and block sides, the 2-word window state (in + out), ptr;
+        # out: static (1+D, nR), dynamic (3 child, nR), its shadow, the initial mask, the node ids
+        win = n * 5 * 8 + n * D * 4 + 2 * 16 + 8 + (1 + D) * nR * 4 + rows * nR * 4 + nR * 8 + nR * 4 + n * 4
+        return win + (env if kind == "rolling_step" else 0)
+    raise KeyError(kind)
+
+
+def load_calibration():
+    """Measured ceilings of this part (scripts/calibrate_bw.py, the hot kernels' access shape), newest profile set."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bw_calibration.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        c = json.load(f)
+    c.pop("rows", None)
+    c["source"] = "profiles/" + os.path.basename(files[-1])
+    return c
 
 
 def episode_bytes(D, n):
@@ -504,7 +551,7 @@ def passes_per_graph(hp):
     return GATHER_EVERY if t >= 400e-6 else 2 * GATHER_EVERY if t >= 200e-6 else 4 * GATHER_EVERY if t >= 100e-6 else 8 * GATHER_EVERY
 
 
-def time_passes(hps, steps, warmup, use_graph, world):
+def time_passes(hps, steps, warmup, use_graph, world, repeats=1):
     """Time `steps` passes, pass i on slot i % len(hps) (one slot = the headline; several = the cold variant)."""
     if not isinstance(hps, (list, tuple)):
         hps = [hps]
@@ -605,16 +652,34 @@ def time_passes(hps, steps, warmup, use_graph, world):
                 else:
                     hps[k].episode()
 
+    first_gather_ms = None
+    if gather:
+        # RCCL sets its rings up lazily inside the first collective: pay (and report) that before the warm-up,
+        # never inside the timed bracket
+        torch.cuda.synchronize(dev)
+        tg = time.perf_counter()
+        flush(1)
+        torch.cuda.synchronize(dev)
+        first_gather_ms = (time.perf_counter() - tg) * 1e3
+    hp.first_gather_ms = first_gather_ms
     run(warmup)
     drain()
-    tdist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    run(steps)
-    drain()
-    torch.cuda.synchronize(dev)
-    tdist.barrier()
-    dt = time.perf_counter() - t0
+    dts, local_dts = [], []
+    for _ in range(max(1, repeats)):
+        # one bracket = EXACTLY `steps` passes between barrier + synchronize on both sides, MAX over ranks
+        tdist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(steps)
+        drain()
+        torch.cuda.synchronize(dev)
+        tdist.barrier()
+        local_dt = time.perf_counter() - t0
+        local_dts.append(local_dt)
+        dts.append(tdist.max_over_ranks(local_dt, dev))
+    hp.bracket_times = dts
+    hp.local_bracket_times = local_dts
+    dt = statistics.median(dts)
     if gather and last_gather:
         r, c = tdd.get_rank(), last_gather["count"]
         mine = last_gather["out"][r * c:(r + 1) * c]
@@ -626,7 +691,7 @@ def time_passes(hps, steps, warmup, use_graph, world):
         written = [j for j in range(ge) if j < min(steps, ge)]
         same = all(bool(torch.equal(torch.nan_to_num(acc[j], nan=-7.0), torch.nan_to_num(acc[0], nan=-7.0))) for j in written)
         hp.passes_identical = dict(passes_compared=len(written), identical=same)
-    return tdist.max_over_ranks(dt, dev), graphs
+    return dt, graphs
 
 
 def kernel_event_times(hp, steps, graph=None):
@@ -1105,7 +1170,9 @@ def run_sweep(cfg, hp, dev, use_graph, path):
             h2.env.check()
             rec = dict(config=name.split(" on ")[0], batch=b, env_steps_per_s=b * n * steps / d2,
                        pass_us=pass_us, step_us=pass_us / n,
-                       alg_GBps=(env_b + mask_b) * b / (pass_us / n * 1e-6) / 1e9,
+                       GBps=compulsory_bytes("transition", D, cs, hp.nw, bits=bool(h2.bits)) * b / (pass_us / n * 1e-6) / 1e9,
+                       GBps_how="compulsory bytes of the implemented step (compulsory_bytes) / step_us",
+                       speed_vs_fp32_copy_GBps=(env_b + mask_b) * b / (pass_us / n * 1e-6) / 1e9,
                        dynamic_MB=round(h2.dynamic0[0].numel() * 4 / 1e6, 1), bits=bool(h2.bits))
             lines.append(rec)
             print("sweep " + json.dumps(rec), file=sys.stderr)
@@ -1144,6 +1211,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed brackets of exactly --steps passes each (barrier + synchronize on both sides, MAX over "
+                         "ranks); value is their median, the line carries all of them")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -1189,6 +1259,10 @@ def main():
         sys.exit(2)
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: libtapenv has no CPU path")
+    shared_gpu = os.environ.get("TAP_DIST_BACKEND") == "gloo"
+    if torch.cuda.device_count() < min(args.gpus, int(os.environ.get("LOCAL_WORLD_SIZE", args.gpus))) and not shared_gpu:
+        # one process per GPU: fail loudly instead of quietly stacking ranks on a device
+        sys.exit("bench.py rank %d: --gpus %d but this process sees %d GPU(s)" % (rank, args.gpus, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()   # > 1 rank per GPU only happens in the gloo self-test
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -1224,10 +1298,18 @@ def main():
         hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits,
                      instances=instances)
     use_graph = not args.no_graph
-    dt, graphs = time_passes(hp, args.steps, args.warmup, use_graph, world)
+    dt, graphs = time_passes(hp, args.steps, args.warmup, use_graph, world, repeats=args.repeats)
     hp.env.check()
     total_steps = B * world * n * args.steps
     value = total_steps / dt
+    # who ran where, and how fast each rank was on its own clock (the job's figure is the MAX over ranks)
+    mine = dict(rank=rank, device_index=local, device=torch.cuda.get_device_name(local), pid=os.getpid(),
+                value=B * n * args.steps / statistics.median(hp.local_bracket_times))
+    per_rank = [mine]
+    if world > 1:
+        import torch.distributed as dist
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     # every rank checks its own last pass against the oracle; the line says "verified" only if all did
     ver = dict(verified=None, why="--no-verify") if args.no_verify else hp.verify()
     if getattr(hp, "gathered_ok", None) is not None and not args.no_verify:
@@ -1278,26 +1360,46 @@ def main():
             dom_us = kt[dom]["med_us"]
             how = ("median event-bracketed launch, uncorrected: reads about 2 us longer than the kernel (an empty event pair "
                    "takes %.1f us, but most of that overlaps a kernel placed between the two records)" % empty_us)
-        ach = per_launch[dom] / (dom_us * 1e-6) / 1e9
+        bits_on = bool(getattr(hp, "bits", True)) or rolling
+        comp = {k: compulsory_bytes(k, D, cs, hp.nw, bits=bits_on) * B
+                for k in ("env_step", "mask_step", "transition", "transition_first", "rolling_window", "rolling_step", "dyn_bits")}
+        comp["episode"] = per_launch["episode"]
+        ach = comp[dom] / (dom_us * 1e-6) / 1e9
+        ach_survey = per_launch[dom] / (dom_us * 1e-6) / 1e9
+        cal = load_calibration()
         kernels = {}
         for k in names:
             kernels[k] = dict(med_us_event_pair=round(kt[k]["med_us"], 3), avg_us_event_pair=round(kt[k]["avg_us"], 3),
                               launches_per_pass=kt[k]["launches"] // npass)
             if "run_us" in kt[k]:
                 kernels[k]["us_per_launch_in_runs"] = round(kt[k]["run_us"], 3)
+            if k in comp:
+                kernels[k]["bytes_per_launch"] = comp[k]
             if k in per_launch:
-                kernels[k]["alg_bytes_per_launch"] = per_launch[k]
+                kernels[k]["alg_bytes_per_launch_survey"] = per_launch[k]
         tkey = args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")
         tr = load_traffic(tkey)
         traffic = tr["bytes"] if tr else None
+        # write-dominated kernels are held against the measured fill rate, the first-step / copy forms against the copy
+        ceiling_kind = "copy" if (dom == "transition_first" or (dom in ("transition", "mask_step") and not bits_on)) else "fill"
+        ceiling = (cal or {}).get("%s_GBps_beyond_cache" % ceiling_kind)
         roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS, "frac_alg": ach / HBM_PEAK_GBS,
+                "frac": ach / HBM_PEAK_GBS,
+                "bytes_per_launch": comp[dom],
+                "bytes_how": "compulsory bytes of the implemented kernel (inputs it did not produce + outputs; the bit-shadow "
+                             "step writes the fp32 tensor and never reads it) x envs per launch",
+                "frac_alg_survey": ach_survey / HBM_PEAK_GBS,
+                "frac_alg_survey_how": "SURVEY 8(d)'s per-env-step figure (prices an fp32 read AND write of dynamic) / kernel_us / "
+                                       "peak: speed relative to a perfect fp32 copy, NOT a bandwidth fraction",
                 "frac_hbm": (traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "peak_measured": dict(GBps=ceiling, kind=ceiling_kind + " beyond the Infinity Cache, 16 B per lane",
+                                      frac=(ach / ceiling) if ceiling else None,
+                                      source=(cal or {}).get("source")) if cal else None,
                 "traffic": traffic,
                 "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profile set %s "
                                    "(profiles/%s_%s_pmc_summary.csv); not re-measured in this run"
                                    % (tr["profile"], tr["profile"].split()[0], args.config)) if tr else None,
-                "alg_bytes_per_env_step": per_launch[dom] // B, "units_per_launch": B,
+                "bytes_per_env_step": comp[dom] // B, "alg_bytes_per_env_step_survey": per_launch[dom] // B, "units_per_launch": B,
                 "kernel_us": dom_us, "kernel_us_how": how, "kernel_us_rocprof": tr.get("kernel_us") if tr else None,
                 "pass_us": pass_us, "launches_per_pass": launches, "event_pair_overhead_us": empty_us}
         if rolling:
@@ -1343,10 +1445,16 @@ def main():
             "data": "synthetic",
             "verified": bool(ver.get("verified")) and ok_all if ver.get("verified") is not None else None,
             "verification": ver,
+            "repeats": dict(brackets=len(hp.bracket_times), steps_per_bracket=args.steps, statistic="median",
+                            values=[total_steps / t for t in hp.bracket_times],
+                            min=total_steps / max(hp.bracket_times), max=total_steps / min(hp.bracket_times),
+                            spread=(max(hp.bracket_times) - min(hp.bracket_times)) / dt),
             "ranks": dict(world_size=world, backend=(torch.distributed.get_backend() if world > 1 else None),
                           rccl_ranks=(torch.distributed.get_world_size() if world > 1 and
                                       torch.distributed.get_backend() == "nccl" else (1 if world == 1 else 0)),
-                          spawned_by_bench=os.environ.get("TAP_BENCH_SPAWNED") == "1"),
+                          spawned_by_bench=os.environ.get("TAP_BENCH_SPAWNED") == "1",
+                          first_all_gather_ms=getattr(hp, "first_gather_ms", None),
+                          per_rank=per_rank),
             "config": {"workload": name, "batch_per_gpu": B, "nodes": n, "window_nodes": hp.nw, "container": cs,
                        "reward_type": reward, "packing_strategy": strategy, "instances": inst, "pass": pas,
                        "launch": ("hipGraph replay, %d passes per graph launch" % getattr(hp, "passes_per_graph", GATHER_EVERY)) if use_graph else "eager"},

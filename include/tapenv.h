@@ -402,6 +402,14 @@ int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *state, int n
                          float *dyn_out, float *current_out, float *mask_out, float *feature_out,
                          float *ratio_out, int32_t *nonbinary_out, int flags, void *stream);
 
+/* ---- measurement support ------------------------------------------------------------------ */
+
+/* Bandwidth calibration in the hot kernels' own access shape (16 bytes per lane, a wavefront covers 1 KiB): SURVEY
+ * 8(d) asks for the HBM peak to be confirmed on the box.  kind 0: dst = src (plain stores), 1: the same with
+ * nontemporal stores, 2: fill dst (plain), 3: fill dst (nontemporal), 4: read src only.  bytes % 16 == 0, 16-byte
+ * aligned buffers.  scripts/calibrate_bw.py times these; nothing on the hot path calls them. */
+int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, size_t bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

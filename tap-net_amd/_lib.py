@@ -85,6 +85,7 @@ _PROTOS = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tap_transition_bits": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "tap_bw_probe": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
 }
 EXPORTS = tuple(_PROTOS)
 
