@@ -257,7 +257,13 @@ __device__ inline void pyset_order_wave(const unsigned char *keys, int n, unsign
 }
 
 // ---- one window step: remove, top up, cut sub-graphs, emit tensors ----------------------------------
-struct RollLds {          // one wavefront's scratch: 4.8 KB, so that 8 workgroups (all 32 waves a CU
+struct RollFastLds {      // the compile-time-shaped emission (rolling_emit_fast)
+    unsigned iw[64];       // lane (k, cm): relation k of sub-graph column cm as a word over sub-graph rows
+    unsigned cw32[64];     // dynamic's column words (3*CH <= 32 rows)
+    float lut[16][4];      // nibble -> four 0.f / 1.f
+    int dims[16][4];       // sorted slot -> the node's block sides
+};
+struct alignas(16) RollLds { // one wavefront's scratch: 4.8 KB, so that 8 workgroups (all 32 waves a CU
                           // gets at B = 8192) fit the 160 KB of LDS
     unsigned char lst[64]; // sub_graph_nodes in list order
     unsigned char ord[64]; // sub-graph node order (matrix index -> node)
@@ -266,8 +272,9 @@ struct RollLds {          // one wavefront's scratch: 4.8 KB, so that 8 workgrou
     union {
         int tbl[2 * PYSET_CAP]; // set-order emulation (step 3)
         u64 cw[PYSET_CAP];      // later: dynamic's column words, bit (sec*child + rm) of cw[col]
+        RollFastLds f;
     };
-    u64 side[5][64];      // column masks by sub-graph index
+    u64 side[5][64];      // column masks by sub-graph index (rolling_emit_fast: by node id)
 };
 
 // one wavefront = one instance, lane v = node v; every lane of the wave must call this
@@ -281,6 +288,13 @@ extern "C" int tap_prof_read(unsigned int *out)
 }
 #define PROF(i) do { const long long t_ = clock64(); if (v == 0 && inst < 8192) tap_prof_w[inst * 8 + (i)] = (unsigned)(t_ - tp); tp = t_; } while (0)
 #define PROF_BEGIN long long tp = clock64()
+#elif defined(TAP_ROLL_STOP)
+// -DTAP_ROLL_STOP: the wave returns at phase mark tap_roll_stop_at (scratch/valu_phases.py counts SQ_INSTS_VALU per
+// phase by differencing); results are garbage past the mark, the state must be restored by the caller
+__constant__ int tap_roll_stop_at = -1;
+extern "C" int tap_prof_set_stop(int i) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tap_roll_stop_at), &i, sizeof(int)); }
+#define PROF(i) do { if (tap_roll_stop_at == (i)) return; } while (0)
+#define PROF_BEGIN do { } while (0)
 #else
 #define PROF(i) do { } while (0)
 #define PROF_BEGIN do { } while (0)
@@ -462,12 +476,135 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
     PROF(7);
 }
 
-template <int D>
+// (4) again, for the window sizes known at compile time (CH nodes: 3*CH <= 32 rows, CH*R <= 64 columns, 5*CH <= 64
+//     (relation, column) pairs): the same tensors with every index computation, loop bound and shift a constant.
+//     Differences from rolling_emit_wave that matter for the instruction count (SQ_INSTS_VALU per window wave at c5:
+//     emission 450 -> ~150, profiles/r03_*):
+//       * window lanes publish their RAW masks by node id; the (relation, column) lanes mask them, test the
+//         "blocker outside every window so far" rule (:1690-1705) once per mask instead of once per node lane, and
+//         pick the CH row bits with the node ids in scalar registers;
+//       * the block sides go through LDS rows by sorted slot, so a column lane reads the side its rotation puts in
+//         a row with one address computation instead of three cross-lane reads and a select chain;
+//       * the fp32 expansion is a table look-up: lane (rsub, c4) interleaves the bits of its four column words
+//         once (rows rsub + RP*q sit RP >= 4 bits apart, so the four columns' bits of one row form a nibble),
+//         and a row's float4 is lut[nibble] -- one bit-field extract and one shift per 16-byte store.
+template <int D, int CH>
+__device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, int v, RollLds &S, u64 entered, u64 window,
+                                                  const RollNode &nd)
+{
+    constexpr int R = D == 2 ? 2 : 6, NRC = CH * R, C4 = NRC / 4, RP = 64 / C4, ROWS = 3 * CH, QN = (ROWS + RP - 1) / RP;
+    static_assert(ROWS <= 32 && NRC <= 64 && NRC % 4 == 0 && 5 * CH <= 64 && RP >= 4 && CH <= 16, "shape outside the fast emission");
+    const int N = a.N;
+    const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
+    const u64 after = all & ~entered;                                  // after_nodes_list
+    const bool inwin = ((window >> v) & 1ull) != 0;
+    PROF_BEGIN;
+    if (inwin) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(window >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)window, 0u));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) S.side[k][v] = nd.rel[k];
+        S.srt[rank] = (unsigned char)v;                                // sorted position -> node (static's column order)
+        *reinterpret_cast<int4 *>(&S.f.dims[rank][0]) = make_int4(nd.bdim[0], nd.bdim[1], nd.bdim[2], 0);
+        if (a.nodes_out) a.nodes_out[(size_t)inst * CH + rank] = v;
+    }
+    if (v < 16)
+        *reinterpret_cast<float4 *>(&S.f.lut[v][0]) = make_float4((float)(v & 1), (float)((v >> 1) & 1), (float)((v >> 2) & 1), (float)((v >> 3) & 1));
+    tap_wave_lds_sync();
+    PROF(4);
+    // lane (k5, cm5): relation k5 of the node in sub-graph column cm5, re-indexed to sub-graph rows
+    {
+        const int k5 = v / CH, cm5 = v - k5 * CH;
+        const bool on5 = v < 5 * CH;
+        const int t = S.ord[on5 ? cm5 : 0];
+        const u64 m = S.side[on5 ? k5 : 0][t];
+        const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+        unsigned ow[(CH + 3) / 4];                                      // the sub-graph order, four node ids per scalar
+#pragma unroll
+        for (int j = 0; j < (CH + 3) / 4; ++j)
+            ow[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned *>(S.ord)[j]);
+        unsigned w = 0u;
+#pragma unroll
+        for (int rm = 0; rm < CH; ++rm) {
+            const unsigned node = (ow[rm >> 2] >> (8 * (rm & 3))) & 0xffu;        // wave-uniform
+            const unsigned half = node >= 32u ? mhi : mlo;
+            w |= ((half >> (node & 31u)) & 1u) << rm;
+        }
+        // :1690-1705 a side blocker that has not entered any window yet => the node counts as blocking itself
+        const bool self = k5 >= 1 && (m & after) != 0ull;
+        w |= self ? (1u << cm5) : 0u;
+        if (on5) S.f.iw[v] = w;
+    }
+    tap_wave_lds_sync();
+    PROF(5);
+    float *st = a.static_out + (size_t)inst * (1 + D) * NRC;
+    float *dy = a.dynamic_out + (size_t)inst * ROWS * NRC;
+    if (v < NRC) {
+        const int col = v, r = v / CH, cm = v - r * CH;
+        // which side pair guards rotation r (:1808-1821): the axis that becomes vertical, p[D-1] of the rotation's
+        // permutation -- 3D: (2,1,2,0,1,0)[r], two bits each; 2D: (1,0)[r]
+        const int pz = D == 3 ? (0x126 >> (2 * r)) & 3 : 1 - r;
+        const bool guarded = pz == 0 || (D == 3 && pz == 1);
+        const int k1 = pz == 0 ? 1 : 3;                                  // left/right or forward/backward
+        const unsigned ws0 = S.f.iw[cm];
+        const unsigned r1 = S.f.iw[k1 * CH + cm], r2 = S.f.iw[(k1 + 1) * CH + cm];
+        const unsigned ws1 = guarded ? r1 : 0u, ws2 = guarded ? r2 : 0u;
+        const int c0 = __popc(ws0), c1 = __popc(ws1), c2 = __popc(ws2);
+        if (a.colsum_out) {
+            a.colsum_out[((size_t)inst * 3 + 0) * NRC + col] = (float)c0;
+            a.colsum_out[((size_t)inst * 3 + 1) * NRC + col] = (float)c1;
+            a.colsum_out[((size_t)inst * 3 + 2) * NRC + col] = (float)c2;
+        }
+        if (a.cur_mask_out) a.cur_mask_out[(size_t)inst * NRC + col] = (c1 * c2 + c0 != 0) ? 0.f : 1.f;   // model.py:297-307
+        const unsigned w = ws0 | (ws1 << CH) | (ws2 << (2 * CH));
+        S.f.cw32[col] = w;
+        if (a.bits_out) a.bits_out[(size_t)inst * NRC + col] = (u64)w;
+        // static (:1795-1801): row 0 = sorted slot, row 1+k = side perm[r][k] of the node in that slot; the three
+        // sides' positions in the slot's LDS row as nibbles (4 * index), one constant per row
+        st[col] = (float)cm;
+        const int r4 = 4 * r;
+        const int o0 = D == 3 ? (0x884400 >> r4) & 15 : (0x40 >> r4) & 15;   // 3D: (0,0,1,1,2,2)[r]   2D: (0,1)[r]
+        const int o1 = D == 3 ? (0x408084 >> r4) & 15 : (0x04 >> r4) & 15;   // 3D: (1,2,0,2,0,1)[r]   2D: (1,0)[r]
+        const char *row = reinterpret_cast<const char *>(&S.f.dims[cm][0]);
+        st[(size_t)1 * NRC + col] = (float)*reinterpret_cast<const int *>(row + o0);
+        st[(size_t)2 * NRC + col] = (float)*reinterpret_cast<const int *>(row + o1);
+        if (D == 3) {
+            const int o2 = (0x040848 >> r4) & 15;                             //     (2,1,2,0,1,0)[r]
+            st[(size_t)3 * NRC + col] = (float)*reinterpret_cast<const int *>(row + o2);
+        }
+    }
+    tap_wave_lds_sync();
+    PROF(6);
+    {
+        const int rsub = v / C4, c4 = v - rsub * C4;
+        if (rsub < RP) {
+            const uint4 cq = *reinterpret_cast<const uint4 *>(&S.f.cw32[c4 * 4]);
+            unsigned mk = 0u;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) mk |= 1u << (RP * q);
+            // bit RP*q + i of `il` = column 4*c4 + i at row rsub + RP*q
+            unsigned il = (cq.x >> rsub) & mk;
+            il |= ((cq.y >> rsub) & mk) << 1;
+            il |= ((cq.z >> rsub) & mk) << 2;
+            il |= ((cq.w >> rsub) & mk) << 3;
+            float4 *dst = reinterpret_cast<float4 *>(dy) + c4 + (size_t)rsub * C4;
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                if (RP * q + rsub < ROWS) {
+                    const unsigned nib = (il >> (RP * q)) & 15u;
+                    store_stream(&dst[(size_t)RP * q * C4], *reinterpret_cast<const float4 *>(&S.f.lut[nib][0]));
+                }
+            }
+        }
+    }
+    PROF(7);
+}
+
+template <int D, int CH>
 __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
 {
     if (inst >= a.B) return;
     PROF_BEGIN;
-    const int N = a.N, child = a.child;
+    const int N = a.N, child = CH ? CH : a.child;
     constexpr int R = D == 2 ? 2 : 6;
     const int nRc = child * R;
     const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
@@ -534,18 +671,22 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     }
     if (short_window) return;
     PROF(2);
-    rolling_emit_wave<D>(a, inst, v, S, entered, window, nd);
+    if constexpr (CH > 0) rolling_emit_fast<D, CH>(a, inst, v, S, entered, window, nd);
+    else rolling_emit_wave<D>(a, inst, v, S, entered, window, nd);
     PROF(3);
 }
 
+// window sizes with a compile-time-shaped kernel (0 = any window, shapes read from the arguments)
+__host__ __device__ constexpr bool roll_fast_ok(int D, int child) { return child == 10 && (D == 2 || D == 3); }
+
 // 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
 // were resident, so one workgroup in eight ran as a second round
-template <int D>
+template <int D, int CH>
 __global__ void __launch_bounds__(TAP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rolling_window(RollArgs a)
 {
     __shared__ RollLds S[TAP_BLOCK / 64];
     const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
-    rolling_window_wave<D>(a, blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
+    rolling_window_wave<D, CH>(a, blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
 }
 
 // ---- fused rolling step: add_new_block for the column picked in the CURRENT window (gathered from
@@ -560,24 +701,24 @@ struct RollStepArgs {
 constexpr int ROLL_EPB = 2;   // instances per workgroup of the fused step (2: 3-wave workgroups pack a CU's 28 wave slots
                               // better than 6-wave ones: 9 x 3 = 27 against 4 x 6 = 24)
 
-template <int D, int G, bool SOFT>
+template <int D, int G, bool SOFT, int CH>
 __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a);
 
-template <int D, int G>
+template <int D, int G, int CH>
 __global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_rolling_step_soft(RollStepArgs a)
 {
-    rolling_step_body<D, G, true>(a);
+    rolling_step_body<D, G, true, CH>(a);
 }
 
-template <int D, int G>
+template <int D, int G, int CH>
 __global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_rolling_step(RollStepArgs a)
 {
-    rolling_step_body<D, G, false>(a);
+    rolling_step_body<D, G, false, CH>(a);
 }
 
-template <int D, int G, bool SOFT>
+template <int D, int G, bool SOFT, int CH>
 __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a)
 {
     constexpr int EPB = ROLL_EPB;                           // instances per workgroup
@@ -595,7 +736,7 @@ __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a)
         tap_lb_place_wave<D, G, !SOFT>(a.s, 0, nullptr, env, cell, lane, s_old + (tid - cell), s_new + (tid - cell));
         return;
     }
-    rolling_window_wave<D>(a.r, base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
+    rolling_window_wave<D, CH>(a.r, base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
 }
 
 // ---- more than 64 blocks per instance ------------------------------------------------------------------------
@@ -851,8 +992,14 @@ extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, 
         TAP_LAUNCH_CHECK(ctx, "k_rolling_window_big");
         return TAP_OK;
     }
-    if (D == 2) hipLaunchKernelGGL(k_rolling_window<2>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_rolling_window<3>, dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    const bool fast = roll_fast_ok(D, child);
+    if (D == 2) {
+        if (fast) hipLaunchKernelGGL((k_rolling_window<2, 10>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_rolling_window<2, 0>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_rolling_window<3, 10>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_rolling_window<3, 0>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+    }
     TAP_LAUNCH_CHECK(ctx, "k_rolling_window");
     return TAP_OK;
 }
@@ -862,8 +1009,14 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
     constexpr int EPB = ROLL_EPB, ENV_WAVES = (EPB * G + 63) / 64, THREADS = 64 * (ENV_WAVES + EPB);
     const int grid = (a.r.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
-    if (a.s.d.flags & TAP_F_HARD) hipLaunchKernelGGL((k_rolling_step<D, G>), dim3(grid), dim3(THREADS), 0, st, a);
-    else hipLaunchKernelGGL((k_rolling_step_soft<D, G>), dim3(grid), dim3(THREADS), 0, st, a);   // soft rewards: no hard-mode walk compiled in
+    const bool hard = a.s.d.flags & TAP_F_HARD;              // soft rewards: no hard-mode walk compiled in
+    if (roll_fast_ok(D, a.r.child)) {
+        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
+    } else {
+        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 0>), dim3(grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 0>), dim3(grid), dim3(THREADS), 0, st, a);
+    }
     TAP_LAUNCH_CHECK(ctx, "k_rolling_step");
     return TAP_OK;
 }
