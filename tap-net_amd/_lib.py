@@ -10,7 +10,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtapenv.so")
+LIB_PATH = os.environ.get("TAP_LIB_PATH") or os.path.join(_HERE, "libtapenv.so")   # TAP_LIB_PATH: A/B builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "tapenv.h")
 
 TAP_OK = 0

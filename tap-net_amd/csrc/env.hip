@@ -24,23 +24,18 @@ extern "C" const char *tap_status_string(int s)
     }
 }
 
-// one thread per (shape, mask): evaluate the hull-free predicate, set the bit
+// one thread per (shape, packed mask): evaluate the hull-free predicate, set the bit (tap_place.h: layout)
 __global__ void k_build_stab_lut(uint32_t *lut)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int off = 0;
-    for (int bx = 1; bx <= 4; ++bx)
-        for (int by = 1; by <= 4; ++by) {
-            const int count = 1 << (bx * by);
-            if (idx >= off && idx < off + count) {
-                const unsigned mc = (unsigned)(idx - off);
-                u64 m = 0; // row-major (i*by + j) -> stride-8
-                for (int i = 0; i < bx; ++i) m |= (u64)((mc >> (i * by)) & ((1u << by) - 1u)) << (8 * i);
-                if (tap_stable3d(bx, by, m)) atomicOr(&lut[idx >> 5], 1u << (idx & 31));
-                return;
-            }
-            off += count;
-        }
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)TAP_LUT_BITS) return;
+    const int shape = (int)(idx >> 16), bx = shape / 4 + 1, by = shape % 4 + 1;
+    const unsigned packed = idx & 0xffffu;
+    for (int i = 0; i < 4; ++i) {                              // only masks inside the bx x by footprint occur
+        const unsigned row = (packed >> (4 * i)) & 15u;
+        if (row && (i >= bx || (row >> by))) return;
+    }
+    if (tap_stable3d(bx, by, tap_lut_unpack(packed))) atomicOr(&lut[idx >> 5], 1u << (idx & 31u));
 }
 
 extern "C" int tap_ctx_create(int device, tap_ctx **out)

@@ -162,8 +162,8 @@ extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, i
     if (!bits_in || (ptr && (!static_ || static_rows < 1)) || update_rows < 0 || update_rows > 3 ||
         (!ptr && update_rows != 0) || bits_in == bits_out || (!bits_out && !dyn_out && !current_out && !mask_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_bits arguments");
-    MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
-                  mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};
+    MaskArgs a = mask_finish(MaskArgs{B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
+                  mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
     if (!mask_bits_ok(a))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
     return launch_mask_step(ctx, a, (hipStream_t)stream);
@@ -180,8 +180,8 @@ extern "C" int tap_mask_step_first(tap_ctx *ctx, int B, int n, int R, int rows, 
     if (!dyn_in || !bits_out || (ptr && (!static_ || static_rows < 1)) || update_rows < 0 || update_rows > 3 ||
         (!ptr && update_rows != 0) || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step_first arguments");
-    MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
-                  mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out};
+    MaskArgs a = mask_finish(MaskArgs{B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                  mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out});
     if (!mask_bits_ok(a))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
     return launch_mask_step(ctx, a, (hipStream_t)stream);
@@ -200,8 +200,8 @@ extern "C" int tap_update_dynamic(tap_ctx *ctx, int B, int n, int nR, int rows, 
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "update_dynamic is out of place (pack.py:370)");
     if ((colsum_in == nullptr) != (colsum_out == nullptr))
         return tap_fail(ctx, TAP_E_INVALID, "colsum_in and colsum_out go together");
-    MaskArgs a = {B, n, nR / n, nR, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
-                  nullptr, colsum_in, colsum_out, nullptr, nullptr};
+    MaskArgs a = mask_finish(MaskArgs{B, n, nR / n, nR, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                  nullptr, colsum_in, colsum_out, nullptr, nullptr});
     return launch_mask_step(ctx, a, (hipStream_t)stream);
 }
 
@@ -213,8 +213,8 @@ extern "C" int tap_update_mask(tap_ctx *ctx, int B, int n, int R, const float *m
     if (B == 0) return TAP_OK;
     if (!colsum || (!current_out && !mask_out)) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     if (ptr && !mask_in) return tap_fail(ctx, TAP_E_INVALID, "update_mask needs mask_in");
-    MaskArgs a = {B, n, R, n * R, 3 * n, 0, 0, nullptr, nullptr, nullptr, ptr, mask_in, colsum,
-                  nullptr, current_out, mask_out};
+    MaskArgs a = mask_finish(MaskArgs{B, n, R, n * R, 3 * n, 0, 0, nullptr, nullptr, nullptr, ptr, mask_in, colsum,
+                  nullptr, current_out, mask_out});
     return launch_mask_step(ctx, a, (hipStream_t)stream);
 }
 
@@ -231,7 +231,7 @@ extern "C" int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int up
         !current_out || !mask_out || static_rows < 1 || update_rows < 0 || update_rows > 3)
         return tap_fail(ctx, TAP_E_INVALID, "bad mask_step arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "mask_step is out of place (pack.py:370)");
-    MaskArgs a = {B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
-                  mask_in, colsum_in, colsum_out, current_out, mask_out};
+    MaskArgs a = mask_finish(MaskArgs{B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                  mask_in, colsum_in, colsum_out, current_out, mask_out});
     return launch_mask_step(ctx, a, (hipStream_t)stream);
 }

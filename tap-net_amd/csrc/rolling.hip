@@ -652,7 +652,9 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     window |= added;
     const int short_window = count != child;
     const bool inwin = (window & bit) != 0;
-    RollNode nd = rolling_node_loads<D>(a, inst, v, inwin && !short_window, rel0);   // in flight under the set order
+    // in flight under the set order (asking for every node's record up front instead -- one round trip fewer on the
+    // wave's critical path, 44 more bytes per node -- measured 17.6 against 15.8 us per fused step at c5)
+    RollNode nd = rolling_node_loads<D>(a, inst, v, inwin && !short_window, rel0);
     tap_wave_lds_sync();
 
     PROF(1);

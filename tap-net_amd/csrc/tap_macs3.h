@@ -172,7 +172,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
 
     // this lane in the y-major view: position / cell (tx, ty), bit ty*W + tx of every level mask
     const bool inT = cell < cells;
-    const int ty = cell / W, tx = cell - ty * W;
+    const int ty = tap_div_small(cell, W), tx = cell - ty * W;
     const int hmT = inT ? S.hm[tx * L + ty] : INT_MAX;
     const u64 *occT = S.occ + (size_t)(inT ? tx * L + ty : 0) * HW;   // this lane's column of F, complemented
     auto wordF = [&](int w) -> u64 {                                     // F bits of levels [64w, 64w + 64)
@@ -706,7 +706,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         const int Z = __shfl(mp, gl0 + win), stab = __shfl(stab_p, gl0 + win), emp = __shfl(emp_p, gl0 + win);
         const int py = win / W, px = win - py * W;
         res.placed = 1; res.x = px; res.y = py; res.z = Z; res.stab = stab;
-        const int cx = cell / L, cy = cell - cx * L;
+        const int cx = tap_div_small(cell, L), cy = cell - cx * L;
         const bool foot = cell < cells && cx >= px && cx < px + bx && cy >= py && cy < py + by;
         u64 nw[MACS3_MAX_HW] = {};
         if (foot) {

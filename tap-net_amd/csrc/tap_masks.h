@@ -24,7 +24,18 @@ struct MaskArgs {
     // dyn_in inside the step (one read of the slab); *nonbinary is incremented by the number of elements that
     // are neither 0 nor 1 (the shadow, and the step's outputs, are only valid when it stays 0)
     int *nonbinary;
+    // lane mapping of the 16-byte row accesses (lane = (row group, column quad)), filled by mask_finish() on the
+    // host so that no kernel divides by a run-time value: c4_magic = ceil(2^16 / (nR/4)), rp = 64 / (nR/4)
+    int c4_magic, rp;
 };
+
+inline MaskArgs mask_finish(MaskArgs a)
+{
+    const int c4 = a.nR >> 2;
+    a.c4_magic = c4 > 0 ? 65536 / c4 + 1 : 0;
+    a.rp = c4 > 0 ? 64 / c4 : 0;
+    return a;
+}
 
 __host__ __device__ __forceinline__ bool mask_builds_bits(const MaskArgs &a) { return !a.bits_in && a.bits_out && a.dyn_in; }
 
@@ -237,7 +248,10 @@ __device__ __forceinline__ void stream_wave_fast(const MaskArgs &a, int senv0, i
 // sums of pack.py:323-326 are popcounts, and the fp32 tensor the network consumes (model.py:378) is
 // EXPANDED from the bits instead of copied -- the step writes `rows*nR*4` bytes per env and reads
 // `nR*8`, half the traffic of the copy.  One round trip: every input is loaded up front and `real`
-// comes out of the row-0 registers by shuffle, as above.  Lane (rsub, c4) = lane / (nR/4), lane %
+// comes out of the row-0 registers by shuffle, as above.  (The expansion as a nibble -> float4 table look-up,
+// which took a third of the vector instructions out of the rolling step (rolling.hip), was measured here too:
+// 7 % SLOWER at the BASELINE batches -- the LDS read sits in every store's dependency chain of a latency-bound
+// launch -- and +8 % only from B = 524 288; not kept.)  Lane (rsub, c4) = lane / (nR/4), lane %
 // (nR/4) keeps four column words and writes the float4 of rows rsub, rsub + 64/(nR/4), ...: a wave
 // store instruction covers whole consecutive rows.  Requirements: nR % 4 == 0, nR <= 64*NC, rows <= 64.
 // First step of an episode (mask_builds_bits): the column words come from the fp32 slab instead of a stored
@@ -250,7 +264,7 @@ __device__ __forceinline__ void stream_build_bits(const MaskArgs &a, int senv0, 
 {
     typedef unsigned long long u64;
     const int nR = a.nR, C4 = nR >> 2, rows = a.rows;
-    const int rsub = lane / C4, c4 = lane - rsub * C4, RP = 64 / C4;
+    const int rsub = (int)(((unsigned)lane * (unsigned)a.c4_magic) >> 16), c4 = lane - rsub * C4, RP = a.rp;
     for (int i = lane; i < NS * nR; i += 64) tile[i] = 0ull;
     tap_wave_lds_sync_m();
     int bad = 0;
@@ -308,7 +322,7 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
 {
     typedef unsigned long long u64;
     const int nR = a.nR, C4 = nR >> 2, rows = a.rows;
-    const int rsub = lane / C4, c4 = lane - rsub * C4, RP = 64 / C4;
+    const int rsub = (int)(((unsigned)lane * (unsigned)a.c4_magic) >> 16), c4 = lane - rsub * C4, RP = a.rp;
     const bool lane_on = rsub < RP;
     constexpr bool build = BUILD;
     u64 *tile = reinterpret_cast<u64 *>(lds);

@@ -164,33 +164,36 @@ __device__ inline int tap_stable3d(int bx, int by, u64 m)
 }
 
 // Table form of tap_stable3d for footprints up to 4x4 (every RAND block: sides 1..4): one bit per
-// (shape, support mask), built once per context by running tap_stable3d itself over all 74 954
-// (shape, mask) pairs (env.hip), 9.4 KB, L2-resident.  In the 3D kernels the hull test was more than
-// half of a placement's time (7.5 of 14.6 us at config c5); the cheap cases (majority, <= 1 support
-// cell) stay inline, the rest become one 32-bit load.
-__device__ __forceinline__ int tap_lut_offset(int bx, int by)
+// (shape, support mask), built once per context by running tap_stable3d itself over every mask of every shape
+// (env.hip).  In the 3D kernels the hull test was more than half of a placement's time (7.5 of 14.6 us at
+// config c5); the cheap cases (majority, <= 1 support cell) stay inline, the rest become one 32-bit load.
+// Layout: shape (bx, by) owns the 64 Kbit slot ((bx-1)*4 + by-1) << 16, and a mask is indexed by its four rows'
+// low nibbles packed side by side (the footprint's rows sit 8 bits apart in the stride-8 mask) -- a fixed
+// layout, so the index is a handful of 32-bit operations with no per-shape offset table or row loop
+// (128 KB, of which only the lines of masks that occur are ever touched).
+constexpr int TAP_LUT_SHAPES = 16;
+constexpr int TAP_LUT_BITS = TAP_LUT_SHAPES << 16;
+constexpr int TAP_LUT_WORDS = TAP_LUT_BITS / 32;
+
+__device__ __forceinline__ unsigned tap_lut_pack(u64 m)   // stride-8 mask of a footprint <= 4x4 -> 16-bit index
 {
-    int off = 0; // prefix sums of 2^(bx*by) over shapes in (bx, by) row-major order
-    for (int i = 1; i <= 4; ++i)
-        for (int j = 1; j <= 4; ++j) {
-            if (i == bx && j == by) return off;
-            off += 1 << (i * j);
-        }
-    return off;
+    unsigned t = (unsigned)m & 0x0f0f0f0fu;                 // rows 0..3 live in the low word
+    t = (t | (t >> 4)) & 0x00ff00ffu;
+    return (t | (t >> 8)) & 0xffffu;
 }
-constexpr int TAP_LUT_BITS = 74954 + 22; // sum over shapes of 2^(bx*by), padded to a word boundary
-constexpr int TAP_LUT_WORDS = (TAP_LUT_BITS + 31) / 32;
+__device__ __forceinline__ u64 tap_lut_unpack(unsigned idx) // inverse of tap_lut_pack
+{
+    return (u64)((idx & 0xfu) | ((idx & 0xf0u) << 4) | ((idx & 0xf00u) << 8) | ((idx & 0xf000u) << 12));
+}
 
 __device__ __forceinline__ int tap_stable3d_any(const uint32_t *lut, int bx, int by, u64 m)
 {
     if (lut == nullptr || bx > 4 || by > 4) return tap_stable3d(bx, by, m);
-    const int k = __popcll(m);
+    const int k = __popc((unsigned)m);                       // footprint <= 4x4: the mask is in the low word
     if (2 * k > bx * by) return 1; // tools.py:730
     if (k <= 1) return 0;          // tools.py:732
-    unsigned mc = 0;               // stride-8 mask -> row-major (i*by + j)
-    for (int i = 0; i < bx; ++i) mc |= (unsigned)((m >> (8 * i)) & ((1u << by) - 1u)) << (i * by);
-    const int idx = tap_lut_offset(bx, by) + (int)mc;
-    return (lut[idx >> 5] >> (idx & 31)) & 1u;
+    const unsigned idx = (unsigned)(((bx - 1) * 4 + (by - 1)) << 16) | tap_lut_pack(m);
+    return (lut[idx >> 5] >> (idx & 31u)) & 1u;
 }
 
 // ---- footprint scan over the group's LDS slice ---------------------------------------------
@@ -249,6 +252,25 @@ __device__ __forceinline__ double tap_score(const PlaceCfg &c, const Counters &c
     return (C + P) + S;
 }
 
+// cell / L for the lane-per-cell groups (cell < 64; 3D sides <= 8): a multiplication by ceil(2^16 / L), the
+// constant picked by scalar compares -- an integer division by a run-time value is ~25 vector instructions
+__device__ __forceinline__ int tap_div_small(int cell, int L)
+{
+    int m;
+    switch (L) {
+    case 1: return cell;
+    case 2: return cell >> 1;
+    case 3: m = 21846; break;
+    case 4: return cell >> 2;
+    case 5: m = 13108; break;
+    case 6: m = 10923; break;
+    case 7: m = 9363; break;
+    case 8: return cell >> 3;
+    default: return cell / L;
+    }
+    return (cell * m) >> 16;
+}
+
 // ---- one placement -------------------------------------------------------------------------
 // s        : the group's LDS slice holding the current height-map (written + barrier'd by caller)
 // cell     : lane index inside the group; hm : this lane's cell height (updated on commit)
@@ -262,7 +284,7 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
                                       bool do_step)
 {
     const int W = c.W, L = c.L;
-    const int x = (D == 2) ? cell : cell / L;
+    const int x = (D == 2) ? cell : tap_div_small(cell, L);
     const int y = (D == 2) ? 0 : cell - x * L;
     const bool incell = cell < W * L;
     const bool hard = (c.flags & TAP_F_HARD) != 0;
@@ -314,19 +336,25 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
             ratio = tap_score(c, cnt, vol, gmax, z, bz, emp, stab);
             key = ((z * L + y) * 3 + cls) * W + x;                // sort order (z, y, class, x)
         }
-        // argmax over the group with the winner's placement riding along (keys of candidates are unique)
-        int pxy = x | (y << 8) | (stab << 16);
-        group_butterfly<G>((int)(threadIdx.x & 63), [&](auto get) {
+        // argmax over the group on (ratio desc, key asc) -- keys of candidates are unique -- then the winner's
+        // placement is fetched from its lane (three cross-lane reads instead of three more values in every step)
+        const int lane = (int)(threadIdx.x & 63);
+        const int mykey = key;
+        group_butterfly<G>(lane, [&](auto get) {
             const double r2 = __hiloint2double(get(__double2hiint(ratio)), get(__double2loint(ratio)));
-            const int k2 = get(key), p2 = get(pxy), z2 = get(z), e2 = get(emp);
-            if (r2 > ratio || (r2 == ratio && k2 < key)) { ratio = r2; key = k2; pxy = p2; z = z2; emp = e2; }
+            const int k2 = get(key);
+            if (r2 > ratio || (r2 == ratio && k2 < key)) { ratio = r2; key = k2; }
         });
         res.placed = ratio > 0.0;
+        const u64 wm = __ballot(cand && mykey == key);            // each group's winner (none: no candidate)
+        const u64 mine = G == 64 ? wm : ((wm >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1ull));
+        const int src = (lane & ~(G - 1)) + (mine ? __ffsll((long long)mine) - 1 : 0);
+        const int pxy = __shfl(x | (y << 8) | (stab << 16), src);
         res.x = pxy & 255;
         res.y = (pxy >> 8) & 255;
-        res.z = z;
+        res.z = __shfl(z, src);
         res.stab = pxy >> 16;
-        emp_w = emp;
+        emp_w = __shfl(emp, src);
     } else {
         // hard: the reference walks the sorted corner list sequentially with a shared `visited`
         // set, sliding each block until it is supported, free and stable (tools.py:2100-2121,
@@ -408,7 +436,7 @@ __device__ __forceinline__ void tap_write_feature(int feature, int W, int L, con
         if (D == 2) {
             if (cell < W - 1) out[cell] = (float)(s[cell + 1] - hm);               // :3739-3743
         } else if (incell) {
-            const int x = cell / L, y = cell - x * L;
+            const int x = tap_div_small(cell, L), y = cell - x * L;
             out[cell] = (float)(x > 0 ? hm - s[cell - L] : 0);                      // :3723-3725
             out[cells + cell] = (float)(y > 0 ? hm - s[cell - 1] : 0);              // :3728-3730
         }

@@ -324,8 +324,8 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "transition is out of place (pack.py:370)");
-    a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
-                   mask_in, colsum_in, colsum_out, current_out, mask_out, nullptr, nullptr};
+    a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                   mask_in, colsum_in, colsum_out, current_out, mask_out, nullptr, nullptr});
     return transition_dispatch(ctx, d, a, stream);
 }
 
@@ -343,8 +343,8 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
-    a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
-                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out};
+    a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
+                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
     if (!mask_bits_ok(a.m))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);
@@ -363,8 +363,8 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
-    a.m = MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
-                   mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out};
+    a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                   mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out});
     if (!mask_bits_ok(a.m))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);
