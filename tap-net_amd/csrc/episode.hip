@@ -58,6 +58,20 @@ __device__ __forceinline__ bool episode_block(const EpisodeArgs &a, int env, int
     return in;
 }
 
+// The block lists are read PF steps at a time by the lanes of the container's group (two dependent loads -- tour
+// entry, then the column of `static` -- for PF steps at once) into an LDS row, instead of two dependent round trips
+// in front of every placement: at ten blocks an episode's 20 serial memory latencies become 2.
+constexpr int EP_PF = 32;
+template <int D, int G>
+__device__ __forceinline__ void episode_prefetch(const EpisodeArgs &a, int env, bool ev, int cell, int t0, int4 *row)
+{
+    for (int j = cell; j < EP_PF && t0 + j < a.n; j += G) {
+        int dims[3], e = 0;
+        const bool in = episode_block<D>(a, env, t0 + j, ev, dims, e);
+        row[j] = make_int4(dims[0], dims[1], dims[2], (in ? 1 : 0) | (e << 1));   // w: in-list flag, error bits above
+    }
+}
+
 // `ratio` of calc_positions_lb_greedy / calc_positions_mcs (tools.py:2442-2445, 3279-3308): Container.calc_ratio's
 // table without the division; 'C+P-lb-soft' is C + P + S here (tools.py:2442).
 __device__ __forceinline__ double episode_ratio(int mode, double C, double P, double S)
@@ -93,10 +107,13 @@ __device__ __forceinline__ void episode_finish(const EpisodeArgs &a, int env, co
 }
 
 // ---- LB_GREEDY ---------------------------------------------------------------------------------------------
-template <int D, int G>
+// SOFT: the caller has checked that TAP_F_HARD is not set; the hard-mode walk is not compiled in (3D: 134 -> ~60
+// VGPRs).  Lane groups never span a wavefront, so the per-step hand-offs are wave-level LDS syncs, not s_barrier.
+template <int D, int G, bool SOFT>
 __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
 {
     __shared__ int s[TAP_BLOCK];
+    __shared__ int4 pf[TAP_BLOCK / G][EP_PF];
     const int tid = threadIdx.x, grp = tid / G, cell = tid % G;
     const int env = blockIdx.x * ((int)blockDim.x / G) + grp;
     const int W = a.d.W, L = a.d.L, n = a.n;
@@ -104,21 +121,27 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode(EpisodeArgs a)
     const PlaceCfg cfg = {W, L, a.d.H, a.d.flags, a.lut};
     int hm = 0, err = 0;
     Counters cnt = {0, 0, 0, 0};
-    for (int t = 0; t < n; ++t) {
-        int dims[3];
-        const bool ok = episode_block<D>(a, env, t, ev, dims, err);
-        const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
-        s[tid] = hm;
-        __syncthreads();
-        const Placement pl = tap_place<D, G>(cfg, s + grp * G, cell, hm, cnt, err, bx, by, bz, ok);
-        __syncthreads();
-        if (ev && cell == 0) {
-            if (a.pos_out) {
-                int32_t *pp = a.pos_out + ((size_t)env * n + t) * D;
-                pp[0] = pl.x;
-                if (D == 3) { pp[1] = pl.y; pp[2] = pl.z; } else pp[1] = pl.z;
+    for (int t0 = 0; t0 < n; t0 += EP_PF) {
+        tap_wave_lds_sync();                                  // the previous rows have been consumed
+        episode_prefetch<D, G>(a, env, ev, cell, t0, pf[grp]);
+        tap_wave_lds_sync();
+        for (int j = 0; j < EP_PF && t0 + j < n; ++j) {
+            const int t = t0 + j;
+            const int4 b = pf[grp][j];
+            const int bx = b.x, by = D == 3 ? b.y : 1, bz = D == 3 ? b.z : b.y;
+            err |= b.w >> 1;
+            s[tid] = hm;
+            tap_wave_lds_sync();
+            const Placement pl = tap_place<D, G, !SOFT>(cfg, s + grp * G, cell, hm, cnt, err, bx, by, bz, (b.w & 1) != 0);
+            tap_wave_lds_sync();
+            if (ev && cell == 0) {
+                if (a.pos_out) {
+                    int32_t *pp = a.pos_out + ((size_t)env * n + t) * D;
+                    pp[0] = pl.x;
+                    if (D == 3) { pp[1] = pl.y; pp[2] = pl.z; } else pp[1] = pl.z;
+                }
+                if (a.stable_out) a.stable_out[(size_t)env * n + t] = (uint8_t)pl.stab;
             }
-            if (a.stable_out) a.stable_out[(size_t)env * n + t] = (uint8_t)pl.stab;
         }
     }
     const int gmax = group_max<G>(incell ? hm : 0);
@@ -130,7 +153,8 @@ template <int D, int G> static int launch_episode(tap_ctx *ctx, const EpisodeArg
 {
     const int epb = TAP_BLOCK / G, grid = (a.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
-    hipLaunchKernelGGL((k_episode<D, G>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    if (a.d.flags & TAP_F_HARD) hipLaunchKernelGGL((k_episode<D, G, false>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
+    else hipLaunchKernelGGL((k_episode<D, G, true>), dim3(grid), dim3(TAP_BLOCK), 0, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_episode");
     return TAP_OK;
 }
@@ -154,10 +178,18 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode_macs2(EpisodeArgs a)
     const PlaceCfg cfg = {W, 1, H, a.d.flags, nullptr};
     int hm = 0, err = 0;
     Counters cnt = {0, 0, 0, 0};
+    __shared__ int4 pf[TAP_BLOCK / G][EP_PF];
+    int4 *const row = pf[tid / G];
     for (int t = 0; t < n; ++t) {
-        int dims[3];
-        const bool in = episode_block<2>(a, env, t, ev, dims, err);
-        const int bx = dims[0], bz = dims[1];
+        if ((t & (EP_PF - 1)) == 0) {                         // t is uniform: every lane takes this branch together
+            tap_wave_lds_sync();
+            episode_prefetch<2, G>(a, env, ev, cell, t, row);
+            tap_wave_lds_sync();
+        }
+        const int4 b = row[t & (EP_PF - 1)];
+        const bool in = (b.w & 1) != 0;
+        err |= b.w >> 1;
+        const int bx = b.x, bz = b.y;
         bool do_step = in;
         if (in && (bx < 1 || bz < 1)) { err |= 4; do_step = false; }
         base[cell] = hm;                                      // L.hm
@@ -189,11 +221,12 @@ template <int G, bool WIDE> static int launch_episode_macs2(tap_ctx *ctx, const 
     const tap_env_desc &d = a.d;
     int threads = TAP_BLOCK; // as many containers per workgroup as fit the 64 KB dynamic-LDS window
     const size_t per_env = (size_t)(WIDE ? macs_wide_group_words(G, d.H, a.n, d.W) : macs_group_words(G, d.H, a.n, d.W)) * sizeof(int);
-    while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
+    const size_t budget = 64 * 1024 - (TAP_BLOCK / G) * EP_PF * sizeof(int4);   // the block-list rows are static LDS
+    while (threads > 64 && (threads / G) * per_env > budget) threads /= 2;
     const int epb = threads / G, grid = (a.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > 64 * 1024)
+    if (lds > budget)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS episode: W=%d H=%d n=%d need %zu bytes of LDS per workgroup", d.W, d.H, a.n, lds);
     hipLaunchKernelGGL((k_episode_macs2<G, WIDE>), dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_episode_macs2");
@@ -217,10 +250,18 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode_macs3(EpisodeArgs a)
     for (int k = cell; k < 256; k += G) S.lrun[k] = (unsigned char)m3_longest_run((unsigned)k);
     int hm = 0, err = 0;
     Counters cnt = {0, 0, 0, 0};
+    __shared__ int4 pf[TAP_BLOCK / G][EP_PF];
+    int4 *const row = pf[tid / G];
     for (int t = 0; t < n; ++t) {
-        int dims[3];
-        const bool in = episode_block<3>(a, env, t, ev, dims, err);
-        const int bx = dims[0], by = dims[1], bz = dims[2];
+        if ((t & (EP_PF - 1)) == 0) {
+            tap_wave_lds_sync();
+            episode_prefetch<3, G>(a, env, ev, cell, t, row);
+            tap_wave_lds_sync();
+        }
+        const int4 b = row[t & (EP_PF - 1)];
+        const bool in = (b.w & 1) != 0;
+        err |= b.w >> 1;
+        const int bx = b.x, by = b.y, bz = b.z;
         bool do_step = in;
         // sides larger than the container: see tap_macs3_wave
         if (in && (bx < 1 || by < 1 || bz < 1 || bx > W || by > Ld)) { err |= 4; do_step = false; }
@@ -252,11 +293,12 @@ template <int G> static int launch_episode_macs3(tap_ctx *ctx, const EpisodeArgs
     const tap_env_desc &d = a.d;
     int threads = TAP_BLOCK;
     const size_t per_env = (size_t)macs3_group_words(G, a.n, d.H) * sizeof(int);
-    while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
+    const size_t budget = 64 * 1024 - (TAP_BLOCK / G) * EP_PF * sizeof(int4);
+    while (threads > 64 && (threads / G) * per_env > budget) threads /= 2;
     const int epb = threads / G, grid = (a.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > 64 * 1024)
+    if (lds > budget)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D episode: n=%d needs %zu bytes of LDS per workgroup", a.n, lds);
     hipLaunchKernelGGL(k_episode_macs3<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_episode_macs3");

@@ -203,7 +203,18 @@ __device__ __forceinline__ void tap_scan(const int *s, int L, int x, int y, int 
                                          int &mx, u64 &eq, int &sum)
 {
     mx = -1; eq = 0; sum = 0;
-    if (D == 2) {
+    if (D == 2 && bx <= 4) {
+        // every RAND block: the (at most 4) LDS reads are issued together, as in the 3D form below
+        int h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = i < bx ? s[x + i] : -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mx = max(mx, h[i]); sum += max(h[i], 0); }
+        unsigned e = 0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) e |= (unsigned)(h[i] == mx) << i;   // h = -1 outside the footprint, mx >= 0
+        eq = e;
+    } else if (D == 2) {
         for (int i = 0; i < bx; ++i) {
             const int h = s[x + i];
             sum += h;
