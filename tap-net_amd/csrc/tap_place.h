@@ -367,55 +367,72 @@ __device__ inline Placement tap_place(const PlaceCfg &c, const int *s, int cell,
         res.stab = pxy >> 16;
         emp_w = __shfl(emp, src);
     } else {
-        // hard: the reference walks the sorted corner list sequentially with a shared `visited`
-        // set, sliding each block until it is supported, free and stable (tools.py:2100-2121,
-        // 2284-2297, 2320-2327).  All lanes of the group run the walk redundantly in lock-step,
-        // so no broadcast is needed afterwards.
-        int z0 = 0;
-        if (cand) { int sum; u64 eq; tap_scan<D>(s, L, x, y, bx, by, z0, eq, sum); }
-        const int mykey = cand ? ((z0 * L + y) * 3 + cls) * W + x : INT_MAX;
-        int last = -1, vis_z = -1;
+        // hard: the reference walks the sorted corner list sequentially with a shared `visited` set, sliding each
+        // block over the positions (_x >= X0, _y >= Y0) until it is supported, free and stable (tools.py:2100-2121,
+        // 2284-2297, 2320-2327).  Whether a block settles at a position depends on the position and the corner's
+        // level only, so every lane scans the footprint at ITS cell once; a corner's walk is then three ballots
+        // (reachable, settles, and the cells up to the first settle become visited), the corner's lane keeps where
+        // its walk ended, and the candidates are scored in parallel afterwards -- "first maximum in list order" is
+        // the soft branch's (ratio desc, key asc) argmax.  (Before: all lanes walked redundantly, one footprint scan
+        // per visited position and three fp64 divisions per settled corner, 0.6 ms per generator launch.)
+        const int lane = (int)(threadIdx.x & 63), gl0 = lane & ~(G - 1);
+        auto gballot = [&](bool p) -> u64 {
+            const u64 b = __ballot(p);
+            return G == 64 ? b : ((b >> gl0) & ((1ull << (G & 63)) - 1ull));
+        };
+        const bool fits = do_step && incell && (x + bx <= W) && (y + by <= L);
+        int mx0 = -1, sum0 = 0;
+        u64 eq0 = 0;
+        if (fits) tap_scan<D>(s, L, x, y, bx, by, mx0, eq0, sum0);
+        const int st0 = (fits && mx0 > 0) ? (D == 2 ? tap_stable2d(bx, eq0) : tap_stable3d_any(c.lut, bx, by, eq0)) : 1;
+        const int mykey = cand ? ((mx0 * L + y) * 3 + cls) * W + x : INT_MAX;
+        const int mine = x | (y << 8) | (max(mx0, 0) << 16);
+        int last = -1, vis_z = -1, my_f = -1;
         u64 visited = 0;
-        double best = -1.0;
         for (int it = 0; it < G; ++it) { // wave-uniform trip count: shuffles stay convergent
             const int kmin = group_min<G>(mykey > last ? mykey : INT_MAX);
+            if (__ballot(kmin != INT_MAX) == 0ull) break;   // every group of the wave has walked its last corner
             if (kmin == INT_MAX) continue;
             last = kmin;
-            const int X0 = kmin % W;
-            int t = kmin / W;
-            t /= 3;
-            const int Y0 = t % L, z = t / L;
+            const u64 cm = gballot(mykey == kmin);           // the corner's lane (keys are unique)
+            const int cxyz = __shfl(mine, gl0 + __ffsll((long long)cm) - 1);
+            const int X0 = cxyz & 255, Y0 = (cxyz >> 8) & 255, z = cxyz >> 16;
             if (z != vis_z) { vis_z = z; visited = 0; }
-            // NOTE: the settle position is kept as ONE packed integer on purpose.  With separate
-            // x / y variables, hipcc 7.2 (-O3, gfx950) mis-compiled this walk when tap_place was
-            // inlined into k_episode's step loop (both came back 0); the packed form is exact and
-            // the parity tests (tests/test_gpu_parity.py, hard-mode cases) pin it.
-            bool ok = false;
-            int spos = 0, sstab = 0, semp = 0;
-            for (int _x = X0; _x + bx <= W; ++_x) {
-                for (int _y = Y0; _y + by <= L; ++_y) {
-                    const u64 pbit = 1ull << (_x * L + _y);
-                    if (ok || (visited & pbit)) continue;             // :2105 (and :2325 once settled)
-                    int mx, sum; u64 eq;
-                    tap_scan<D>(s, L, _x, _y, bx, by, mx, eq, sum);
-                    if (z > 0 && mx < z) continue;                // :2106 nothing underneath
-                    visited |= pbit;                              // :2107
-                    if (z >= c.H) { err |= 1; continue; }         // :2109 IndexError
-                    if (mx > z) continue;                         // :2109 not free
-                    const int st = (z == 0) ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d_any(c.lut, bx, by, eq));
-                    if (!st) continue;                            // :2112-2114 hard rejects
-                    ok = true; spos = _x * 64 + _y; sstab = st;
-                    semp = cnt.empty + bx * by * z - sum;
-                }
-                if (ok) break;
-            }
-            if (ok) {
-                const double r = tap_score(c, cnt, vol, gmax, z, bz, semp, sstab);
-                if (r > best) { // first maximum in list order
-                    best = r; res.placed = 1; res.x = spos >> 6; res.y = spos & 63; res.z = z; res.stab = sstab; emp_w = semp;
-                }
-            }
+            const bool reach = fits && x >= X0 && y >= Y0 && !((visited >> cell) & 1ull) && !(z > 0 && mx0 < z); // :2105-2106
+            const bool settle = reach && z < c.H && mx0 <= z && (z == 0 || st0);                                 // :2109-2114
+            const u64 okm = gballot(settle), reachm = gballot(reach);
+            const int f = okm ? __ffsll((long long)okm) - 1 : 64;                     // scan order = cell order
+            visited |= reachm & (f >= 63 ? ~0ull : ((2ull << f) - 1ull));             // :2107, nothing past the settle
+            if (z >= c.H && reachm) err |= 1;                                         // :2109 IndexError
+            if (mykey == kmin) my_f = okm ? f : -1;
         }
+        // the settled corners, scored by their own lanes
+        const int fsrc = gl0 + max(my_f, 0);
+        const int f_xy = __shfl(mine, fsrc), f_sum = __shfl(sum0, fsrc), f_st = __shfl(st0, fsrc);
+        double ratio = -1.0;
+        int key = INT_MAX, z = 0, stab = 0, emp = 0;
+        if (my_f >= 0) {
+            z = max(mx0, 0);
+            stab = (z == 0) ? 1 : f_st;
+            emp = cnt.empty + bx * by * z - f_sum;
+            ratio = tap_score(c, cnt, vol, gmax, z, bz, emp, stab);
+            key = mykey;
+        }
+        const int wkey = key;
+        group_butterfly<G>(lane, [&](auto get) {
+            const double r2 = __hiloint2double(get(__double2hiint(ratio)), get(__double2loint(ratio)));
+            const int k2 = get(key);
+            if (r2 > ratio || (r2 == ratio && k2 < key)) { ratio = r2; key = k2; }
+        });
+        res.placed = ratio > 0.0;
+        const u64 wm = gballot(my_f >= 0 && wkey == key);
+        const int src = gl0 + (wm ? __ffsll((long long)wm) - 1 : 0);
+        const int pxy = __shfl((f_xy & 0xffff) | (stab << 16), src);
+        res.x = pxy & 255;
+        res.y = (pxy >> 8) & 255;
+        res.z = __shfl(z, src);
+        res.stab = pxy >> 16;
+        emp_w = __shfl(emp, src);
     }
 
     // commit (tools.py:2167-2174); a failed placement leaves everything but the step counter
