@@ -928,7 +928,7 @@ def attach_reference_cpu(cb, config):
     build container (1 process and 8 processes) next to the oracle on the same work.  First-class fields:
     reference_value = this box's oracle figure / that ratio (derived), reference_measured = the build
     container's own figure (measured there)."""
-    for name in ("r02_reference_cpu.jsonl", "r01d_reference_cpu.jsonl"):
+    for name in ("r03_reference_cpu.jsonl", "r02_reference_cpu.jsonl", "r01d_reference_cpu.jsonl"):
         rp = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(rp):
             continue

@@ -106,7 +106,8 @@ int tap_env_feature_len(const tap_env_desc *d);
 
 /* tools.Container.__init__ state / clear_container (tools.py:3629-3655, 3858-3885).  The blob is cleared by a
  * kernel, not hipMemsetAsync: the call may be captured into a hipGraph (a captured memset becomes a graph memset
- * node, which was observed to run out of order with the neighbouring kernel nodes on replay). */
+ * node, which was observed to run out of order with the neighbouring kernel nodes on replay).  `state` must be
+ * 16-byte aligned (TAP_E_INVALID otherwise). */
 int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream);
 
 /* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy

@@ -52,8 +52,9 @@ extern "C" int tap_ctx_create(int device, tap_ctx **out)
     int prev = 0;
     (void)hipGetDevice(&prev);
     c->chk = nullptr;
+    c->chk_next = 0;
     bool ok = hipSetDevice(device) == hipSuccess &&
-              hipMalloc(reinterpret_cast<void **>(&c->chk), 2 * sizeof(int32_t)) == hipSuccess &&
+              hipMalloc(reinterpret_cast<void **>(&c->chk), 2 * TAP_CHK_SLOTS * sizeof(int32_t)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&c->stab_lut), TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess &&
               hipMemset(c->stab_lut, 0, TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess;
     if (ok) {
@@ -204,11 +205,11 @@ extern "C" int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, v
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (!state) return tap_fail(ctx, TAP_E_INVALID, "null state");
-    const size_t bytes = tap_env_layout(d, nullptr, nullptr);
-    if ((reinterpret_cast<uintptr_t>(state) | bytes) % 16) {      // torch allocations are 256-byte aligned; any other caller
-        TAP_HIP_CHECK(ctx, hipMemsetAsync(state, 0, bytes, (hipStream_t)stream));
-        return TAP_OK;
-    }
+    const size_t bytes = tap_env_layout(d, nullptr, nullptr);       // a multiple of 256
+    if (reinterpret_cast<uintptr_t>(state) % 16)
+        // every section of the blob is laid out for 16-byte accesses; torch allocations are 256-byte aligned.  (No
+        // hipMemsetAsync fallback: captured into a hipGraph it becomes the memset node that replays out of order.)
+        return tap_fail(ctx, TAP_E_INVALID, "the state blob must be 16-byte aligned");
     const size_t n16 = bytes / 16;
     const unsigned grid = (unsigned)((n16 + TAP_BLOCK - 1) / TAP_BLOCK < 2048 ? (n16 + TAP_BLOCK - 1) / TAP_BLOCK : 2048);
     hipLaunchKernelGGL(k_zero16, dim3(grid ? grid : 1), dim3(TAP_BLOCK), 0, (hipStream_t)stream,
@@ -424,6 +425,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_env_check(int B, const int32_t *e
 extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *state,
                              int32_t *n_bad_out, void *stream)
 {
+    if (n_bad_out) *n_bad_out = 0;
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
@@ -434,13 +436,16 @@ extern "C" int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *st
     // reads 8 bytes, not B words
     int32_t host[2] = {0, 0};
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ctx->chk, 0, 2 * sizeof(int32_t), st);
+    // one of TAP_CHK_SLOTS pairs of ints per call, handed out round-robin: checks issued back to back on different
+    // streams (or from two threads, against the "a ctx is not thread-safe" rule) do not reduce into each other
+    int32_t *chk = ctx->chk + 2 * (__atomic_fetch_add(&ctx->chk_next, 1u, __ATOMIC_RELAXED) % TAP_CHK_SLOTS);
+    hipError_t e = hipMemsetAsync(chk, 0, 2 * sizeof(int32_t), st);
     if (e == hipSuccess) {
         const int grid = min((d->B + TAP_BLOCK - 1) / TAP_BLOCK, 1024);
-        hipLaunchKernelGGL(k_env_check, dim3(grid), dim3(TAP_BLOCK), 0, st, d->B, v.err, ctx->chk);
+        hipLaunchKernelGGL(k_env_check, dim3(grid), dim3(TAP_BLOCK), 0, st, d->B, v.err, chk);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(host, ctx->chk, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(host, chk, sizeof(host), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return tap_fail(ctx, TAP_E_HIP, "error-word readback failed: %s", hipGetErrorString(e));
     const int bad = host[0], bits = host[1];

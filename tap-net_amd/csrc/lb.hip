@@ -19,10 +19,10 @@ struct LbView {
     int W, L, H, D, cap;
     int16_t *vox;  // [cells][H] of this env
     uint8_t *lfs;  // [H*L][cap]
-    int8_t *lfn;   // [H*L] list length - 1 (so that the all-zero blob is the initial [0] everywhere)
+    uint8_t *lfn;  // [H*L] (list length - 1) mod 256 (so that the all-zero blob is the initial [0] everywhere; lengths 0 .. 250)
     __device__ int16_t &v(int x, int y, int z) const { return vox[(size_t)(x * L + y) * H + z]; }
     __device__ uint8_t *list(int z, int y) const { return lfs + (size_t)(z * L + y) * cap; }
-    __device__ int len(int z, int y) const { return lfn[z * L + y] + 1; }
+    __device__ int len(int z, int y) const { return (lfn[z * L + y] + 1) & 0xff; }
     __device__ bool has(int z, int y, int x) const
     {
         const uint8_t *l = list(z, y);
@@ -75,7 +75,7 @@ __device__ static void lb_try(const LbView &s, const PlaceCfg &c, const Counters
         }
 }
 
-__global__ void __launch_bounds__(TAP_BLOCK) k_lb_step(StepArgs a, int16_t *vox, uint8_t *lfs, int8_t *lfn, int cap)
+__global__ void __launch_bounds__(TAP_BLOCK) k_lb_step(StepArgs a, int16_t *vox, uint8_t *lfs, uint8_t *lfn, int cap)
 {
     const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
     const int B = a.d.B;
@@ -212,8 +212,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_lb_step(StepArgs a, int16_t *vox,
                     int n = s.len(pz + zz, py + yy);
                     for (int i = 0; i < n; ++i)
                         if (l[i] == px) { for (int k = i; k + 1 < n; ++k) l[k] = l[k + 1]; --n; break; }
-                    if (px + bx < W && s.v(px + bx, py + yy, pz + zz) == 0 && n < cap) l[n++] = (uint8_t)(px + bx);
-                    s.lfn[(pz + zz) * L + py + yy] = (int8_t)(n - 1);
+                    if (px + bx < W && s.v(px + bx, py + yy, pz + zz) == 0) {
+                        if (n < cap) l[n++] = (uint8_t)(px + bx);
+                        else err |= 16;          // cannot happen while the entries are distinct right edges (<= W of them)
+                    }
+                    s.lfn[(pz + zz) * L + py + yy] = (uint8_t)(n - 1);
                 }
             if (over) err |= 1;
             else

@@ -10,10 +10,13 @@
 
 #include "tapenv.h"
 
+constexpr int TAP_CHK_SLOTS = 64;
+
 struct tap_ctx {
     int device;
     uint32_t *stab_lut; // device: tap_stable3d for footprints <= 4x4 (tap_place.h), built at create
-    int32_t *chk;       // device: 2 ints (flagged envs, OR of their error words) for tap_env_check
+    int32_t *chk;       // device: TAP_CHK_SLOTS x 2 ints (flagged envs, OR of their error words) for tap_env_check
+    unsigned chk_next;  //   next slot
     char err[512];
 };
 
@@ -76,7 +79,7 @@ struct EnvView {
     int32_t *scratch; // LB_GREEDY above 64 cells (big.hip): cells ints per container
     int16_t *vox;     // legacy LB (lb.hip): [B][cells][H] block ids, -1 under covered holes   (tools.py:3630)
     uint8_t *lfs;     //   [B][H*L][W+2] level_free_space lists                                (tools.py:3649-3653)
-    int8_t *lfn;      //   [B][H*L] list length - 1: the zeroed blob is the initial [0] everywhere
+    uint8_t *lfn;     //   [B][H*L] (list length - 1) mod 256: the zeroed blob is the initial [0] everywhere
 };
 
 inline size_t tap_align256(size_t x) { return (x + 255) & ~size_t(255); }
@@ -106,7 +109,7 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
         v->scratch = tap_is_big(d) ? reinterpret_cast<int32_t *>(p + o_scr) : nullptr;
         v->vox = lb ? reinterpret_cast<int16_t *>(p + o_vox) : nullptr;
         v->lfs = lb ? reinterpret_cast<uint8_t *>(p + o_lfs) : nullptr;
-        v->lfn = lb ? reinterpret_cast<int8_t *>(p + o_lfn) : nullptr;
+        v->lfn = lb ? reinterpret_cast<uint8_t *>(p + o_lfn) : nullptr;
         v->hm = reinterpret_cast<int32_t *>(p + o_hm);
         v->cnt = reinterpret_cast<int32_t *>(p + o_cnt);
         v->err = reinterpret_cast<int32_t *>(p + o_err);

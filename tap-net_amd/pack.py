@@ -776,6 +776,7 @@ def create_dataset(blocks_num, train_size, valid_size, obj_dim, initial_containe
         raise NotImplementedError("random-dependency data sets without an initial container (generate_deps_prob)")
     if seed is None:
         seed = np.random.randint(123456789)
+    np.random.seed(seed)                                                          # pack.py:592
     train_dir, valid_dir = _dataset_dirs('rand', blocks_num, train_size, valid_size, obj_dim, initial_container_width, size_range)
     for k, (data_dir, size) in enumerate(((train_dir, train_size), (valid_dir, valid_size))):
         if _have(data_dir):
@@ -803,6 +804,7 @@ def create_dataset_gt(blocks_num, train_size, valid_size, obj_dim, target_contai
         raise NotImplementedError("perfect-packing instances are generated for arm_size 1 (the reference's default)")
     if seed is None:
         seed = np.random.randint(123456789)
+    np.random.seed(seed)                                                          # pack.py:486
     train_dir, valid_dir = _dataset_dirs('gt', blocks_num, train_size, valid_size, obj_dim, initial_container_width, size_range)
     rs = np.random.RandomState(int(seed) % (2 ** 31))
     for k, (data_dir, size) in enumerate(((train_dir, train_size), (valid_dir, valid_size))):
@@ -813,16 +815,26 @@ def create_dataset_gt(blocks_num, train_size, valid_size, obj_dim, target_contai
             continue
         kw = dict(seed=(int(seed) + 7919 * k) % (2 ** 31), device=device, input_type=input_type)
         if obj_dim == 2:
+            # the height restriction of generate_ppsg_instances_2d's default is tuned for size_range (1, 5) at 20 blocks;
+            # any other request draws from the reference's whole height distribution
+            area = (4.9, 8.4) if tuple(size_range) == (1, 5) and blocks_num == 20 else None
             blocks, positions = generate.generate_ppsg_instances_2d(int(size), blocks_num, initial_container_width,
                                                                     initial_container_height, target_container_width,
-                                                                    tuple(size_range), **kw)
+                                                                    tuple(size_range), mean_block_area=area, **kw)
+            note = ("2D perfect-packing instances of tap-net_amd's device generator (generate_blocks_with_GT's steps)%s\n"
+                    % ("; heights restricted to mean block areas 4.9 .. 8.4 (14 .. 24 at W = 7: 90 % of generate_height_prob)"
+                       if area else ""))
         else:
             blocks, positions = generate.generate_ppsg_instances(int(size), blocks_num, initial_container_width,
                                                                  initial_container_height, target_container_width,
                                                                  tuple(size_range), **kw)
+            note = ("3D perfect-packing instances of tap-net_amd's device generator: stacked 10-block BPP_Generator_3D "
+                    "packings (the reference's single acceptance loop does not reach more than ~10 blocks)\n")
         cs = generate.initial_container(obj_dim, initial_container_width, initial_container_height)
         static, dynamic = generate.precedence_tensors(blocks, positions, cs, arm_size)
         datafiles.write_dataset(data_dir, static, dynamic, positions, container_ids=np.tile(ids, (int(size), 1)))
+        with open(data_dir + 'GENERATOR.txt', 'w') as f:                           # tells these files from ones the reference wrote
+            f.write(note)
     return train_dir, valid_dir
 
 

@@ -145,9 +145,9 @@ class RollingDataset(object):
                 maps *= 2
         if input_type == 'mul-with':
             static_dim += 1
-        self.decoder_static = torch.zeros(1, static_dim, 1, device=device)               # rolling.py:529-534
-        self.decoder_dynamic = (torch.zeros(1, width, 1, device=device) if D == 2 else
-                                torch.zeros(1, maps, width, width, device=device))
+        self.decoder_static = torch.zeros(1, static_dim, 1, device=device, requires_grad=True)   # rolling.py:529-534
+        self.decoder_dynamic = (torch.zeros(1, width, 1, device=device, requires_grad=True) if D == 2 else
+                                torch.zeros(1, maps, width, width, device=device, requires_grad=True))
         self.num_samples = N
 
     @staticmethod
