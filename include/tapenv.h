@@ -294,7 +294,8 @@ int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32
 /* One decoding step of rolling.validate in one launch: add_new_block for the column `ptr` picked
  * in the CURRENT window (block gathered from static_cur, the tensor tap_rolling_window / _step
  * wrote last) fused with remove_block + convert_to_input() for the NEXT window (written to
- * static_next, which must be a different buffer).  feature_out as in tap_env_step.  LB_GREEDY. */
+ * static_next, which must be a different buffer).  feature_out as in tap_env_step.  One kernel for LB_GREEDY on
+ * containers of at most 64 cells and instances of at most 64 blocks; otherwise the two launches behind this entry. */
 int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
                      const int32_t *blocks, const uint64_t *rel, uint64_t *state, const int64_t *ptr,
                      const float *static_cur, float *static_next, float *dynamic_out,
@@ -379,7 +380,9 @@ enum {
  * tap_mask_step + tap_env_step_gather fused, so the placement's latency hides under the HBM-bound
  * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
  * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
- * LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D with H <= 512).  feature_out nullable; ratio_out (B,) f32 required with
+ * One kernel for LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D with H <= 512); every other
+ * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY above 64 cells, MACS 2D up to 64 columns) runs the
+ * same step as its two launches behind this entry.  feature_out nullable; ratio_out (B,) f32 required with
  * TAP_T_RATIO. */
 int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                    int update_rows, const float *dyn_in, const float *static_, int static_rows,

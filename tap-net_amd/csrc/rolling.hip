@@ -1033,15 +1033,19 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
-    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: LB_GREEDY on containers of at most 64 cells (use tap_env_step_gather + tap_rolling_window)");
     rc = roll_check(ctx, d->B, d->D, N, child);
     if (rc) return rc;
-    if (N > 64)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "rolling_step: at most 64 blocks per instance (use tap_env_step_gather + tap_rolling_window)");
     if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||
         static_cur == static_next)
         return tap_fail(ctx, TAP_E_INVALID, "bad rolling_step arguments (static_cur and static_next must differ)");
+    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d) || N > 64) {
+        // no single kernel for these (MACS / legacy LB placements, thread-per-container shapes, instances above 64
+        // blocks): the same step as its two launches
+        rc = tap_env_step_gather(ctx, d, env_state, static_cur, 1 + d->D, child * (d->D == 2 ? 2 : 6), ptr, nullptr,
+                                 feature_out, stream);
+        return rc ? rc : tap_rolling_window(ctx, d->B, d->D, N, child, blocks, rel, state, ptr, static_next, dynamic_out,
+                                            colsum_out, bits_out, current_mask_out, nodes_out, err_out, stream);
+    }
     RollStepArgs a = {};
     const int R = d->D == 2 ? 2 : 6;
     a.r.B = d->B; a.r.D = d->D; a.r.N = N; a.r.child = child; a.r.blocks = blocks;

@@ -283,6 +283,22 @@ template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransAr
 
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
 
+// Shapes and strategies whose placement is one THREAD per container (legacy 'LB', LB_GREEDY above 64 cells or a 3D
+// side above 8) or needs the wide MACS 2D form (17 .. 64 columns): no single kernel carries both halves of the step.
+// The tap_transition* entry points then run the same step as its two launches (precedence update, placement) plus
+// reset / calc_ratio where the flags ask for them, so a caller drives every shape through one entry point.
+static bool transition_single_kernel(const tap_env_desc *d)
+{
+    return !(d->strategy == TAP_LB || tap_is_big(d) || (d->strategy == TAP_MACS && d->D == 2 && d->W > 16));
+}
+
+static int transition_tail(tap_ctx *ctx, const tap_env_desc *d, void *state, const TransArgs &a, void *stream)
+{
+    int rc = tap_env_step_gather(ctx, d, state, a.s.static_, a.s.static_rows, a.s.nR, a.s.ptr, nullptr, a.s.feature_out, stream);
+    if (rc == TAP_OK && (a.flags & TAP_T_RATIO)) rc = tap_env_ratio(ctx, d, state, a.ratio_out, nullptr, nullptr, stream);
+    return rc;
+}
+
 static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                              int update_rows, const float *static_, int static_rows, const int64_t *ptr,
                              const float *mask_in, float *current_out, float *mask_out, float *feature_out,
@@ -291,11 +307,7 @@ static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, i
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
-    if (d->strategy == TAP_LB || tap_is_big(d))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "no fused step for the legacy LB strategy or containers above 64 cells: use tap_mask_step + tap_env_step_gather");
     if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
-    if (d->strategy == TAP_MACS && d->D == 2 && d->W > 16)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "no fused step for MACS containers above 16 columns: use tap_mask_step + tap_env_step_gather");
     if (!state || !static_ || !ptr || !mask_in || !current_out || !mask_out || n < 1 || R < 1 || rows < 1 ||
         static_rows < 1 + d->D || update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
@@ -324,6 +336,12 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "transition is out of place (pack.py:370)");
+    if (!transition_single_kernel(d)) {
+        if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
+        rc = tap_mask_step(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, colsum_in, dyn_out,
+                           colsum_out, current_out, mask_out, stream);
+        return rc ? rc : transition_tail(ctx, d, state, a, stream);
+    }
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
                    mask_in, colsum_in, colsum_out, current_out, mask_out, nullptr, nullptr});
     return transition_dispatch(ctx, d, a, stream);
@@ -343,6 +361,12 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
+    if (!transition_single_kernel(d)) {
+        if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
+        rc = tap_mask_step_bits(ctx, d->B, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
+                                dyn_out, current_out, mask_out, stream);
+        return rc ? rc : transition_tail(ctx, d, state, a, stream);
+    }
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                    mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
     if (!mask_bits_ok(a.m))
@@ -363,6 +387,12 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
+    if (!transition_single_kernel(d)) {
+        if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
+        rc = tap_mask_step_first(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,
+                                 dyn_out, current_out, mask_out, nonbinary_out, stream);
+        return rc ? rc : transition_tail(ctx, d, state, a, stream);
+    }
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
                    mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out});
     if (!mask_bits_ok(a.m))

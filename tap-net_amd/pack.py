@@ -387,9 +387,10 @@ class MaskStepper(object):
 
 
 class EnvTransition(MaskStepper):
-    """One launch per decoding step: update_dynamic + update_mask + gather + add_new_block
-    (tap_transition), optionally starting from a fresh container and optionally emitting
-    calc_ratio."""
+    """One call per decoding step: update_dynamic + update_mask + gather + add_new_block
+    (tap_transition*), optionally starting from a fresh container and optionally emitting
+    calc_ratio -- ONE kernel for the lane-per-cell shapes, the same step as its two launches behind the
+    same entry point for the others (``env.fused_ok`` tells which)."""
 
     def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True, bits=None):
         super(EnvTransition, self).__init__(static, dynamic, input_type, allow_rot, bits)
@@ -402,14 +403,6 @@ class EnvTransition(MaskStepper):
         import ctypes as C
         ptr = ptr.to(device=self.dynamic.device, dtype=torch.int64).contiguous()
         self._check_step_args(ptr, dyn_out)
-        if not self.env.fused_ok:
-            # strategies / shapes without a fused step (legacy 'LB', LB_GREEDY above 64 cells or a 3D side above 8,
-            # MACS 2D above 16 columns): the same step as two launches
-            if fresh:
-                self.env.reset()
-            out, cur, new = MaskStepper.step(self, ptr, dyn_out)
-            feat = self.env.add_new_blocks_gather(self.static, ptr, want_feature=want_feature)
-            return out, cur, new, feat, (self.env.calc_ratios() if want_ratio else None)
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)

@@ -184,7 +184,8 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
     decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
     ar = torch.arange(B, device=dev)
     tour, picked, feats = [], [], []
-    fused = fused and env.desc.strategy == _lib.TAP_LB_GREEDY and env.fused_ok and N <= 64
+    # fused: tap_rolling_step per decoding step -- one kernel for LB_GREEDY on lane-per-cell containers and N <= 64, the
+    # placement and the window launch behind the same entry point otherwise
     ptr, ratio, step = None, None, 0
     win = rw.next(None)
     for _ in range(N - child):                                   # one_step windows

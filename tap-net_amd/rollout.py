@@ -75,8 +75,6 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     dev = _lib.resolve_device(static.device)
     if env is None:
         env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
-    if not env.fused_ok:                                          # legacy LB / containers above 64 cells
-        fused = False
     if fused:
         masks = EnvTransition(static.to(dev), dynamic.to(dev), env, input_type, allow_rot, bits)
     else:
