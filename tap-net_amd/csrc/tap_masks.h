@@ -388,10 +388,21 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
             const u64 n0 = w[k][0].x & ~clr, n1 = w[k][0].y & ~clr, n2 = w[k][1].x & ~clr, n3 = w[k][1].y & ~clr;
             if (a.dyn_out) {
                 float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
-                for (int r = rsub; r < rows; r += RP) {
-                    const float4 v = make_float4(bit_as_float(n0, r), bit_as_float(n1, r), bit_as_float(n2, r),
-                                                 bit_as_float(n3, r));
-                    store_stream(&dst[(size_t)r * C4], v);
+                if (rows <= 32) {
+                    // n <= 10 (every BASELINE window): the column words fit 32 bits -- a bit-field extract and a
+                    // convert per element, no half selection
+                    const unsigned m0 = (unsigned)n0, m1 = (unsigned)n1, m2 = (unsigned)n2, m3 = (unsigned)n3;
+                    for (int r = rsub; r < rows; r += RP) {
+                        const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
+                                                     (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
+                        store_stream(&dst[(size_t)r * C4], v);
+                    }
+                } else {
+                    for (int r = rsub; r < rows; r += RP) {
+                        const float4 v = make_float4(bit_as_float(n0, r), bit_as_float(n1, r), bit_as_float(n2, r),
+                                                     bit_as_float(n3, r));
+                        store_stream(&dst[(size_t)r * C4], v);
+                    }
                 }
             }
             if (rsub == 0 && a.bits_out) {

@@ -411,7 +411,7 @@ static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransA
         default: return launch_transition_macs3<64>(ctx, a, (hipStream_t)stream);
         }
     }
-    if (d->strategy == TAP_MACS)
+    if (d->strategy == TAP_MACS)   // (16 lanes per container for W <= 8 measured 2.3 x slower at c4: the per-lane work grows with G)
         return d->W <= 8 ? launch_transition_macs<8>(ctx, a, (hipStream_t)stream)
                          : launch_transition_macs<16>(ctx, a, (hipStream_t)stream);
     if (d->D == 2) {
