@@ -334,7 +334,8 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
 /* ---- the same two seams on a bit shadow of `dynamic` ------------------------------------ */
 /* `dynamic` only ever holds 0 and 1 (the precedence matrices PACKDataset builds, pack.py:101-195;
  * update_dynamic only writes zeros, pack.py:370-374).  Carried as a (B, nR) uint64 shadow -- word j
- * of env b = column j, bit r = dynamic[b, r, j] != 0, rows <= 64 -- a step no longer re-reads the
+ * of env b = column j, bit r = dynamic[b, r, j] != 0; for 65 <= rows <= 128 (windows of 22 .. 42 nodes) the
+ * shadow is (B, 2, nR): plane 0 = rows 0..63, plane 1 = rows 64..127 -- a step no longer re-reads the
  * fp32 tensor: clearing the chosen rows is an AND, the column sums of pack.py:323-326 are popcounts,
  * and the fp32 tensor the network consumes next (model.py:378) is expanded from the bits, so the
  * step WRITES rows*nR*4 bytes per env and reads nR*8.  Outputs are bit-identical to tap_mask_step /
@@ -342,7 +343,7 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
 
 /* bits_out = shadow of dynamic; *nonbinary_out (device int32, nullable, caller zeroes it) is
  * incremented by the number of elements that are neither 0 nor 1 -- the shadow is only valid at 0.
- * bits_out NULL: count only (then rows may exceed 64). */
+ * bits_out NULL: count only (then rows may exceed 128). */
 int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
                  unsigned long long *bits_out, int32_t *nonbinary_out, void *stream);
 
@@ -352,7 +353,7 @@ int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
  * unused) gives the initial mask of model.py:297-307.  A ptr outside [0, nR) -- the reference's gather
  * raises -- clears no row and removes no column, here and in tap_update_dynamic / tap_mask_step /
  * tap_transition* (whose placement half also raises error bit 4 for it).  Requires nR % 4 == 0, nR <= 256,
- * rows <= 64, 16-byte aligned buffers, bits_in != bits_out. */
+ * rows <= 128, 16-byte aligned buffers, bits_in != bits_out. */
 int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
                        const unsigned long long *bits_in, const float *static_, int static_rows,
                        const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
@@ -390,7 +391,8 @@ int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int 
                    float *dyn_out, float *colsum_out, float *current_out, float *mask_out,
                    float *feature_out, float *ratio_out, int flags, void *stream);
 
-/* tap_transition with the precedence update done on the bit shadow (tap_mask_step_bits). */
+/* tap_transition with the precedence update done on the bit shadow (tap_mask_step_bits).  The single kernels
+ * carry the one-word shadow (rows <= 64); with the two-word shadow the step runs as its two launches. */
 int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                         int update_rows, const unsigned long long *bits_in, const float *static_,
                         int static_rows, const int64_t *ptr, const float *mask_in,

@@ -41,13 +41,17 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_bits(int B, int nR, int rows,
     const float *slab = dyn + (size_t)env * rows * nR;
     int bad = 0;
     for (int j = lane; j < nR; j += WAVE) {
-        unsigned long long w = 0;
+        unsigned long long w = 0, w2 = 0;
         for (int r = 0; r < rows; ++r) {
             const float v = slab[(size_t)r * nR + j];
-            w |= (unsigned long long)(v != 0.f) << (r & 63);
+            if (r < 64) w |= (unsigned long long)(v != 0.f) << r;
+            else w2 |= (unsigned long long)(v != 0.f) << (r & 63);
             bad += (v != 0.f && v != 1.f);
         }
-        if (bits) bits[(size_t)env * nR + j] = w;         // null: count only (any number of rows)
+        if (bits) {                                        // null: count only (any number of rows)
+            if (rows <= 64) bits[(size_t)env * nR + j] = w;
+            else { bits[(size_t)env * 2 * nR + j] = w; bits[((size_t)env * 2 + 1) * nR + j] = w2; } // two planes
+        }
     }
     if (bad && nonbinary) atomicAdd(nonbinary, bad);
 }
@@ -57,7 +61,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_bits(int B, int nR, int rows,
 // given); NC == 0 = the generic
 // element-wise path, which also serves tap_update_mask (no copy) and tap_update_dynamic without a
 // shadow.
-// MODE: 0 = fp32 copy with the column-sum shadow (or the generic path), 1 = bit shadow, 2 = first step
+// MODE: 0 = fp32 copy with the column-sum shadow (or the generic path), 1 = bit shadow, 2 = first step;
+// 3 / 4 = the same two on the two-word shadow (65 .. 128 rows)
 template <int NC, int MODE>
 __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
 {
@@ -68,7 +73,9 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
     if (env >= a.B) return;
     if (NC > 0) {
         const bool on[1] = {true};
-        if (MODE == 1) stream_wave_bits<1, (NC > 0 ? NC : 1), false>(a, env, lane, on);
+        if (MODE == 3) stream_wave_bits2<(NC > 0 ? NC : 1), false>(a, env, lane, nullptr);
+        else if (MODE == 4) stream_wave_bits2<(NC > 0 ? NC : 1), true>(a, env, lane, mask_lds + (size_t)wave * 4 * a.nR);
+        else if (MODE == 1) stream_wave_bits<1, (NC > 0 ? NC : 1), false>(a, env, lane, on);
         else if (MODE == 2) stream_wave_bits<1, (NC > 0 ? NC : 1), true>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         else stream_wave_fast<1, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         return;
@@ -98,10 +105,11 @@ static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)
 {
     const int grid = (a.B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
-    const size_t lds = (size_t)ENVS_PER_BLOCK * 3 * a.nR * sizeof(float);
-    const int mode = a.bits_in ? 1 : mask_builds_bits(a) ? 2 : 0;
+    const bool wide = (a.bits_in || mask_builds_bits(a)) && a.rows > 64;     // two words per column
+    const size_t lds = (size_t)ENVS_PER_BLOCK * (wide ? 4 : 3) * a.nR * sizeof(float);
+    const int mode = (a.bits_in ? 1 : mask_builds_bits(a) ? 2 : 0) + (wide ? 2 : 0);
 #define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_mask_step<NC_, M_>), dim3(grid), dim3(TAP_BLOCK), LDS_, st, a)
-#define TAP_LAUNCH_M(NC_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, lds); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, lds); else TAP_LAUNCH_T(NC_, 0, lds); } while (0)
+#define TAP_LAUNCH_M(NC_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, lds); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, lds); else if (mode == 3) TAP_LAUNCH_T(NC_, 3, lds); else if (mode == 4) TAP_LAUNCH_T(NC_, 4, lds); else TAP_LAUNCH_T(NC_, 0, lds); } while (0)
     switch (mask_fast_path_cols(a)) {
     case 1: TAP_LAUNCH_M(1); break;
     case 2: TAP_LAUNCH_M(2); break;
@@ -141,7 +149,7 @@ extern "C" int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *
 {
     if (B < 0 || nR < 1 || rows < 1) return tap_fail(ctx, TAP_E_INVALID, "bad shape B=%d nR=%d rows=%d", B, nR, rows);
     if (B == 0) return TAP_OK;
-    if (rows > 64 && bits_out) return tap_fail(ctx, TAP_E_UNSUPPORTED, "the bit shadow holds at most 64 rows (rows=%d)", rows);
+    if (rows > 128 && bits_out) return tap_fail(ctx, TAP_E_UNSUPPORTED, "the bit shadow holds at most 128 rows (rows=%d)", rows);
     if (!dynamic || (!bits_out && !nonbinary_out)) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     const int grid = (B + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     if (grid == 0) return TAP_OK;
@@ -165,7 +173,7 @@ extern "C" int tap_mask_step_bits(tap_ctx *ctx, int B, int n, int R, int rows, i
     MaskArgs a = mask_finish(MaskArgs{B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                   mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
     if (!mask_bits_ok(a))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
     return launch_mask_step(ctx, a, (hipStream_t)stream);
 }
 
@@ -183,7 +191,7 @@ extern "C" int tap_mask_step_first(tap_ctx *ctx, int B, int n, int R, int rows, 
     MaskArgs a = mask_finish(MaskArgs{B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
                   mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out});
     if (!mask_bits_ok(a))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
     return launch_mask_step(ctx, a, (hipStream_t)stream);
 }
 

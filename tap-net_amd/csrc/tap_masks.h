@@ -428,11 +428,153 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
     }
 }
 
-// the bit shadow needs 16-byte rows of words and float4 rows
+// ---- the bit shadow with TWO words per column: 65 <= rows <= 128 (windows of 22 .. 42 nodes) -------------
+// Plane w of env b (rows 64w .. 64w + 63) lives at bits[(b*2 + w)*nR + j]; everything else is the step above
+// (one round trip, `real` by shuffle, lane (rsub, c4) expands the float4 of rows rsub, rsub + RP, ...).  One
+// slab per wave; lds: 2*nR words for the first-step form.
+__host__ __device__ __forceinline__ int mask_bit_planes(int rows) { return rows > 64 ? 2 : 1; }
+
+__device__ __forceinline__ unsigned long long bits_range64(int a, int b) // bits [a, b) clipped to [0, 64)
+{
+    a = a < 0 ? 0 : a;
+    b = b > 64 ? 64 : b;
+    if (a >= b) return 0ull;
+    return ((b - a) >= 64 ? ~0ull : ((1ull << (b - a)) - 1ull)) << a;
+}
+
+template <int NC, bool BUILD>
+__device__ __forceinline__ void stream_wave_bits2(const MaskArgs &a, int env, int lane, float *lds)
+{
+    typedef unsigned long long u64;
+    const int nR = a.nR, C4 = nR >> 2, rows = a.rows;
+    const int rsub = (int)(((unsigned)lane * (unsigned)a.c4_magic) >> 16), c4 = lane - rsub * C4, RP = a.rp;
+    const bool lane_on = rsub < RP;
+    u64 *tile = reinterpret_cast<u64 *>(lds);
+    const long p = a.ptr ? (long)a.ptr[env] : -1;                            // no ptr: the initial mask
+    float row0[NC], keep[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = lane + 64 * c;
+        const bool ok = j < nR;
+        row0[c] = (ok && a.static_) ? a.static_[(size_t)env * a.static_rows * nR + j] : 0.f;
+        keep[c] = ok ? (a.mask_in ? a.mask_in[(size_t)env * nR + j] : 1.f) : 0.f;
+    }
+    if (BUILD) {
+        for (int i = lane; i < 2 * nR; i += 64) tile[i] = 0ull;
+        tap_wave_lds_sync_m();
+        int bad = 0;
+        constexpr int U = 4;
+        const float4 *src = reinterpret_cast<const float4 *>(a.dyn_in + (size_t)env * rows * nR) + c4;
+        u64 acc[2][4] = {{0ull, 0ull, 0ull, 0ull}, {0ull, 0ull, 0ull, 0ull}};
+        for (int r0 = rsub; r0 < rows; r0 += U * RP) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) v[u] = src[(size_t)min(r0 + u * RP, rows - 1) * C4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int r = r0 + u * RP;
+                if (r >= rows || !lane_on) continue;
+                const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u64 nz = e[q] != 0.f;
+                    bad += (nz && e[q] != 1.f);
+                    if (r < 64) acc[0][q] |= nz << r; else acc[1][q] |= nz << (r - 64);
+                }
+            }
+        }
+        if (lane_on) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (acc[w][q]) atomicOr(&tile[w * nR + c4 * 4 + q], acc[w][q]);
+        }
+        if (a.nonbinary) {
+            const unsigned long long any = __ballot(bad != 0);
+            if (any) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o);
+                if (lane == 0) atomicAdd(a.nonbinary, bad);
+            }
+        }
+        tap_wave_lds_sync_m();
+    }
+    const u64 *win = BUILD ? tile : a.bits_in + (size_t)env * 2 * nR;
+    u64 bj[NC][2], w4[2][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = lane + 64 * c;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) bj[c][w] = j < nR ? win[w * nR + j] : 0ull;
+    }
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(win + w * nR + c4 * 4);
+        const ulonglong2 s0 = lane_on ? src[0] : make_ulonglong2(0, 0), s1 = lane_on ? src[1] : make_ulonglong2(0, 0);
+        w4[w][0] = s0.x; w4[w][1] = s0.y; w4[w][2] = s1.x; w4[w][3] = s1.y;
+    }
+    float r0 = -1.f;                                                          // pack.py:339 via shuffle
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float t = __shfl(row0[c], (int)(p & 63));
+        if ((p >> 6) == c && p >= 0 && p < nR) r0 = t;
+    }
+    const long real = (long)r0;
+    u64 clr[2] = {0ull, 0ull};                                                // pack.py:370-374
+    for (int i = 0; i < a.update_rows; ++i) {
+        const long r = real + (long)a.n * i;
+        if (real >= 0 && r < rows) { if (r < 64) clr[0] |= 1ull << r; else clr[1] |= 1ull << (r - 64); }
+    }
+    if (lane_on) {
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w4[w][q] &= ~clr[w];
+        if (a.dyn_out) {
+            float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
+            for (int r = rsub; r < rows; r += RP) {
+                const bool up = r >= 64;
+                const int rb = r & 63;
+                const float4 v = make_float4(bit_as_float(up ? w4[1][0] : w4[0][0], rb), bit_as_float(up ? w4[1][1] : w4[0][1], rb),
+                                             bit_as_float(up ? w4[1][2] : w4[0][2], rb), bit_as_float(up ? w4[1][3] : w4[0][3], rb));
+                store_stream(&dst[(size_t)r * C4], v);
+            }
+        }
+        if (rsub == 0 && a.bits_out) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + ((size_t)env * 2 + w) * nR + c4 * 4);
+                dst[0] = make_ulonglong2(w4[w][0], w4[w][1]);
+                dst[1] = make_ulonglong2(w4[w][2], w4[w][3]);
+            }
+        }
+    }
+    const long real_m = (p >= 0 && p < nR) ? tap_mod_col(p, a.n, a.nR) : -1 - (long)a.n * a.R;    // pack.py:314-316
+    const int n = a.n;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int j = lane + 64 * c;
+        if (j >= nR) continue;
+        const u64 lo = bj[c][0] & ~clr[0], hi = bj[c][1] & ~clr[1];
+        int sec[3];                                                           // pack.py:323-326 as popcounts
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+            sec[s] = __popcll(lo & bits_range64(s * n, (s + 1) * n)) + __popcll(hi & bits_range64(s * n - 64, (s + 1) * n - 64));
+        float kp = keep[c];
+        for (int r = 0; r < a.R; ++r)
+            if (j == real_m + (long)n * r) kp = 0.f;                          // pack.py:320-321
+        if (a.mask_out) a.mask_out[(size_t)env * nR + j] = kp;
+        if (a.cur_out) a.cur_out[(size_t)env * nR + j] = (sec[1] * sec[2] + sec[0]) != 0 ? 0.f : kp; // :327-329
+    }
+}
+
+// the bit shadow needs 16-byte rows of words and float4 rows; rows <= 64: one word per column (every kernel that
+// carries the step), 65 .. 128: two (masks.hip's stand-alone step; the fused entry points run it as their first launch)
 inline bool mask_bits_ok(const MaskArgs &a)
 {
     return (a.bits_in || mask_builds_bits(a)) && (a.ptr == nullptr || a.static_ != nullptr) && (a.nR % 4 == 0) &&
-           a.nR <= 256 && a.rows >= 1 && a.rows <= 64 &&
+           a.nR <= 256 && a.rows >= 1 && a.rows <= 128 &&
            ((reinterpret_cast<uintptr_t>(a.dyn_out) | reinterpret_cast<uintptr_t>(a.dyn_in)) % 16 == 0) &&
            ((reinterpret_cast<uintptr_t>(a.bits_in) | reinterpret_cast<uintptr_t>(a.bits_out)) % 16 == 0);
 }

@@ -361,7 +361,7 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
-    if (!transition_single_kernel(d)) {
+    if (!transition_single_kernel(d) || rows > 64) {      // the fused kernels carry the one-word shadow only
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_bits(ctx, d->B, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
                                 dyn_out, current_out, mask_out, stream);
@@ -370,7 +370,7 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                    mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
     if (!mask_bits_ok(a.m))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);
 }
 
@@ -387,7 +387,7 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
-    if (!transition_single_kernel(d)) {
+    if (!transition_single_kernel(d) || rows > 64) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_first(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,
                                  dyn_out, current_out, mask_out, nonbinary_out, stream);
@@ -396,7 +396,7 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
                    mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out});
     if (!mask_bits_ok(a.m))
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 64, 16-byte aligned buffers");
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);
 }
 

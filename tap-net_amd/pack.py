@@ -261,7 +261,7 @@ def first_shadow_and_mask(dynamic, blocks_num, counter=None):
         counter = _deferred.get(dev.index)
         if counter is None:
             counter = _deferred[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
-    bits = torch.empty(B, nR, dtype=torch.int64, device=dev)
+    bits = torch.empty(B, _bit_planes(rows) * nR, dtype=torch.int64, device=dev)
     cur = torch.empty(B, nR, dtype=torch.float32, device=dev)
     mask = torch.empty(B, nR, dtype=torch.float32, device=dev)
     c = _lib.ctx(dev)
@@ -273,18 +273,24 @@ def first_shadow_and_mask(dynamic, blocks_num, counter=None):
 
 
 def bits_supported(rows, nR):
-    """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_mask_step_bits)."""
-    return rows <= 64 and nR % 4 == 0 and nR <= 256
+    """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_mask_step_bits): one word per column up to 64
+    rows (windows of at most 21 nodes), two up to 128 rows (42 nodes)."""
+    return rows <= 128 and nR % 4 == 0 and nR <= 256
+
+
+def _bit_planes(rows):
+    return 2 if rows > 64 else 1
 
 
 def dynamic_bits(dynamic, counter=None, want_bits=True):
-    """Bit shadow of a 0/1-valued ``dynamic`` (B, rows <= 64, nR): -> (bits (B, nR) int64 with bit r of
-    word j = dynamic[b, r, j] != 0, nonbinary (1,) int32 = number of elements that are neither 0 nor 1;
+    """Bit shadow of a 0/1-valued ``dynamic`` (B, rows <= 128, nR): -> (bits (B, nR) int64 with bit r of
+    word j = dynamic[b, r, j] != 0 -- above 64 rows (B, 2*nR): plane 0 = rows 0..63, plane 1 = rows 64.. --,
+    nonbinary (1,) int32 = number of elements that are neither 0 nor 1;
     the shadow stands for the tensor only when that count is 0).  ``counter``: accumulate the count into
     this device int32 instead of a fresh one; ``want_bits`` False: count only (any number of rows)."""
     dyn = _f32c(dynamic)
     B, rows, nR = dyn.shape
-    bits = torch.empty(B, nR, dtype=torch.int64, device=dyn.device) if want_bits else None
+    bits = torch.empty(B, _bit_planes(rows) * nR, dtype=torch.int64, device=dyn.device) if want_bits else None
     bad = counter if counter is not None else torch.zeros(1, dtype=torch.int32, device=dyn.device)
     c = _lib.ctx(dyn.device)
     with torch.cuda.device(dyn.device):
@@ -325,7 +331,7 @@ class MaskStepper(object):
                 self.bits = st
             self.nonbinary = isinstance(st, str) and st == 'nonbinary'
         if bits is True and self.bits is None:
-            raise ValueError("dynamic cannot be carried as a bit shadow (needs rows <= 64, nR % 4 == 0, "
+            raise ValueError("dynamic cannot be carried as a bit shadow (needs rows <= 128, nR % 4 == 0, "
                              "nR <= 256 and only 0/1 values)")
         if self.bits is None:                            # the column sums are only needed without the shadow
             self.colsum = dynamic_colsum(self.dynamic, self.n)
