@@ -599,12 +599,189 @@ __device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, i
     PROF(7);
 }
 
+
+// ---- 65 .. 128 blocks per instance: still ONE wavefront per instance, lane v = nodes v and v + 64 -------------
+// Every graph is two 64-bit words per node (the layout k_rolling_init_big writes: NW = 2 words per mask, the N
+// movement masks first, then per node its four side masks), the state is (entered, window) of two words each, held
+// wave-uniform.  The steps are the ones above: layers are two ballots, a node's rank counts both words.  The
+// emission turns every window node's masks into words over the sub-graph ROWS first (bit rm = node ord[rm]), after
+// which nothing depends on N any more.  Windows of at most 32 nodes (side[k][2*slot + word] fills the relation
+// slots exactly); the tensor goes out packed (rolling_emit_wave's float4 expansion) when it has the bit-shadow
+// shape, element by element otherwise.
+constexpr int ROLL_CH_WIDE = -2;      // template tag: this form instead of the one-word graph step
+
+template <int D>
+__device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, RollLds &S)
+{
+    if (inst >= a.B) return;
+    const int N = a.N, child = a.child;
+    constexpr int R = D == 2 ? 2 : 6, NW = 2;
+    const int nRc = child * R;
+    const u64 all_lo = ~0ull, all_hi = N >= 128 ? ~0ull : ((1ull << (N - 64)) - 1ull);
+    const u64 bit = 1ull << v, below = bit - 1ull;
+    const bool has_hi = v + 64 < N;                                   // this lane's second node exists
+    auto uniform64 = [](u64 x) -> u64 {
+        return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)x);
+    };
+    const u64 *relb = a.rel + (size_t)inst * 5 * N * NW;
+    const ulonglong2 *mv = reinterpret_cast<const ulonglong2 *>(relb);
+    const ulonglong2 m_lo = mv[v], m_hi = has_hi ? mv[v + 64] : make_ulonglong2(0ull, 0ull);
+    u64 *stp = a.state + (size_t)inst * 2 * NW;
+    const u64 s0 = stp[0], s1 = stp[1], s2 = stp[2], s3 = stp[3];
+    const long ptr_raw = a.remove_ptr ? (long)a.remove_ptr[inst] : 0;
+    u64 e_lo = uniform64(s0), e_hi = uniform64(s1), w_lo = uniform64(s2), w_hi = uniform64(s3);
+
+    // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
+    if (a.remove_ptr) {
+        const long slot = tap_mod_col((long)uniform64((u64)ptr_raw), child, nRc);
+        const int nlo = __popcll(w_lo);
+        const bool hit_lo = (w_lo & bit) && __popcll(w_lo & below) == slot;
+        const bool hit_hi = (w_hi & bit) && nlo + __popcll(w_hi & below) == slot;
+        w_lo &= ~__ballot(hit_lo);
+        w_hi &= ~__ballot(hit_hi);
+    }
+    // (2) top the window up (generate.py:1724-1750)
+    int count = __popcll(w_lo) + __popcll(w_hi);
+    if (w_lo & bit) S.lst[__popcll(w_lo & below)] = (unsigned char)v;
+    if (w_hi & bit) S.lst[__popcll(w_lo) + __popcll(w_hi & below)] = (unsigned char)(v + 64);
+    u64 a_lo = 0, a_hi = 0;
+    while (count < child) {
+        const u64 g_lo = all_lo & ~(e_lo | a_lo), g_hi = all_hi & ~(e_hi | a_hi);     // nodes still in gm_copy
+        const bool single = __popcll(g_lo) + __popcll(g_hi) == 1;
+        const bool f_lo = (g_lo & bit) && (single || ((m_lo.x & g_lo) | (m_lo.y & g_hi)) == 0);
+        const bool f_hi = has_hi && (g_hi & bit) && (single || ((m_hi.x & g_lo) | (m_hi.y & g_hi)) == 0);
+        const u64 fm_lo = __ballot(f_lo), fm_hi = __ballot(f_hi);
+        if ((fm_lo | fm_hi) == 0) break;
+        const int need = child - count;
+        const int r_lo = __popcll(fm_lo & below), r_hi = __popcll(fm_lo) + __popcll(fm_hi & below);
+        const bool t_lo = f_lo && r_lo < need, t_hi = f_hi && r_hi < need;
+        if (t_lo) S.lst[count + r_lo] = (unsigned char)v;
+        if (t_hi) S.lst[count + r_hi] = (unsigned char)(v + 64);
+        const u64 tm_lo = __ballot(t_lo), tm_hi = __ballot(t_hi);
+        a_lo |= tm_lo; a_hi |= tm_hi;
+        count += __popcll(tm_lo) + __popcll(tm_hi);
+    }
+    e_lo |= a_lo; e_hi |= a_hi;
+    w_lo |= a_lo; w_hi |= a_hi;
+    const int short_window = count != child;
+    const bool in_lo = (w_lo & bit) != 0, in_hi = (w_hi & bit) != 0;
+    const int nlo = __popcll(w_lo);
+    // the window nodes' side records and block sides, in flight under the set order
+    ulonglong2 sd[2][4];
+    int bd[2][3] = {{0, 0, 0}, {0, 0, 0}};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const bool on = (h ? in_hi : in_lo) && !short_window;
+        const int node = v + 64 * h;
+        const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(relb + (size_t)N * NW + (size_t)node * 4 * NW);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sd[h][k] = on ? q[k] : make_ulonglong2(0ull, 0ull);
+#pragma unroll
+        for (int k = 0; k < D; ++k) bd[h][k] = on ? a.blocks[((size_t)inst * N + node) * D + k] : 0;
+    }
+    tap_wave_lds_sync();
+
+    // (3) node order of the induced sub-graphs: 2 * child <= 64 < N, always the set order (:1684-1688, 1758-1761)
+    if (!short_window) {
+        if (child <= 18) pyset_order_wave(S.lst, child, S.ord, v);
+        else if (v == 0) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
+    }
+    tap_wave_lds_sync();
+    if (v == 0) {
+        stp[0] = e_lo; stp[1] = e_hi; stp[2] = w_lo; stp[3] = w_hi;
+        if (a.err_out) a.err_out[inst] = short_window;
+    }
+    if (short_window) return;
+
+    // (4) tensors (generate.py:1778-1822).  Scratch inside the (now idle) set-order tables: cw (packed form, at most
+    //     126 columns) | iw: 5*child row words | dims: the block sides by sorted slot
+    unsigned *iw = reinterpret_cast<unsigned *>(S.tbl) + 256;
+    int *dims = S.tbl + 416;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (!(h ? in_hi : in_lo)) continue;
+        const int node = v + 64 * h;
+        const int slot = h ? nlo + __popcll(w_hi & below) : __popcll(w_lo & below);    // sorted position
+        const ulonglong2 m0 = h ? m_hi : m_lo;
+        S.side[0][2 * slot] = m0.x; S.side[0][2 * slot + 1] = m0.y;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { S.side[1 + k][2 * slot] = sd[h][k].x; S.side[1 + k][2 * slot + 1] = sd[h][k].y; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) dims[slot * 3 + k] = bd[h][k];
+        S.srt[slot] = (unsigned char)node;
+        if (a.nodes_out) a.nodes_out[(size_t)inst * child + slot] = node;
+    }
+    tap_wave_lds_sync();
+    const u64 af_lo = all_lo & ~e_lo, af_hi = all_hi & ~e_hi;          // after_nodes_list
+    for (int idx = v; idx < 5 * child; idx += 64) {                    // (relation k, sub-graph column cm)
+        const int k = idx / child, cm = idx - k * child;
+        const int u = S.ord[cm];
+        const int slot = u < 64 ? __popcll(w_lo & ((1ull << u) - 1ull)) : nlo + __popcll(w_hi & ((1ull << (u - 64)) - 1ull));
+        u64 lo = S.side[k][2 * slot], hi = S.side[k][2 * slot + 1];
+        // :1690-1705: a blocker that has not entered any window yet => the side counts as self-blocked
+        const bool selfb = k > 0 && ((lo & af_lo) | (hi & af_hi)) != 0;
+        lo &= w_lo; hi &= w_hi;
+        if (selfb) { if (u < 64) lo |= 1ull << u; else hi |= 1ull << (u - 64); }
+        unsigned w = 0u;
+        for (int rm = 0; rm < child; ++rm) {
+            const int node = S.ord[rm];
+            w |= (unsigned)(((node >= 64 ? hi : lo) >> (node & 63)) & 1ull) << rm;
+        }
+        iw[idx] = w;
+    }
+    tap_wave_lds_sync();
+    const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
+    const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
+    float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
+    const int rows = 3 * child;
+    const bool packed = rows <= 64 && (nRc & 3) == 0 && nRc <= 128;
+    for (int col = v; col < nRc; col += 64) {
+        const int r = col / child, cm = col - r * child;
+        const int *p = D == 2 ? perm2[r] : perm3[r];
+        st[col] = (float)cm;                                                          // :1795-1801, cm = sorted slot
+        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)dims[cm * 3 + p[k]];
+        unsigned ws[3];
+#pragma unroll
+        for (int sec = 0; sec < 3; ++sec) {                                           // :1808-1821, cm = sub-graph index
+            int k = 0;
+            if (sec > 0) k = p[D - 1] == 0 ? sec : (D == 3 && p[D - 1] == 1) ? 2 + sec : -1;
+            ws[sec] = k < 0 ? 0u : iw[k * child + cm];
+            if (a.colsum_out) a.colsum_out[((size_t)inst * 3 + sec) * nRc + col] = (float)__popc(ws[sec]);
+        }
+        if (a.cur_mask_out)                                                           // model.py:297-307
+            a.cur_mask_out[(size_t)inst * nRc + col] = (__popc(ws[1]) * __popc(ws[2]) + __popc(ws[0]) != 0) ? 0.f : 1.f;
+        if (packed) {
+            const u64 w = (u64)ws[0] | ((u64)ws[1] << child) | ((u64)ws[2] << (2 * child));
+            S.cw[col] = w;
+            if (a.bits_out) a.bits_out[(size_t)inst * nRc + col] = w;
+        } else {
+            for (int rm = 0; rm < child; ++rm)
+#pragma unroll
+                for (int sec = 0; sec < 3; ++sec)
+                    dy[(size_t)(sec * child + rm) * nRc + col] = (float)((ws[sec] >> rm) & 1u);
+        }
+    }
+    if (!packed) return;
+    tap_wave_lds_sync();
+    const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
+    if (rsub < RP) {
+        const u64 c0 = S.cw[c4 * 4], c1 = S.cw[c4 * 4 + 1], c2 = S.cw[c4 * 4 + 2], c3 = S.cw[c4 * 4 + 3];
+        float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
+        for (int rw = rsub; rw < rows; rw += RP)
+            store_stream(&dst[(size_t)rw * C4], make_float4(bit_as_float(c0, rw), bit_as_float(c1, rw), bit_as_float(c2, rw),
+                                                            bit_as_float(c3, rw)));
+    }
+}
+
 template <int D, int CH>
 __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
 {
+    if constexpr (CH == ROLL_CH_WIDE) { rolling_window_wave2<D>(a, inst, v, S); return; }
     if (inst >= a.B) return;
     PROF_BEGIN;
-    const int N = a.N, child = CH ? CH : a.child;
+    const int N = a.N, child = CH > 0 ? CH : a.child;
     constexpr int R = D == 2 ? 2 : 6;
     const int nRc = child * R;
     const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
@@ -680,6 +857,8 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
 
 // window sizes with a compile-time-shaped kernel (0 = any window, shapes read from the arguments)
 __host__ __device__ constexpr bool roll_fast_ok(int D, int child) { return child == 10 && (D == 2 || D == 3); }
+// instances the two-word wavefront form takes (rolling_window_wave2)
+__host__ __device__ constexpr bool roll_wide_ok(int N, int child) { return N > 64 && N <= 128 && child <= 32; }
 
 // 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
 // were resident, so one workgroup in eight ran as a second round
@@ -986,6 +1165,12 @@ extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, 
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bits_out needs 3*child <= 64, (child*R) %% 4 == 0, child*R <= 256");
     const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
     if (grid == 0) return TAP_OK;
+    if (roll_wide_ok(N, child)) {                                     // 65 .. 128 blocks: one wavefront per instance
+        if (D == 2) hipLaunchKernelGGL((k_rolling_window<2, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((k_rolling_window<3, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        TAP_LAUNCH_CHECK(ctx, "k_rolling_window(wide)");
+        return TAP_OK;
+    }
     if (N > 64) {                                                     // one thread per instance
         if (child > 76) return tap_fail(ctx, TAP_E_UNSUPPORTED, "window too large for the set-order table");
         const int g2 = (B + 63) / 64;
@@ -1012,7 +1197,10 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
     const int grid = (a.r.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     const bool hard = a.s.d.flags & TAP_F_HARD;              // soft rewards: no hard-mode walk compiled in
-    if (roll_fast_ok(D, a.r.child)) {
+    if (a.r.N > 64) {
+        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, a);
+        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, a);
+    } else if (roll_fast_ok(D, a.r.child)) {
         if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
         else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
     } else {
@@ -1038,8 +1226,8 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||
         static_cur == static_next)
         return tap_fail(ctx, TAP_E_INVALID, "bad rolling_step arguments (static_cur and static_next must differ)");
-    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d) || N > 64) {
-        // no single kernel for these (MACS / legacy LB placements, thread-per-container shapes, instances above 64
+    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d) || (N > 64 && !roll_wide_ok(N, child))) {
+        // no single kernel for these (MACS / legacy LB placements, thread-per-container shapes, instances above 128
         // blocks): the same step as its two launches
         rc = tap_env_step_gather(ctx, d, env_state, static_cur, 1 + d->D, child * (d->D == 2 ? 2 : 6), ptr, nullptr,
                                  feature_out, stream);

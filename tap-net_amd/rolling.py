@@ -74,7 +74,7 @@ class RollingWindows(object):
     def _new_bits(self, nRc):
         """Buffer for the window tensor's bit shadow (pack.dynamic_bits layout), None if the shape has none."""
         from .pack import bits_supported
-        if not bits_supported(3 * self.child, nRc):
+        if 3 * self.child > 64 or not bits_supported(3 * self.child, nRc):   # the window kernels emit the one-word shadow
             return None
         return torch.empty(self.B, nRc, dtype=torch.int64, device=self.device)
 
