@@ -100,76 +100,9 @@ template <int G>
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wide_step(StepArgs a)
 {
     extern __shared__ int lds[];
-    const int tid = threadIdx.x, cell = tid % G;
-    const int env = blockIdx.x * ((int)blockDim.x / G) + tid / G;
-    const int B = a.d.B, W = a.d.W, H = a.d.H;
-    const bool ev = env < B, incell = cell < W;
-    const int gl0 = (tid & 63) - cell;
-    const MacsWideLds L = macs_wide_lds(lds + (tid / G) * macs_wide_group_words(G, H, a.d.n_max, W), G, H, macs_ems_cap(W, a.d.n_max));
-
-    int hm = (ev && incell) ? a.v.hm[(size_t)env * W + cell] : 0;
-    const int cv = (ev && cell < 4) ? a.v.cnt[(size_t)env * 4 + cell] : 0;
-    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
-    int bx = 1, bz = 1;
-    bool act = ev;
-    if (ev) {
-        if (a.static_) {
-            bool badp;
-            const long p = tap_col((long)a.ptr[env], a.nR, badp);
-            const float vx = a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
-            const float vz = a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
-            bx = badp ? 0 : (int)vx;
-            bz = badp ? 0 : (int)vz;
-        } else if (a.blocks_dtype == TAP_DT_F32) {
-            bx = (int)((const float *)a.blocks)[(size_t)env * 2];
-            bz = (int)((const float *)a.blocks)[(size_t)env * 2 + 1];
-        } else {
-            bx = ((const int32_t *)a.blocks)[(size_t)env * 2];
-            bz = ((const int32_t *)a.blocks)[(size_t)env * 2 + 1];
-        }
-        if (a.active) act = a.active[env] != 0;
-    }
-    int err = 0;
-    bool do_step = act;
-    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }
-    if (act && (bx < 1 || bz < 1)) { err |= 4; do_step = false; }
-
-    L.hm[cell] = hm;
-    for (int i = cell; i < H; i += G) L.taken[i] = 0;
-    if (ev) // one round trip for the whole placement history
-        for (int k = cell; k < cnt.count * 4 && k < a.d.n_max * 4; k += G) {
-            const int i = k >> 2, f = k & 3;
-            L.hist[k] = (f < 2 ? a.v.pos : a.v.blk)[(size_t)(i * 2 + (f & 1)) * B + env];
-        }
-    tap_wave_lds_sync();
-    const int step = cnt.count;
-    const PlaceCfg cfg = {W, 1, H, a.d.flags, nullptr};
-    // an env beyond the batch shares its wave with live ones: its group still runs the (empty) placement so
-    // that every ballot of the wave is executed by all of its lanes
-    const Placement pl = tap_macs_place_wide<G>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
-    err = group_or<G>(err);
-
-    tap_wave_lds_sync();
-    L.hm[cell] = hm;
-    tap_wave_lds_sync();
-    if (ev) {
-        if (incell) a.v.hm[(size_t)env * W + cell] = hm;
-        if (a.feature_out)
-            tap_write_feature<2, G>(a.d.feature, W, 1, L.hm, cell, hm, a.feature_out + (size_t)env * a.flen);
-        if (cell == 0) {
-            if (do_step) {
-                reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
-                a.v.pos[(size_t)(step * 2) * B + env] = pl.x;
-                a.v.pos[(size_t)(step * 2 + 1) * B + env] = pl.z;
-                a.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
-                a.v.blk[(size_t)(step * 2) * B + env] = bx;   // history the later steps read
-                a.v.blk[(size_t)(step * 2 + 1) * B + env] = bz; // (tools.py:2531-2533), failures too
-            }
-            if (err) a.v.err[env] |= err;
-        }
-    } else if (a.d.feature == TAP_FEAT_ZERO) {
-        (void)group_min<G>(INT_MAX);
-    }
+    const int tid = threadIdx.x;
+    tap_macs_wide_wave<G>(a, 0, nullptr, blockIdx.x * ((int)blockDim.x / G) + tid / G, tid % G, tid & 63,
+                          lds + (tid / G) * macs_wide_group_words(G, a.d.H, a.d.n_max, a.d.W));
 }
 
 template <int G> static int launch_macs_wide(tap_ctx *ctx, const StepArgs &a, hipStream_t st)

@@ -1,0 +1,60 @@
+// tap_transition.h -- what the fused-step kernels of transition.hip and transition_wide.hip share: the argument
+// block, the stream wave (the precedence update of one or two envs by one wavefront) and the workgroup geometry.
+#pragma once
+
+#include "tap_common.h"
+#include "tap_masks.h"
+#include "tap_place.h"
+
+struct TransArgs {
+    StepArgs s;   // placement (always the gather form: s.static_, s.ptr)
+    MaskArgs m;   // precedence update
+    int flags;
+    float *ratio_out;
+};
+
+// ---- a stream wave: out-of-place copy of SPW consecutive slabs with the chosen rows cleared
+//      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
+// MODE: 0 = fp32 copy with the column-sum shadow, 1 = on the bit shadow, 2 = first step (shadow built in the launch)
+template <int SPW, int NC, int MODE>
+__device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
+{
+    bool on[SPW];
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
+    if (NC > 0) {
+        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false>(m, senv0, lane, on, lds);
+        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true>(m, senv0, lane, on, lds);
+        else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
+        return;
+    }
+    const size_t slab = (size_t)m.rows * m.nR;
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+        if (!on[k]) continue;
+        const int senv = senv0 + k;
+        bool badp;
+        const long pc = tap_col((long)m.ptr[senv], m.nR, badp);
+        // pack.py:339; an index outside [0, nR) clears nothing and removes no column (tap_masks.h)
+        const long real = badp ? -1 : (long)m.static_[(size_t)senv * m.static_rows * m.nR + pc];
+        const long p = badp ? -1 : pc;
+        const ClearRanges cr = clear_ranges(m, real);
+        const float *src = m.dyn_in + (size_t)senv * slab;
+        float *dst = m.dyn_out + (size_t)senv * slab;
+        for (long f = lane; f < (long)slab; f += 64) {
+            float v = src[f];
+            if (in_cleared(cr, (int)f)) v = 0.f;
+            dst[f] = v;
+        }
+        mask_env(m, senv, lane, real, p);
+    }
+}
+
+template <int G, int SW> struct TransGeom {
+    static constexpr int EPB = (G == 64) ? 4 : 8;   // envs per workgroup
+    static constexpr int ENV_WAVES = EPB * G / 64;  // waves made of placement lane groups
+    static constexpr int STREAM_WAVES = (SW < EPB) ? SW : EPB; // waves that stream the dynamic slabs
+    static constexpr int SPW = EPB / STREAM_WAVES;  // slabs per stream wave
+    static constexpr int THREADS = 64 * (ENV_WAVES + STREAM_WAVES);
+};
+

@@ -21,59 +21,8 @@
 #include "tap_macs3.h"
 #include "tap_masks.h"
 #include "tap_place.h"
+#include "tap_transition.h"
 #include "tap_waves.h"
-
-struct TransArgs {
-    StepArgs s;   // placement (always the gather form: s.static_, s.ptr)
-    MaskArgs m;   // precedence update
-    int flags;
-    float *ratio_out;
-};
-
-// ---- a stream wave: out-of-place copy of SPW consecutive slabs with the chosen rows cleared
-//      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
-// MODE: 0 = fp32 copy with the column-sum shadow, 1 = on the bit shadow, 2 = first step (shadow built in the launch)
-template <int SPW, int NC, int MODE>
-__device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
-{
-    bool on[SPW];
-#pragma unroll
-    for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
-    if (NC > 0) {
-        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false>(m, senv0, lane, on, lds);
-        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true>(m, senv0, lane, on, lds);
-        else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
-        return;
-    }
-    const size_t slab = (size_t)m.rows * m.nR;
-#pragma unroll
-    for (int k = 0; k < SPW; ++k) {
-        if (!on[k]) continue;
-        const int senv = senv0 + k;
-        bool badp;
-        const long pc = tap_col((long)m.ptr[senv], m.nR, badp);
-        // pack.py:339; an index outside [0, nR) clears nothing and removes no column (tap_masks.h)
-        const long real = badp ? -1 : (long)m.static_[(size_t)senv * m.static_rows * m.nR + pc];
-        const long p = badp ? -1 : pc;
-        const ClearRanges cr = clear_ranges(m, real);
-        const float *src = m.dyn_in + (size_t)senv * slab;
-        float *dst = m.dyn_out + (size_t)senv * slab;
-        for (long f = lane; f < (long)slab; f += 64) {
-            float v = src[f];
-            if (in_cleared(cr, (int)f)) v = 0.f;
-            dst[f] = v;
-        }
-        mask_env(m, senv, lane, real, p);
-    }
-}
-
-template <int G, int SW> struct TransGeom {
-    static constexpr int EPB = (G == 64) ? 4 : 8;   // envs per workgroup
-    static constexpr int ENV_WAVES = EPB * G / 64;  // waves made of placement lane groups
-    static constexpr int STREAM_WAVES = (SW < EPB) ? SW : EPB; // waves that stream the dynamic slabs
-    static constexpr int SPW = EPB / STREAM_WAVES;  // slabs per stream wave
-    static constexpr int THREADS = 64 * (ENV_WAVES + STREAM_WAVES);
-};
 
 template <int D, int G, int NC, int SW, int MODE>
 __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TransArgs a)
@@ -284,12 +233,17 @@ template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransAr
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
 
 // Shapes and strategies whose placement is one THREAD per container (legacy 'LB', LB_GREEDY above 64 cells or a 3D
-// side above 8) or needs the wide MACS 2D form (17 .. 64 columns): no single kernel carries both halves of the step.
+// side above 8), or a wide MACS 2D container (17 .. 64 columns) too tall for one workgroup's LDS: no single kernel
+// carries both halves of the step.
 // The tap_transition* entry points then run the same step as its two launches (precedence update, placement) plus
 // reset / calc_ratio where the flags ask for them, so a caller drives every shape through one entry point.
-static bool transition_single_kernel(const tap_env_desc *d)
+bool tap_transition_macs_wide_fits(const tap_env_desc *d, int nR);                      // transition_wide.hip
+int tap_transition_macs_wide(tap_ctx *ctx, const TransArgs &a, hipStream_t st);
+
+static bool transition_single_kernel(const tap_env_desc *d, int nR)
 {
-    return !(d->strategy == TAP_LB || tap_is_big(d) || (d->strategy == TAP_MACS && d->D == 2 && d->W > 16));
+    if (d->strategy == TAP_MACS && d->D == 2 && d->W > 16) return tap_transition_macs_wide_fits(d, nR);
+    return !(d->strategy == TAP_LB || tap_is_big(d));
 }
 
 static int transition_tail(tap_ctx *ctx, const tap_env_desc *d, void *state, const TransArgs &a, void *stream)
@@ -336,7 +290,7 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "transition is out of place (pack.py:370)");
-    if (!transition_single_kernel(d)) {
+    if (!transition_single_kernel(d, n * R)) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, colsum_in, dyn_out,
                            colsum_out, current_out, mask_out, stream);
@@ -361,7 +315,7 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
-    if (!transition_single_kernel(d) || rows > 64) {      // the fused kernels carry the one-word shadow only
+    if (!transition_single_kernel(d, n * R) || rows > 64) {      // the fused kernels carry the one-word shadow only
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_bits(ctx, d->B, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
                                 dyn_out, current_out, mask_out, stream);
@@ -387,7 +341,7 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
-    if (!transition_single_kernel(d) || rows > 64) {
+    if (!transition_single_kernel(d, n * R) || rows > 64) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_first(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,
                                  dyn_out, current_out, mask_out, nonbinary_out, stream);
@@ -411,6 +365,7 @@ static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransA
         default: return launch_transition_macs3<64>(ctx, a, (hipStream_t)stream);
         }
     }
+    if (d->strategy == TAP_MACS && d->W > 16) return tap_transition_macs_wide(ctx, a, (hipStream_t)stream);
     if (d->strategy == TAP_MACS)   // (16 lanes per container for W <= 8 measured 2.3 x slower at c4: the per-lane work grows with G)
         return d->W <= 8 ? launch_transition_macs<8>(ctx, a, (hipStream_t)stream)
                          : launch_transition_macs<16>(ctx, a, (hipStream_t)stream);
