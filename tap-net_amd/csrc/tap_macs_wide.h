@@ -3,8 +3,8 @@
 // the same three phases as tap_macs.h (read its header first); what differs is where things live: the
 // height-map stays in the group's LDS slice instead of a register array per lane (a 64-entry array would not
 // fit), column masks are 64-bit, and a level's `taken` mask is a 64-bit word.  Used by macs.hip's stand-alone
-// step and by the fused step of transition_wide.hip -- the reference's own MACS runs are 5 and 7 columns wide,
-// so this is a coverage path, not a tuned one.
+// step only -- the reference's own MACS runs are 5 and 7 columns wide, so this is a coverage path, not a tuned
+// one (a fused transition for it was measured slower than the two launches, see transition.hip).
 #pragma once
 
 #include "tap_macs.h"
@@ -249,9 +249,8 @@ __device__ inline Placement tap_macs_place_wide(const PlaceCfg &c, const MacsWid
     return res;
 }
 
-// One env's whole step as executed by its lane group (stand-alone step in macs.hip, placement waves of the fused
-// transition in transition_wide.hip): load state + history, place, store state and feature, and -- for the fused
-// form -- the fresh-container start and calc_ratio (flags: TAP_T_*).
+// One env's whole step as executed by its lane group (macs.hip's stand-alone step): load state + history, place,
+// store state and feature; flags: TAP_T_FRESH / TAP_T_RATIO as in tap_macs3_wave (fresh-container start, calc_ratio).
 template <int G>
 __device__ inline void tap_macs_wide_wave(const StepArgs &a, int flags, float *ratio_out, int env, int cell, int lane,
                                           int *lds_group)

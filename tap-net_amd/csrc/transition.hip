@@ -233,17 +233,15 @@ template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransAr
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
 
 // Shapes and strategies whose placement is one THREAD per container (legacy 'LB', LB_GREEDY above 64 cells or a 3D
-// side above 8), or a wide MACS 2D container (17 .. 64 columns) too tall for one workgroup's LDS: no single kernel
-// carries both halves of the step.
+// side above 8) or the wide MACS 2D form (17 .. 64 columns): no single kernel carries both halves of the step.  (For
+// wide MACS one was built and measured in round 3 -- tap_macs_wide_wave as the placement waves of a k_transition_macs
+// look-alike: 121 against 97 us per step at W = 20, n = 12, B = 8192, equal at W = 40: the placement is ~100 us of
+// register-heavy work, the stream waves hide nothing and their wave slots cost a quarter of the resident envs.)
 // The tap_transition* entry points then run the same step as its two launches (precedence update, placement) plus
 // reset / calc_ratio where the flags ask for them, so a caller drives every shape through one entry point.
-bool tap_transition_macs_wide_fits(const tap_env_desc *d, int nR);                      // transition_wide.hip
-int tap_transition_macs_wide(tap_ctx *ctx, const TransArgs &a, hipStream_t st);
-
-static bool transition_single_kernel(const tap_env_desc *d, int nR)
+static bool transition_single_kernel(const tap_env_desc *d)
 {
-    if (d->strategy == TAP_MACS && d->D == 2 && d->W > 16) return tap_transition_macs_wide_fits(d, nR);
-    return !(d->strategy == TAP_LB || tap_is_big(d));
+    return !(d->strategy == TAP_LB || tap_is_big(d) || (d->strategy == TAP_MACS && d->D == 2 && d->W > 16));
 }
 
 static int transition_tail(tap_ctx *ctx, const tap_env_desc *d, void *state, const TransArgs &a, void *stream)
@@ -290,7 +288,7 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "transition is out of place (pack.py:370)");
-    if (!transition_single_kernel(d, n * R)) {
+    if (!transition_single_kernel(d)) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, colsum_in, dyn_out,
                            colsum_out, current_out, mask_out, stream);
@@ -315,7 +313,7 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
-    if (!transition_single_kernel(d, n * R) || rows > 64) {      // the fused kernels carry the one-word shadow only
+    if (!transition_single_kernel(d) || rows > 64) {      // the fused kernels carry the one-word shadow only
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_bits(ctx, d->B, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
                                 dyn_out, current_out, mask_out, stream);
@@ -341,7 +339,7 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
-    if (!transition_single_kernel(d, n * R) || rows > 64) {
+    if (!transition_single_kernel(d) || rows > 64) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_first(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,
                                  dyn_out, current_out, mask_out, nonbinary_out, stream);
@@ -365,7 +363,6 @@ static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransA
         default: return launch_transition_macs3<64>(ctx, a, (hipStream_t)stream);
         }
     }
-    if (d->strategy == TAP_MACS && d->W > 16) return tap_transition_macs_wide(ctx, a, (hipStream_t)stream);
     if (d->strategy == TAP_MACS)   // (16 lanes per container for W <= 8 measured 2.3 x slower at c4: the per-lane work grows with G)
         return d->W <= 8 ? launch_transition_macs<8>(ctx, a, (hipStream_t)stream)
                          : launch_transition_macs<16>(ctx, a, (hipStream_t)stream);
