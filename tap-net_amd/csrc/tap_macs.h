@@ -133,6 +133,15 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
     int gmax = 0;
 #pragma unroll
     for (int k = 0; k < G; ++k) gmax = max(gmax, hmr[k]);
+    // Group-uniform column masks of a level come from the lanes' own columns: one compare per lane and a DPP OR
+    // over the group (bits 0..15: hm <= z "free", bits 16..31: hm == z "on") -- 7 vector instructions instead of
+    // the 6 G of a scan over the register copy, which phases 1 and 2 paid per level, per placed block and per EMS
+    // (c4: 5 % of the fused step at n = 20).  The register copy stays for phase 3, where every lane scores its OWN slot.
+    const int hx = incell ? hm : INT_MAX;                   // lanes beyond W: never free, never on
+    const unsigned cbit = 1u << cell, cbit2 = 0x10001u << cell;
+    auto level_masks = [&](int z) -> unsigned {
+        return (unsigned)group_or<G>((int)(hx < z ? cbit : hx == z ? cbit2 : 0u));
+    };
 
     // ---- phase 1: EMS list (identical on every lane of the group) ---------------------------------
     int n_ems = 0;
@@ -144,8 +153,9 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
     // (a) per-level free runs (tools.py:2517-2529); only z = 0 and z in {hm[c]} differ from below
     for (int z = 0;;) {
         if (z + bz > H) break;                                                // :2519
-        unsigned m = macs_mask_le<G>(hmr, wmask, z);
-        const unsigned on = macs_mask_eq<G>(hmr, wmask, z);
+        const unsigned lm = level_masks(z);
+        unsigned m = lm & 0xffffu;
+        const unsigned on = lm >> 16;
         while (m) {
             const int x1 = __ffs((int)m) - 1;
             const int len = __ffs((int)~(m >> x1)) - 1;                       // maximal run [x1, x1+len)
@@ -155,9 +165,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
             if (z > 0 && !(on & run)) continue;                               // :2526-2528 same run below
             EMS_PUSH(x1, z, x1 + len - 1);                                    // :2529
         }
-        int nz = INT_MAX;                                                     // :2520 next level that differs
-#pragma unroll
-        for (int k = 0; k < G; ++k) nz = (hmr[k] > z) ? min(nz, hmr[k]) : nz;
+        const int nz = group_min<G>((incell && hm > z) ? hm : INT_MAX);     // :2520 next level that differs
         if (nz == INT_MAX) break;
         z = nz;
     }
@@ -166,7 +174,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         const int x = L.hist[i * 4], z = L.hist[i * 4 + 1], xx = L.hist[i * 4 + 2], zz = L.hist[i * 4 + 3];
         const int tz = z + zz;
         if (!(tz < H)) continue;                                              // :2535
-        const unsigned fr = macs_mask_le<G>(hmr, wmask, tz);
+        const unsigned fr = level_masks(tz) & 0xffffu;
         const unsigned span = (xx >= 32 ? 0xffffffffu : ((1u << xx) - 1u)) << x; // slice clips at W (:2537)
         if (((span & wmask) & ~fr) == 0) {
             const int want = (x & 0xff) | (((x + xx - 1) & 0xff) << 8) | (tz << 16);
@@ -192,11 +200,13 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
     const int X = W - bx + 1;
     const unsigned fpm = (1u << bx) - 1u;
     int n_slots = 0;
+    int pk_next = n_ems > 0 ? L.ems[0] : 0;
     for (int e = 0; e < n_ems; ++e) {
-        const int pk = L.ems[e];
+        const int pk = pk_next;
+        pk_next = L.ems[e + 1 < n_ems ? e + 1 : e];                           // the next entry, in flight under this one
         const int X1 = pk & 0xff, X2 = (pk >> 8) & 0xff, Z = pk >> 16;
         // every lane tests its own column as the block's left edge at level Z (:2571-2588)
-        const unsigned fr = macs_mask_le<G>(hmr, wmask, Z), on = macs_mask_eq<G>(hmr, wmask, Z);
+        const unsigned lm = level_masks(Z), fr = lm & 0xffffu, on = lm >> 16;
         bool good = false;
         if (incell && cell + bx <= W) {
             const unsigned eq = (on >> cell) & fpm;
