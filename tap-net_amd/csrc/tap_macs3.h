@@ -73,7 +73,9 @@ __device__ __forceinline__ Macs3Lds macs3_lds(int *base, int G, int H)
 template <int G> __device__ __forceinline__ u64 ballot_g(bool p, int gl0)
 {
     const u64 b = __ballot(p);
-    return G == 64 ? b : ((b >> gl0) & ((1ull << (G & 63)) - 1ull));
+    if (G == 64) return b;
+    if (G == 32) return gl0 ? (b >> 32) : (b & 0xffffffffull);   // a select of two scalar halves, not a 64-bit vector shift
+    return (b >> gl0) & ((1ull << (G & 63)) - 1ull);
 }
 
 template <int G> __device__ __forceinline__ u64 group_or64(u64 v)
@@ -209,15 +211,16 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
     bool x1def = false;   // ... which :2865 may read before any assignment (UnboundLocalError)
     const mk below_me = ((mk)1 << cell) - 1;
     // exclusive prefix sum of v over the group's lanes (and the group's total)
-    auto excl_scan = [&](int v, int &total) -> int {
-        int s_ = v;
-#pragma unroll
-        for (int o = 1; o < G; o <<= 1) {
-            const int t_ = __shfl_up(s_, o, G);
-            if (cell >= o) s_ += t_;
+    // (bit by bit from ballots -- v < 2^NB -- instead of a shuffle scan: log2(G) trips through the LDS crossbar)
+    auto excl_scan = [&](int v, int &total, int nbits) -> int {
+        int pre = 0, tot = 0;
+        for (int b = 0; b < nbits; ++b) {                                            // kernel-uniform trip count
+            const mk m = (mk)ballot_g<G>((v >> b) & 1, gl0);
+            pre += m3_popc((mk)(m & below_me)) << b;
+            tot += m3_popc(m) << b;
         }
-        total = __shfl(s_, gl0 + G - 1);
-        return s_ - v;
+        total = tot;
+        return pre;
     };
     // the last lane (in list order) that assigned `x1` hands it on
     auto carry_x1 = [&](bool asg, int asgv) {
@@ -273,7 +276,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                 }
             }
             int total;
-            const int off = excl_scan(cn, total);
+            const int off = excl_scan(cn, total, 4);                                 // cn <= 8
             for (int j = 0; j < cn; ++j) {
                 const int at = n_ems + off + j;
                 if (at < MACS3_EMS_CAP) S.ems[at] = S.cand[cell * 8 + j];            // own slots: no hand-off needed
@@ -399,7 +402,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         for (int j = 0; j < yy; ++j) full = full && (rowT(Tt, y + j) & spanx) == spanx;
         const int ns = (a0 >= 0) + (a1 >= 0) + (b0 >= 0) + (b1 >= 0);
         int total;
-        const int off = excl_scan(ns + (has_top ? (full ? 1 : xx * yy) : 0), total);
+        const int off = excl_scan(ns + (has_top ? (full ? 1 : xx * yy) : 0), total, 7);   // <= 4 + 64
         {
             int j = off;
             if (a0 >= 0) S.cand[j++] = a0;
@@ -423,8 +426,21 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             // voxel identities from the history: colb = placed blocks over this lane's column (tx, ty),
             // alive = placed blocks that cross the top level of this lane's BLOCK; one pass for both
             u64 colb = 0, alive = 0;
-            const bool by_bits = step <= 64;
-            if (by_bits)
+            const bool by_bits = step <= 64, narrow = step <= 32;                   // narrow: 32-bit shifts and shuffles
+            if (narrow) {
+                unsigned cb = 0u, al = 0u;
+#pragma unroll 4
+                for (int q = 0; q < step; ++q) {
+                    const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
+                    const bool placed = (hk.x >> 16) & 1;
+                    const int kz = hk.y & 0xffff, kx = hk.x & 15, ky = (hk.x >> 4) & 15;
+                    const bool over = tx >= kx && tx < kx + ((hk.x >> 8) & 15) && ty >= ky && ty < ky + ((hk.x >> 12) & 15);
+                    const bool cross = t >= kz && t < kz + (hk.y >> 16);
+                    cb |= (unsigned)(placed && over) << q;
+                    al |= (unsigned)(placed && cross) << q;
+                }
+                colb = cb; alive = al;
+            } else if (by_bits)
 #pragma unroll 4
                 for (int q = 0; q < step; ++q) {                                     // no branches: the reads pipeline
                     const int2 hk = reinterpret_cast<const int2 *>(S.hist)[q];
@@ -435,8 +451,9 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                     colb |= (u64)(placed && over) << q;
                     alive |= (u64)(placed && cross) << q;
                 }
-            auto shfl64 = [](u64 v, int src) -> u64 {
-                return ((u64)(unsigned)__shfl((int)(v >> 32), src) << 32) | (unsigned)__shfl((int)v, src);
+            auto shfl64 = [narrow](u64 v, int src) -> u64 {
+                const unsigned lo = (unsigned)__shfl((int)v, src);
+                return narrow ? (u64)lo : (((u64)(unsigned)__shfl((int)(v >> 32), src) << 32) | lo);
             };
             const int left = (wl + 63) & 63;                                         // the cell at x-1 (same row)
             const u64 colbL = shfl64(colb, left);
@@ -579,27 +596,28 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         wm[cell * 5] = U; wm[cell * 5 + 1] = M1; wm[cell * 5 + 2] = M2; wm[cell * 5 + 3] = M3; wm[cell * 5 + 4] = M4;
         tap_wave_lds_sync();
         const int nk = min(G, n_ems - e0);
-        mk Un = wm[0];
+        mk Un = wm[0], n1 = wm[1], n2 = wm[2], n3 = wm[3], n4 = wm[4];
         for (int k = 0; k < nk; ++k) {
-            const mk Uk = Un;
-            Un = wm[(k + 1 < nk ? k + 1 : k) * 5];                                   // next space's mask, in flight
+            const mk Uk = Un, c1 = n1, c2 = n2, c3 = n3, c4 = n4;
+            const int kn = (k + 1 < nk ? k + 1 : k) * 5;                             // next space's masks, in flight
+            Un = wm[kn]; n1 = wm[kn + 1]; n2 = wm[kn + 2]; n3 = wm[kn + 3]; n4 = wm[kn + 4];
             if (!(Uk & ~taken)) continue;
-            const mk m1 = wm[k * 5 + 1] & ~takenx;
+            const mk m1 = c1 & ~takenx;
             if (m1) {
                 const int q = m3_ffs(m1), px = (q * invL) >> 8;
                 settle(px, q - px * L);
             }
-            const mk m2 = wm[k * 5 + 2] & ~taken;
+            const mk m2 = c2 & ~taken;
             if (m2) {
                 const int py = (m3_ffs(m2) * invW) >> 8;
                 settle(31 - __clz((int)rowT(m2, py)), py);
             }
-            const mk m3 = wm[k * 5 + 3] & ~takenx;
+            const mk m3 = c3 & ~takenx;
             if (m3) {
                 const int q = m3_fls(m3), px = (q * invL) >> 8;
                 settle(px, q - px * L);
             }
-            const mk m4 = wm[k * 5 + 4] & ~taken;
+            const mk m4 = c4 & ~taken;
             if (m4) {
                 const int py = (m3_fls(m4) * invW) >> 8;
                 settle(__ffs((int)rowT(m4, py)) - 1, py);
