@@ -16,6 +16,7 @@ Fixtures:
   reward_tour.npz                    pack.reward on those tours
   kat.npz                            hand-checkable known answers
   rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
+  rolling_big.npz                    the same for instances of 70 .. 130 blocks (node ids above 63)
   render.npz                         pack.render's eight metric files (LB_GREEDY / MACS / MUL, 2D / 3D, two-container types)
   ppsg3d.npz                         generate.BPP_Generator_3D / generate_blocks_with_GT (3D) under recorded seeds
   ppsg2d.npz                         generate.BPP_Generator_2D_easy / generate_blocks_with_GT (2D) under recorded seeds
@@ -541,14 +542,20 @@ def make_kat(tools):
     save("kat.npz", **out)
 
 
-def make_rolling(tools, generate):
+ROLLING_SHAPES = ((2, 50, 10, [7, 250], 6), (3, 50, 10, [7, 7, 250], 4), (2, 24, 6, [6, 120], 6), (3, 20, 5, [5, 5, 100], 4))
+# instances above 64 blocks (rolling.py:702 --total_blocks_num is free): node ids above 63 go through the CPython-set
+# iteration order with a non-zero perturb, two-word graphs on the device (rolling_big.npz, round 3)
+ROLLING_BIG_SHAPES = ((2, 100, 10, [7, 500], 2), (3, 100, 10, [7, 7, 500], 2), (2, 128, 16, [9, 600], 1), (3, 130, 12, [7, 7, 600], 1),
+                      (2, 70, 20, [7, 400], 1))
+
+
+def make_rolling(tools, generate, shapes=ROLLING_SHAPES, name="rolling.npz", seed=77):
     """generate.InitialContainer (generate.py:1589-1839) driven like rolling.validate
     (rolling.py:589-637): windows of 10 nodes over 50-/24-block instances, random feasible picks."""
     out = {}
     cases = []
-    rng = np.random.RandomState(77)
-    for D, N, child, init, count in ((2, 50, 10, [7, 250], 6), (3, 50, 10, [7, 7, 250], 4),
-                                     (2, 24, 6, [6, 120], 6), (3, 20, 5, [5, 5, 100], 4)):
+    rng = np.random.RandomState(seed)
+    for D, N, child, init, count in shapes:
         R = math.factorial(D)
         for c in range(count):
             np.random.seed(1000 * D + 10 * N + c)
@@ -577,7 +584,7 @@ def make_rolling(tools, generate):
             out[tag + "_nodes"] = np.asarray(nodes)
             out[tag + "_ptr"] = np.asarray(ptrs, dtype=np.int16)
     out["cases"] = np.asarray(cases)
-    save("rolling.npz", **out)
+    save(name, **out)
 
 
 def main():
@@ -603,6 +610,7 @@ def main():
     if want("stable3d"): make_stable3d(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)
+    if want("rolling_big"): make_rolling(tools, generate, ROLLING_BIG_SHAPES, "rolling_big.npz", seed=78)
     if want("render"): make_render(pack)
     if want("data"):
         with tempfile.TemporaryDirectory() as tmp:

@@ -203,10 +203,12 @@ def test_instance_generation_from_reference_datasets(D):
         assert np.array_equal(dyn, ds["dynamic"][b].astype(np.float32)), b
 
 
-def test_rolling_windows():
-    """generate.InitialContainer window traces (the outer loop of rolling.py)."""
+@pytest.mark.parametrize("fixture", ["rolling.npz", "rolling_big.npz"])
+def test_rolling_windows(fixture):
+    """generate.InitialContainer window traces (the outer loop of rolling.py); rolling_big.npz: instances of 70 .. 130
+    blocks, where node ids above 63 meet the CPython-set iteration order."""
     import ast
-    z = G.load("rolling.npz")
+    z = G.load(fixture)
     for i, m in enumerate(z["cases"]):
         meta = ast.literal_eval(str(m))
         tag = "r%d_" % i

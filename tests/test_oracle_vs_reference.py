@@ -81,13 +81,14 @@ def test_macs3d(ref, reward):
     _diff(ref[0], [4, 7, 40], 12, reward, "diff", "MACS", 4, 43)
 
 
-def test_masks(ref):
+@pytest.mark.parametrize("shape", [(32, 6, 2), (16, 30, 2), (8, 42, 6), (8, 22, 6)])   # 18 .. 126 rows
+def test_masks(ref, shape):
     import torch
     pack = ref[1]
     rng = np.random.RandomState(5)
-    B, n, R = 32, 6, 2
+    B, n, R = shape
     dyn = (rng.rand(B, 3 * n, n * R) < 0.12).astype(np.float32)
-    static = np.zeros((B, 3, n * R), np.float32)
+    static = np.zeros((B, 3 if R == 2 else 4, n * R), np.float32)     # 1 + D rows: pack.py reads D off the shape
     static[:, 0, :] = np.tile(np.arange(n), R)
     mask = (rng.rand(B, n * R) < 0.8).astype(np.float32)
     ptr = rng.randint(0, n * R, size=B).astype(np.int64)
