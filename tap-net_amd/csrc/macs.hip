@@ -177,6 +177,11 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 }
 
 #ifdef TAP_PROF
+extern "C" int tap_prof_read_macs2(unsigned int *out)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tap_prof_m2), sizeof(unsigned int) * 8192 * 8);
+    return 0;
+}
 extern "C" int tap_prof_read_macs3(unsigned int *out)
 {
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tap_prof_m3), sizeof(unsigned int) * 8192 * 16);

@@ -31,7 +31,8 @@
 // most two per placed block (tools.py:2517-2555); two walks (slots) per EMS.  Even, for alignment.
 __host__ __device__ constexpr int macs_ems_cap(int W, int n_max)
 {
-    return ((W + 1) * ((W + 1) / 2) + 2 * n_max + 1) & ~1;
+    const int cap = ((W + 1) * ((W + 1) / 2) + 2 * n_max + 1) & ~1;
+    return cap < 16 ? 16 : cap;   // the slot list (2 cap ints) doubles as the 2 G-entry scratch of phase 1 (b), G <= 16
 }
 constexpr int MACS_MAX_H = 256;
 
@@ -108,6 +109,18 @@ template <int G> __device__ __forceinline__ int macs_sum(const int (&hmr)[G], in
     return s;
 }
 
+// -DTAP_PROF: shader-clock deltas per phase, first lane of each workgroup (scratch/prof_m2.py reads them)
+#ifdef TAP_PROF
+static __device__ unsigned int tap_prof_m2[8192 * 8];
+#define M2_PROF(i) do { const long long t_ = clock64(); if ((threadIdx.x) == 0 && blockIdx.x < 8192) tap_prof_m2[blockIdx.x * 8 + (i)] = (unsigned)(t_ - tp2_); tp2_ = t_; } while (0)
+#define M2_PROF_BEGIN long long tp2_ = clock64()
+#define M2_PROF_NOTE(i, v) tap_prof_m2[blockIdx.x * 8 + (i)] = (unsigned)(v)
+#else
+#define M2_PROF_NOTE(i, v) do { } while (0)
+#define M2_PROF(i) do { } while (0)
+#define M2_PROF_BEGIN do { } while (0)
+#endif
+
 // One placement.  Preconditions: L.hm[cell] = hm, L.taken[0..H) = 0, L.hist[0..4*cnt.count) =
 // (x, z, bx, bz) of the earlier steps, all visible to the group (wave-level sync by the caller).
 // do_step is group-uniform.  On return hm/cnt are updated and res describes the placement.
@@ -124,6 +137,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
     const bool incell = cell < W;
     Placement res = {0, 0, 0, 0, 0};
     if (!do_step) return res;
+    M2_PROF_BEGIN;
     const int hard = c.flags & TAP_F_HARD;
     const int vol = bx * bz, step = cnt.count;
     const unsigned wmask = (1u << W) - 1u, gmask = (1u << G) - 1u;
@@ -169,33 +183,65 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         if (nz == INT_MAX) break;
         z = nz;
     }
-    // (b) tops of the blocks placed so far (tools.py:2531-2555); failed steps sit at (0, 0)
-    for (int i = 0; i < step; ++i) {
-        const int x = L.hist[i * 4], z = L.hist[i * 4 + 1], xx = L.hist[i * 4 + 2], zz = L.hist[i * 4 + 3];
+    M2_PROF(0);
+    // (b) tops of the blocks placed so far (tools.py:2531-2555); failed steps sit at (0, 0).
+    //     What a placed block contributes depends on the block and the height-map only, so the blocks are taken ONE
+    //     PER LANE, G at a time (round 3; the group-uniform loop cost 750 cycles per block, 44 % of a placement at
+    //     step 19 of c4): the lane scans its register copy of the map at ITS block's top level, forms its (at most
+    //     two) entries, and the entries are appended in block order through prefix counts.  A fully free top is
+    //     appended only when the list does not hold it yet (:2538): absent from the list so far and from the entries
+    //     of the earlier blocks of the same round (an equal earlier entry is in the list, or equals one that is).
+    const unsigned below_me = (1u << cell) - 1u;
+    for (int base = 0; base < step; base += G) {
+        const int i = base + cell;
+        const bool valid = i < step;
+        const int hi4 = (valid ? i : base) * 4;
+        const int x = L.hist[hi4], z = L.hist[hi4 + 1], xx = L.hist[hi4 + 2], zz = L.hist[hi4 + 3];
         const int tz = z + zz;
-        if (!(tz < H)) continue;                                              // :2535
-        const unsigned fr = level_masks(tz) & 0xffffu;
-        const unsigned span = (xx >= 32 ? 0xffffffffu : ((1u << xx) - 1u)) << x; // slice clips at W (:2537)
-        if (((span & wmask) & ~fr) == 0) {
-            const int want = (x & 0xff) | (((x + xx - 1) & 0xff) << 8) | (tz << 16);
-            int dup = 0;                                                      // :2538
-            for (int k = cell; k < n_ems; k += G) dup |= L.ems[k] == want;
-            if (!((__ballot(dup != 0) >> gl0) & gmask)) EMS_PUSH(x, tz, x + xx - 1); // one ballot, no shuffle chain
-        } else {
-            if (x + xx - 1 >= W) { err |= 8; continue; }                      // reference: IndexError :2550
-            if (((fr >> x) & 1u) && x > 0 && ((fr >> (x - 1)) & 1u)) {        // :2543-2548 left part
-                const int len = __ffs((int)~(fr >> x)) - 1;                   // free columns from x rightwards
-                EMS_PUSH(x, tz, x + min(len, xx) - 1);
-            }
+        int c0 = -1, c1 = -1;
+        bool flagged = false;
+        if (valid && tz < H) {                                                // :2535
+            const unsigned fr = macs_mask_le<G>(hmr, wmask, tz);
+            const unsigned span = (xx >= 32 ? 0xffffffffu : ((1u << xx) - 1u)) << x; // slice clips at W (:2537)
             const int xe = x + xx - 1;
-            if (((fr >> xe) & 1u) && x + xx < W && ((fr >> (x + xx)) & 1u)) { // :2550-2555 right part
-                const unsigned low = fr << (31 - xe);                         // bit xe -> bit 31
-                const int len = __clz((int)~low);                             // free columns from xe leftwards
-                EMS_PUSH(xe - min(len, xx) + 1, tz, xe);
+            if (((span & wmask) & ~fr) == 0) {
+                c0 = (x & 0xff) | ((xe & 0xff) << 8) | (tz << 16);
+                flagged = true;
+            } else if (xe >= W) {
+                err |= 8;                                                     // reference: IndexError :2550
+            } else {
+                if (((fr >> x) & 1u) && x > 0 && ((fr >> (x - 1)) & 1u)) {    // :2543-2548 left part
+                    const int len = __ffs((int)~(fr >> x)) - 1;               // free columns from x rightwards
+                    c0 = (x & 0xff) | (((x + min(len, xx) - 1) & 0xff) << 8) | (tz << 16);
+                }
+                if (((fr >> xe) & 1u) && x + xx < W && ((fr >> (x + xx)) & 1u)) { // :2550-2555 right part
+                    const unsigned low = fr << (31 - xe);                     // bit xe -> bit 31
+                    const int len = __clz((int)~low);                         // free columns from xe leftwards
+                    c1 = ((xe - min(len, xx) + 1) & 0xff) | ((xe & 0xff) << 8) | (tz << 16);
+                }
             }
         }
+        // this round's entries side by side in the (still unused) slot list, for the "already listed" test
+        L.slots[2 * cell] = c0;
+        L.slots[2 * cell + 1] = c1;
+        tap_wave_lds_sync();
+        bool keep0 = c0 >= 0;
+        if (flagged) {
+            bool dup = false;
+            for (int k = 0; k < n_ems; ++k) dup |= L.ems[k] == c0;
+            for (int k = 0; k < 2 * cell; ++k) dup |= L.slots[k] == c0;
+            keep0 = !dup;
+        }
+        const bool keep1 = c1 >= 0;
+        const unsigned k0 = (unsigned)((__ballot(keep0) >> gl0) & gmask), k1 = (unsigned)((__ballot(keep1) >> gl0) & gmask);
+        const int at0 = n_ems + __popc(k0 & below_me) + __popc(k1 & below_me), at1 = at0 + (keep0 ? 1 : 0);
+        if (keep0) { if (at0 < ems_cap) L.ems[at0] = c0; else err |= 16; }
+        if (keep1) { if (at1 < ems_cap) L.ems[at1] = c1; else err |= 16; }
+        n_ems = min(ems_cap, n_ems + __popc(k0) + __popc(k1));
+        tap_wave_lds_sync();                                                  // entries written by other lanes
     }
 
+    M2_PROF(1);
     // ---- phase 2: both corner walks of every EMS (tools.py:2680-2700) -> slot list ------------------
     const int X = W - bx + 1;
     const unsigned fpm = (1u << bx) - 1u;
@@ -240,6 +286,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         L.taken[Z] = (unsigned short)tk; // every lane stores the same value and reads back its own
     }
 
+    M2_PROF(2);
     // ---- phase 3: score the slots (tools.py:2590-2604), lanes round-robin ---------------------------
     const int valid2 = cnt.valid + vol;
     const bool tiebreak = (c.flags & TAP_F_MCS_TIE) != 0, zero = (c.flags & TAP_F_MCS_ZERO) != 0;
@@ -267,6 +314,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         if (r > my_r) { my_r = r; my_slot = s; } // slots come in increasing order: first maximum kept
     }
     const double rmax = group_fmax<G>(my_r);
+    M2_PROF(3);
     // winner (:2713-2736): the first slot reaching rmax, or -- with the 'mcs' tie-break -- the first
     // one among them with the largest usable-space score
     int win = INT_MAX;
@@ -296,6 +344,7 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         }
     }
 
+    M2_PROF(4);
     // ---- commit (tools.py:2738-2747) -------------------------------------------------------------------
     if (win != INT_MAX) {
         int xs, Z, sum, stab;
@@ -308,6 +357,8 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         if (Z + bz > H) err |= 1;
     }
     cnt.count += 1;
+    M2_PROF(5);
+    if ((threadIdx.x) == 0 && blockIdx.x < 8192) { M2_PROF_NOTE(6, n_ems); M2_PROF_NOTE(7, n_slots); }
 #undef EMS_PUSH
     return res;
 }
