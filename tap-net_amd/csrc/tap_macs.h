@@ -164,24 +164,56 @@ __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, 
         if (n_ems < ems_cap) L.ems[n_ems++] = ((x1) & 0xff) | (((x2) & 0xff) << 8) | ((z) << 16); \
         else err |= 16;                                                                      \
     } while (0)
-    // (a) per-level free runs (tools.py:2517-2529); only z = 0 and z in {hm[c]} differ from below
-    for (int z = 0;;) {
-        if (z + bz > H) break;                                                // :2519
-        const unsigned lm = level_masks(z);
-        unsigned m = lm & 0xffffu;
-        const unsigned on = lm >> 16;
+    // (a) per-level free runs (tools.py:2517-2529); only z = 0 and z in {hm[c]} differ from below.  Level 0 is
+    //     listed by the whole group (identical writes); every other level belongs to the lane of the FIRST column at
+    //     that height, which lists the level's runs from its register copy of the map, and the lists are appended in
+    //     level order (offset = entries of the owners of lower levels) -- the levels of the 8 containers of a wave
+    //     used to be walked one after the other, each walk as long as the longest of the eight.
+    if (bz <= H) {                                                            // :2519 at z = 0
+        unsigned m = level_masks(0) & 0xffffu;
         while (m) {
             const int x1 = __ffs((int)m) - 1;
             const int len = __ffs((int)~(m >> x1)) - 1;                       // maximal run [x1, x1+len)
             const unsigned run = ((1u << len) - 1u) << x1;
             m &= ~run;
             if (x1 + bx > W) break;                                           // :2525
-            if (z > 0 && !(on & run)) continue;                               // :2526-2528 same run below
-            EMS_PUSH(x1, z, x1 + len - 1);                                    // :2529
+            EMS_PUSH(x1, 0, x1 + len - 1);                                    // :2529
         }
-        const int nz = group_min<G>((incell && hm > z) ? hm : INT_MAX);     // :2520 next level that differs
-        if (nz == INT_MAX) break;
-        z = nz;
+    }
+    {
+        const int RS = (W + 1) / 2;                                           // runs of one level, at most
+        int *mine = L.slots + cell * RS, *keys = L.slots + G * RS;            // scratch inside the (unused) slot list
+        const int z = hm;
+        const unsigned on = macs_mask_eq<G>(hmr, wmask, z);
+        const bool owner = incell && z > 0 && z + bz <= H && !(on & ((1u << cell) - 1u));   // :2519, first column at z
+        int cn = 0;
+        if (owner) {
+            unsigned m = macs_mask_le<G>(hmr, wmask, z);
+            while (m) {
+                const int x1 = __ffs((int)m) - 1;
+                const int len = __ffs((int)~(m >> x1)) - 1;
+                const unsigned run = ((1u << len) - 1u) << x1;
+                m &= ~run;
+                if (x1 + bx > W) break;                                       // :2525
+                if (!(on & run)) continue;                                    // :2526-2528 same run below
+                mine[cn++] = (x1 & 0xff) | (((x1 + len - 1) & 0xff) << 8) | (z << 16);
+            }
+        }
+        keys[cell] = owner ? ((z << 8) | cn) : -1;
+        tap_wave_lds_sync();
+        int off = 0, total = 0;
+        for (int k = 0; k < G; ++k) {                                         // uniform addresses: broadcast reads
+            const int kk = keys[k];
+            if (kk < 0) continue;
+            total += kk & 0xff;
+            if ((kk >> 8) < z) off += kk & 0xff;
+        }
+        for (int j = 0; j < cn; ++j) {
+            const int at = n_ems + off + j;
+            if (at < ems_cap) L.ems[at] = mine[j]; else err |= 16;
+        }
+        n_ems = min(ems_cap, n_ems + total);
+        tap_wave_lds_sync();
     }
     M2_PROF(0);
     // (b) tops of the blocks placed so far (tools.py:2531-2555); failed steps sit at (0, 0).
