@@ -1390,7 +1390,9 @@ def main():
                              "step writes the fp32 tensor and never reads it) x envs per launch",
                 "frac_alg_survey": ach_survey / HBM_PEAK_GBS,
                 "frac_alg_survey_how": "SURVEY 8(d)'s per-env-step figure (prices an fp32 read AND write of dynamic) / kernel_us / "
-                                       "peak: speed relative to a perfect fp32 copy, NOT a bandwidth fraction",
+                                       "peak: speed relative to a perfect fp32 copy, NOT a bandwidth fraction -- it passes 1.0 "
+                                       "where the bit-shadow kernel, which never performs the priced fp32 read, outruns such a copy "
+                                       "(`frac` and `frac_hbm` are the bandwidth fractions and stay below 1)",
                 "frac_hbm": (traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                 "peak_measured": dict(GBps=ceiling, kind=ceiling_kind + " beyond the Infinity Cache, 16 B per lane",
                                       frac=(ach / ceiling) if ceiling else None,
