@@ -382,8 +382,9 @@ enum {
  * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
  * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
  * One kernel for LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D with H <= 512); every other
- * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY above 64 cells, MACS 2D up to 64 columns) runs the
- * same step as its two launches behind this entry.  feature_out nullable; ratio_out (B,) f32 required with
+ * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY above 64 cells, MACS 2D up to 64 columns, a MACS
+ * container whose candidate lists do not fit a fused workgroup's LDS) runs the same step as its two launches behind
+ * this entry.  feature_out nullable; ratio_out (B,) f32 required with
  * TAP_T_RATIO. */
 int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                    int update_rows, const float *dyn_in, const float *static_, int static_rows,
