@@ -122,25 +122,39 @@ __device__ __forceinline__ int m3_longest_run(unsigned v)
 }
 // largest all-free axis-aligned rectangle of an x-major W x L bit grid (bit x*L + y)
 // lrun: the group's 256-entry table of m3_longest_run in LDS (one read instead of a data-dependent loop)
-__device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask, const unsigned char *lrun)
+// Every (first row, last row) pair, no early exits: the table look-ups are independent of each other and go out
+// back to back (a pruned loop waits one LDS round trip per pair).  WW = the container's W as a compile-time bound
+// (5 x 5: 15 pairs instead of the 36 of an 8-row grid), picked by a scalar switch.
+template <int WW>
+__device__ __forceinline__ int m3_maxrect_t(u64 fm, int L, unsigned lmask, const unsigned char *lrun)
 {
-    // every (first row, last row) pair, no early exits: the table look-ups are independent of each other and
-    // go out back to back (a pruned loop waits one LDS round trip per pair); rows beyond W are empty
-    unsigned row[8];
+    unsigned row[WW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) row[i] = i < W ? (unsigned)(fm >> (i * L)) & lmask : 0u;
+    for (int i = 0; i < WW; ++i) row[i] = (unsigned)(fm >> (i * L)) & lmask;
     int best = 0;
 #pragma unroll
-    for (int i1 = 0; i1 < 8; ++i1) {
-        if (i1 >= W) break;                                  // group-uniform
+    for (int i1 = 0; i1 < WW; ++i1) {
         unsigned acc = lmask;
 #pragma unroll
-        for (int i2 = i1; i2 < 8; ++i2) {
+        for (int i2 = i1; i2 < WW; ++i2) {
             acc &= row[i2];
             best = max(best, (i2 - i1 + 1) * (int)lrun[acc]);
         }
     }
     return best;
+}
+__device__ inline int m3_maxrect(u64 fm, int W, int L, unsigned lmask, const unsigned char *lrun)
+{
+    switch (W) {                                             // kernel-uniform
+    case 1: return m3_maxrect_t<1>(fm, L, lmask, lrun);
+    case 2: return m3_maxrect_t<2>(fm, L, lmask, lrun);
+    case 3: return m3_maxrect_t<3>(fm, L, lmask, lrun);
+    case 4: return m3_maxrect_t<4>(fm, L, lmask, lrun);
+    case 5: return m3_maxrect_t<5>(fm, L, lmask, lrun);
+    case 6: return m3_maxrect_t<6>(fm, L, lmask, lrun);
+    case 7: return m3_maxrect_t<7>(fm, L, lmask, lrun);
+    default: return m3_maxrect_t<8>(fm, L, lmask, lrun);
+    }
 }
 
 // -DTAP_PROF: shader-clock deltas per phase of the group in lanes 0..G-1 of each workgroup's first wave
