@@ -560,6 +560,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         stab_p = mp == 0 ? 1 : tap_stable3d_any(c.lut, bx, by, eq);                  // tools.is_stable
     }
     const bool okp = posv && (stab_p || !hard);                                      // :2963-2965
+    M3_PROF(11);
     const int X = W - bx + 1, Y = L - by + 1;
     // The walk order is sequential (a position settled for one space is skipped by the later ones), but what a
     // space contributes apart from that is not: one lane per space builds the set of positions that settle at
@@ -607,6 +608,7 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
             if (xr > 0 && yr > 0) { M3 = gx & rectx(0, xr, 0, yr); U |= gy & rect(0, xr, 0, yr); }    // :3101 x down, then y down
             if (X1 < X && yr > 0) { M4 = gy & rect(X1, X, 0, yr); U |= M4; }                          // :3109 y down, then x up
         }
+        M3_PROF(12);
         wm[cell * 5] = U; wm[cell * 5 + 1] = M1; wm[cell * 5 + 2] = M2; wm[cell * 5 + 3] = M3; wm[cell * 5 + 4] = M4;
         tap_wave_lds_sync();
         const int nk = min(G, n_ems - e0);
