@@ -111,14 +111,23 @@ def lib():
     return _lib
 
 
+_resolved = {}   # torch.device with an index -> itself, checked once (the seams call this several times per step)
+
+
 def resolve_device(device):
     """-> torch.device('cuda', index); raises TapError (no CPU fallback) when that is impossible."""
+    hit = _resolved.get(device) if isinstance(device, torch.device) else None
+    if hit is not None:
+        return hit
     dev = torch.device(device)
     if dev.type != "cuda":
         raise TapError(TAP_E_NODEVICE, "tensors must live on a ROCm device, got %s; there is no CPU path" % dev)
     if not torch.cuda.is_available():
         raise TapError(TAP_E_NODEVICE, "no HIP device is visible; there is no CPU path")
-    return dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+    if dev.index is not None:
+        _resolved[dev] = dev
+        return dev
+    return torch.device("cuda", torch.cuda.current_device())
 
 
 def ctx(device):
@@ -147,7 +156,13 @@ def check(status, context):
     raise TapError(status, msg)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_of(device):
+    """The HIP stream torch is currently issuing to on ``device`` (read at every call: callers switch streams)."""
+    if _raw_stream is not None and isinstance(device, torch.device) and device.index is not None:
+        return _vp(_raw_stream(device.index))          # no Stream object, no device look-up: ~0.3 us instead of ~5
     return _vp(torch.cuda.current_stream(device).cuda_stream)
 
 

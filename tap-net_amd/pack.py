@@ -339,6 +339,15 @@ class MaskStepper(object):
             self.current_mask, self.mask = first[1], first[2]
         else:
             self.current_mask, self.mask = initial_mask(self.dynamic, self.n, bits=self.bits)
+        # per-step plumbing resolved once (an eager decoding loop is host-bound: every look-up here is paid per step)
+        self._dev = _lib.resolve_device(self.dynamic.device)
+        self._ctx = _lib.ctx(self._dev)
+        self._static_ptr, self._static_rows = _lib.ptr(self.static), int(self.static.shape[1])
+
+    def _as_ptr(self, ptr):
+        if ptr.dtype is torch.int64 and ptr.device == self._dev and ptr.is_contiguous():
+            return ptr
+        return ptr.to(device=self._dev, dtype=torch.int64).contiguous()
 
     def _check_step_args(self, ptr, dyn_out):
         if tuple(ptr.shape) != (self.B,):
@@ -349,19 +358,19 @@ class MaskStepper(object):
 
     def step(self, ptr, dyn_out=None):
         """-> (new_dynamic, current_mask, mask).  ``dyn_out`` lets a caller recycle buffers."""
-        ptr = ptr.to(device=self.dynamic.device, dtype=torch.int64).contiguous()
+        ptr = self._as_ptr(ptr)
         self._check_step_args(ptr, dyn_out)
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
-        c = _lib.ctx(out.device)
+        c = self._ctx
         if self.bits is not None:
             nb = torch.empty_like(self.bits)
-            with torch.cuda.device(out.device):
+            with torch.cuda.device(self._dev):
                 _lib.check(_lib.lib().tap_mask_step_bits(
                     c, self.B, self.n, self.R, self.rows, self.update_rows, _lib.ptr(self.bits),
-                    _lib.ptr(self.static), self.static.shape[1], _lib.ptr(ptr), _lib.ptr(self.mask),
-                    _lib.ptr(nb), _lib.ptr(out), _lib.ptr(cur), _lib.ptr(new), _lib.stream_of(out.device)), c)
+                    self._static_ptr, self._static_rows, _lib.ptr(ptr), _lib.ptr(self.mask),
+                    _lib.ptr(nb), _lib.ptr(out), _lib.ptr(cur), _lib.ptr(new), _lib.stream_of(self._dev)), c)
             self.dynamic, self.bits, self.current_mask, self.mask = out, nb, cur, new
             return out, cur, new
         cs = torch.empty_like(self.colsum)
@@ -403,27 +412,29 @@ class EnvTransition(MaskStepper):
         self.env = env
         if env.batch_size != self.B or env.block_dim != self.block_dim:
             raise ValueError("container batch / dimension does not match the instance tensors")
+        import ctypes as C
+        self._desc_ref, self._state_ptr = C.byref(env.desc), _lib.ptr(env._state)
 
     def step(self, ptr, fresh=False, want_ratio=False, want_feature=True, dyn_out=None):
         """-> (new_dynamic, current_mask, mask, feature, ratio)."""
         import ctypes as C
-        ptr = ptr.to(device=self.dynamic.device, dtype=torch.int64).contiguous()
+        ptr = self._as_ptr(ptr)
         self._check_step_args(ptr, dyn_out)
         out = dyn_out if dyn_out is not None else torch.empty_like(self.dynamic)
         cur = torch.empty_like(self.mask)
         new = torch.empty_like(self.mask)
         feat = self.env._new_feature() if want_feature else None
-        ratio = torch.empty(self.B, dtype=torch.float32, device=out.device) if want_ratio else None
+        ratio = torch.empty(self.B, dtype=torch.float32, device=self._dev) if want_ratio else None
         flags = (_lib.TAP_T_FRESH if fresh else 0) | (_lib.TAP_T_RATIO if want_ratio else 0)
-        c = _lib.ctx(out.device)
+        c = self._ctx
         if self.bits is not None:
             nb = torch.empty_like(self.bits)
-            with torch.cuda.device(out.device):
+            with torch.cuda.device(self._dev):
                 _lib.check(_lib.lib().tap_transition_bits(
-                    c, C.byref(self.env.desc), _lib.ptr(self.env._state), self.n, self.R, self.rows,
-                    self.update_rows, _lib.ptr(self.bits), _lib.ptr(self.static), self.static.shape[1],
+                    c, self._desc_ref, self._state_ptr, self.n, self.R, self.rows,
+                    self.update_rows, _lib.ptr(self.bits), self._static_ptr, self._static_rows,
                     _lib.ptr(ptr), _lib.ptr(self.mask), _lib.ptr(nb), _lib.ptr(out), _lib.ptr(cur),
-                    _lib.ptr(new), _lib.ptr(feat), _lib.ptr(ratio), flags, _lib.stream_of(out.device)), c)
+                    _lib.ptr(new), _lib.ptr(feat), _lib.ptr(ratio), flags, _lib.stream_of(self._dev)), c)
             self.dynamic, self.bits, self.current_mask, self.mask = out, nb, cur, new
             return out, cur, new, feat, ratio
         cs = torch.empty_like(self.colsum)
