@@ -49,6 +49,11 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
 }
 
 // ---- the same fusion for MACS / MUL 2D (tap_macs.h): G = 8/16 lanes per env ---------------------
+// (Register cliff, measured in round 3: a workgroup is 5 waves and a CU gets 4 of them at B = 8192; at 71 VGPRs -- 7
+//  waves per SIMD -- the step takes 17.8 us, at 85 -- 5 per SIMD, where the 20 waves only fit if the dispatcher spreads
+//  them perfectly -- 23.6 us.  A window-maximum form of macs_adj (80 instead of 590 instructions, tie-break 5.1 k -> 2.6 k
+//  cycles stand-alone) crossed that line and was dropped; amdgpu_waves_per_eu(7, 8) brings either form to 72 VGPRs but
+//  costs 3 % by itself.)
 template <int G, int NC, int MODE>
 __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(TransArgs a)
 {
