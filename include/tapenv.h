@@ -272,8 +272,9 @@ int tap_ppsg_check(tap_ctx *ctx, int B, int n, int input_simple, const uint64_t 
  * node j's mask = "block a blocks block j": rel_out holds 5*N*NW words per instance -- first the N movement
  * masks, then one record of four masks (left, right, forward, backward) per node, so that a step reads the
  * window nodes' side masks as one piece of a cache line each; state_out holds 2*NW words (entered, window).
- * Up to 64 blocks an instance is handled by one wavefront (lane = node); above that by one thread per
- * instance (tap_rolling_window only, not tap_rolling_step);
+ * Up to 64 blocks an instance is handled by one wavefront (lane = node), up to 128 blocks with windows of at
+ * most 32 nodes still by one wavefront (lane = two nodes, two-word masks); above that by one thread per instance
+ * (tap_rolling_step then runs its two launches);
  * state_out is cleared. */
 int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container_size, int arm_size,
                      const int32_t *blocks, const int32_t *positions, uint64_t *rel_out,
@@ -295,7 +296,8 @@ int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32
  * in the CURRENT window (block gathered from static_cur, the tensor tap_rolling_window / _step
  * wrote last) fused with remove_block + convert_to_input() for the NEXT window (written to
  * static_next, which must be a different buffer).  feature_out as in tap_env_step.  One kernel for LB_GREEDY on
- * containers of at most 64 cells and instances of at most 64 blocks; otherwise the two launches behind this entry. */
+ * containers of at most 64 cells and instances of at most 128 blocks (windows of at most 32 nodes above 64 blocks);
+ * otherwise the two launches behind this entry. */
 int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
                      const int32_t *blocks, const uint64_t *rel, uint64_t *state, const int64_t *ptr,
                      const float *static_cur, float *static_next, float *dynamic_out,

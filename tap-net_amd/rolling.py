@@ -15,8 +15,9 @@ from .pack import EnvTransition
 class RollingWindows(object):
     """B instances of N <= 256 packed blocks each; ``next(ptr)`` drops the block picked in the
     previous window and returns the next window's network input.  Up to 64 blocks an instance is one
-    wavefront (lane = node, graphs = 64-bit masks) and ``step`` fuses the placement with the next window;
-    above that the same steps run one thread per instance on multi-word masks (``next`` only)."""
+    wavefront (lane = node, graphs = 64-bit masks), up to 128 blocks with windows of at most 32 nodes still one
+    wavefront (lane = two nodes, two-word masks), and ``step`` fuses the placement with the next window; above that
+    the same steps run one thread per instance on multi-word masks and ``step`` is two launches."""
 
     def __init__(self, blocks, positions, initial_container_size, child_graph_size=10, arm_size=1):
         self.blocks = blocks.to(torch.int32).contiguous()
