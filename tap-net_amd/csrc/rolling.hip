@@ -488,54 +488,16 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
 //       * the fp32 expansion is a table look-up: lane (rsub, c4) interleaves the bits of its four column words
 //         once (rows rsub + RP*q sit RP >= 4 bits apart, so the four columns' bits of one row form a nibble),
 //         and a row's float4 is lut[nibble] -- one bit-field extract and one shift per 16-byte store.
+// the compile-time-shaped second half of rolling_emit_fast: S.f.iw (the 5*CH row words), S.f.dims (block sides by
+// sorted slot), S.f.lut and S.srt are in place; columns, masks, static and the float4 expansion of `dynamic`.
+// (also the tail of the two-word form for 10-node windows, rolling_window_wave2)
 template <int D, int CH>
-__device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, int v, RollLds &S, u64 entered, u64 window,
-                                                  const RollNode &nd)
+__device__ __forceinline__ void rolling_emit_fast_tail(const RollArgs &a, int inst, int v, RollLds &S)
 {
     constexpr int R = D == 2 ? 2 : 6, NRC = CH * R, C4 = NRC / 4, RP = 64 / C4, ROWS = 3 * CH, QN = (ROWS + RP - 1) / RP;
-    static_assert(ROWS <= 32 && NRC <= 64 && NRC % 4 == 0 && 5 * CH <= 64 && RP >= 4 && CH <= 16, "shape outside the fast emission");
-    const int N = a.N;
-    const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
-    const u64 after = all & ~entered;                                  // after_nodes_list
-    const bool inwin = ((window >> v) & 1ull) != 0;
-    PROF_BEGIN;
-    if (inwin) {
-        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(window >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)window, 0u));
-#pragma unroll
-        for (int k = 0; k < 5; ++k) S.side[k][v] = nd.rel[k];
-        S.srt[rank] = (unsigned char)v;                                // sorted position -> node (static's column order)
-        *reinterpret_cast<int4 *>(&S.f.dims[rank][0]) = make_int4(nd.bdim[0], nd.bdim[1], nd.bdim[2], 0);
-        if (a.nodes_out) a.nodes_out[(size_t)inst * CH + rank] = v;
-    }
-    if (v < 16)
-        *reinterpret_cast<float4 *>(&S.f.lut[v][0]) = make_float4((float)(v & 1), (float)((v >> 1) & 1), (float)((v >> 2) & 1), (float)((v >> 3) & 1));
-    tap_wave_lds_sync();
-    PROF(4);
-    // lane (k5, cm5): relation k5 of the node in sub-graph column cm5, re-indexed to sub-graph rows
-    {
-        const int k5 = v / CH, cm5 = v - k5 * CH;
-        const bool on5 = v < 5 * CH;
-        const int t = S.ord[on5 ? cm5 : 0];
-        const u64 m = S.side[on5 ? k5 : 0][t];
-        const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
-        unsigned ow[(CH + 3) / 4];                                      // the sub-graph order, four node ids per scalar
-#pragma unroll
-        for (int j = 0; j < (CH + 3) / 4; ++j)
-            ow[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned *>(S.ord)[j]);
-        unsigned w = 0u;
-#pragma unroll
-        for (int rm = 0; rm < CH; ++rm) {
-            const unsigned node = (ow[rm >> 2] >> (8 * (rm & 3))) & 0xffu;        // wave-uniform
-            const unsigned half = node >= 32u ? mhi : mlo;
-            w |= ((half >> (node & 31u)) & 1u) << rm;
-        }
-        // :1690-1705 a side blocker that has not entered any window yet => the node counts as blocking itself
-        const bool self = k5 >= 1 && (m & after) != 0ull;
-        w |= self ? (1u << cm5) : 0u;
-        if (on5) S.f.iw[v] = w;
-    }
-    tap_wave_lds_sync();
-    PROF(5);
+#if defined(TAP_PROF)
+    long long tp = clock64();
+#endif
     float *st = a.static_out + (size_t)inst * (1 + D) * NRC;
     float *dy = a.dynamic_out + (size_t)inst * ROWS * NRC;
     if (v < NRC) {
@@ -599,6 +561,57 @@ __device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, i
     PROF(7);
 }
 
+template <int D, int CH>
+__device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, int v, RollLds &S, u64 entered, u64 window,
+                                                  const RollNode &nd)
+{
+    constexpr int R = D == 2 ? 2 : 6, NRC = CH * R, C4 = NRC / 4, RP = 64 / C4, ROWS = 3 * CH;
+    static_assert(ROWS <= 32 && NRC <= 64 && NRC % 4 == 0 && 5 * CH <= 64 && RP >= 4 && CH <= 16, "shape outside the fast emission");
+    const int N = a.N;
+    const u64 all = N == 64 ? ~0ull : ((1ull << N) - 1ull);
+    const u64 after = all & ~entered;                                  // after_nodes_list
+    const bool inwin = ((window >> v) & 1ull) != 0;
+    PROF_BEGIN;
+    if (inwin) {
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(window >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)window, 0u));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) S.side[k][v] = nd.rel[k];
+        S.srt[rank] = (unsigned char)v;                                // sorted position -> node (static's column order)
+        *reinterpret_cast<int4 *>(&S.f.dims[rank][0]) = make_int4(nd.bdim[0], nd.bdim[1], nd.bdim[2], 0);
+        if (a.nodes_out) a.nodes_out[(size_t)inst * CH + rank] = v;
+    }
+    if (v < 16)
+        *reinterpret_cast<float4 *>(&S.f.lut[v][0]) = make_float4((float)(v & 1), (float)((v >> 1) & 1), (float)((v >> 2) & 1), (float)((v >> 3) & 1));
+    tap_wave_lds_sync();
+    PROF(4);
+    // lane (k5, cm5): relation k5 of the node in sub-graph column cm5, re-indexed to sub-graph rows
+    {
+        const int k5 = v / CH, cm5 = v - k5 * CH;
+        const bool on5 = v < 5 * CH;
+        const int t = S.ord[on5 ? cm5 : 0];
+        const u64 m = S.side[on5 ? k5 : 0][t];
+        const unsigned mlo = (unsigned)m, mhi = (unsigned)(m >> 32);
+        unsigned ow[(CH + 3) / 4];                                      // the sub-graph order, four node ids per scalar
+#pragma unroll
+        for (int j = 0; j < (CH + 3) / 4; ++j)
+            ow[j] = (unsigned)__builtin_amdgcn_readfirstlane((int)reinterpret_cast<const unsigned *>(S.ord)[j]);
+        unsigned w = 0u;
+#pragma unroll
+        for (int rm = 0; rm < CH; ++rm) {
+            const unsigned node = (ow[rm >> 2] >> (8 * (rm & 3))) & 0xffu;        // wave-uniform
+            const unsigned half = node >= 32u ? mhi : mlo;
+            w |= ((half >> (node & 31u)) & 1u) << rm;
+        }
+        // :1690-1705 a side blocker that has not entered any window yet => the node counts as blocking itself
+        const bool self = k5 >= 1 && (m & after) != 0ull;
+        w |= self ? (1u << cm5) : 0u;
+        if (on5) S.f.iw[v] = w;
+    }
+    tap_wave_lds_sync();
+    PROF(5);
+    rolling_emit_fast_tail<D, CH>(a, inst, v, S);
+}
+
 
 // ---- 65 .. 128 blocks per instance: still ONE wavefront per instance, lane v = nodes v and v + 64 -------------
 // Every graph is two 64-bit words per node (the layout k_rolling_init_big writes: NW = 2 words per mask, the N
@@ -609,6 +622,8 @@ __device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, i
 // slots exactly); the tensor goes out packed (rolling_emit_wave's float4 expansion) when it has the bit-shadow
 // shape, element by element otherwise.
 constexpr int ROLL_CH_WIDE = -2;      // template tag: this form instead of the one-word graph step
+// window sizes with a compile-time-shaped kernel (0 = any window, shapes read from the arguments)
+__host__ __device__ constexpr bool roll_fast_ok(int D, int child) { return child == 10 && (D == 2 || D == 3); }
 
 template <int D>
 __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, RollLds &S)
@@ -667,18 +682,20 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
     const int short_window = count != child;
     const bool in_lo = (w_lo & bit) != 0, in_hi = (w_hi & bit) != 0;
     const int nlo = __popcll(w_lo);
-    // the window nodes' side records and block sides, in flight under the set order
-    ulonglong2 sd[2][4];
-    int bd[2][3] = {{0, 0, 0}, {0, 0, 0}};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const bool on = (h ? in_hi : in_lo) && !short_window;
-        const int node = v + 64 * h;
+    // the side records and block sides of this lane's window node, in flight under the set order.  A lane seldom holds
+    // two window nodes (v and v + 64): the second one's are fetched afterwards, when it exists (keeps 19 registers free)
+    const bool both = in_lo && in_hi;
+    const int h1 = in_lo ? 0 : 1;                                        // the half served first
+    ulonglong2 sd[4];
+    int bd[3] = {0, 0, 0};
+    {
+        const bool on = (in_lo || in_hi) && !short_window;
+        const int node = v + 64 * h1;
         const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(relb + (size_t)N * NW + (size_t)node * 4 * NW);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sd[h][k] = on ? q[k] : make_ulonglong2(0ull, 0ull);
+        for (int k = 0; k < 4; ++k) sd[k] = on ? q[k] : make_ulonglong2(0ull, 0ull);
 #pragma unroll
-        for (int k = 0; k < D; ++k) bd[h][k] = on ? a.blocks[((size_t)inst * N + node) * D + k] : 0;
+        for (int k = 0; k < D; ++k) bd[k] = on ? a.blocks[((size_t)inst * N + node) * D + k] : 0;
     }
     tap_wave_lds_sync();
 
@@ -696,21 +713,38 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
 
     // (4) tensors (generate.py:1778-1822).  Scratch inside the (now idle) set-order tables: cw (packed form, at most
     //     126 columns) | iw: 5*child row words | dims: the block sides by sorted slot
-    unsigned *iw = reinterpret_cast<unsigned *>(S.tbl) + 256;
-    int *dims = S.tbl + 416;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (!(h ? in_hi : in_lo)) continue;
+    //     10-node windows (the reference's --nodes 10) finish in rolling_emit_fast's compile-time-shaped tail, which
+    //     reads the row words, the block sides and the nibble table from RollFastLds.
+    const bool fast = roll_fast_ok(D, child);
+    unsigned *iw = fast ? S.f.iw : reinterpret_cast<unsigned *>(S.tbl) + 256;
+    int *dims = fast ? &S.f.dims[0][0] : S.tbl + 416;
+    const int dstride = fast ? 4 : 3;
+    if (fast && v < 16)
+        *reinterpret_cast<float4 *>(&S.f.lut[v][0]) = make_float4((float)(v & 1), (float)((v >> 1) & 1), (float)((v >> 2) & 1), (float)((v >> 3) & 1));
+    auto publish = [&](int h, const ulonglong2 (&rec)[4], const int (&sides)[3]) {
         const int node = v + 64 * h;
         const int slot = h ? nlo + __popcll(w_hi & below) : __popcll(w_lo & below);    // sorted position
         const ulonglong2 m0 = h ? m_hi : m_lo;
         S.side[0][2 * slot] = m0.x; S.side[0][2 * slot + 1] = m0.y;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { S.side[1 + k][2 * slot] = sd[h][k].x; S.side[1 + k][2 * slot + 1] = sd[h][k].y; }
+        for (int k = 0; k < 4; ++k) { S.side[1 + k][2 * slot] = rec[k].x; S.side[1 + k][2 * slot + 1] = rec[k].y; }
 #pragma unroll
-        for (int k = 0; k < 3; ++k) dims[slot * 3 + k] = bd[h][k];
+        for (int k = 0; k < 3; ++k) dims[slot * dstride + k] = sides[k];
         S.srt[slot] = (unsigned char)node;
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + slot] = node;
+    };
+    if (in_lo || in_hi) publish(h1, sd, bd);
+    if (__ballot(both)) {                                              // rare: a lane with two window nodes
+        if (both) {
+            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(relb + (size_t)N * NW + (size_t)(v + 64) * 4 * NW);
+            ulonglong2 rec[4];
+            int sides[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rec[k] = q[k];
+#pragma unroll
+            for (int k = 0; k < D; ++k) sides[k] = a.blocks[((size_t)inst * N + v + 64) * D + k];
+            publish(1, rec, sides);
+        }
     }
     tap_wave_lds_sync();
     const u64 af_lo = all_lo & ~e_lo, af_hi = all_hi & ~e_hi;          // after_nodes_list
@@ -731,6 +765,10 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
         iw[idx] = w;
     }
     tap_wave_lds_sync();
+    if (fast) {                                                        // kernel-uniform
+        rolling_emit_fast_tail<D, 10>(a, inst, v, S);
+        return;
+    }
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
@@ -741,7 +779,7 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
         const int r = col / child, cm = col - r * child;
         const int *p = D == 2 ? perm2[r] : perm3[r];
         st[col] = (float)cm;                                                          // :1795-1801, cm = sorted slot
-        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)dims[cm * 3 + p[k]];
+        for (int k = 0; k < D; ++k) st[(size_t)(1 + k) * nRc + col] = (float)dims[cm * dstride + p[k]];
         unsigned ws[3];
 #pragma unroll
         for (int sec = 0; sec < 3; ++sec) {                                           // :1808-1821, cm = sub-graph index
@@ -855,8 +893,6 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     PROF(3);
 }
 
-// window sizes with a compile-time-shaped kernel (0 = any window, shapes read from the arguments)
-__host__ __device__ constexpr bool roll_fast_ok(int D, int child) { return child == 10 && (D == 2 || D == 3); }
 // instances the two-word wavefront form takes (rolling_window_wave2)
 __host__ __device__ constexpr bool roll_wide_ok(int N, int child) { return N > 64 && N <= 128 && child <= 32; }
 
@@ -1198,8 +1234,9 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
     if (grid == 0) return TAP_OK;
     const bool hard = a.s.d.flags & TAP_F_HARD;              // soft rewards: no hard-mode walk compiled in
     if (a.r.N > 64) {
-        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, a);
+        // (soft rewards too: the soft-only kernel's 64-register cap costs the two-word window code 20 spilled registers
+        //  and 24.6 against 21.1 us per step at N = 100, B = 8192; this one is held to 72)
+        hipLaunchKernelGGL((k_rolling_step<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, a);
     } else if (roll_fast_ok(D, a.r.child)) {
         if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
         else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
