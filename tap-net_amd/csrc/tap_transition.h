@@ -1,4 +1,5 @@
-// tap_transition.h -- what the fused-step kernels of transition.hip and transition_wide.hip share: the argument
+// tap_transition.h -- what the fused-step kernels of transition.hip share (kept apart so that a further translation
+// unit of fused kernels can compile beside it): the argument
 // block, the stream wave (the precedence update of one or two envs by one wavefront) and the workgroup geometry.
 #pragma once
 
