@@ -14,6 +14,8 @@
 // two kinds never exchange data, so there is no s_barrier: lane groups never span a wave and LDS
 // hand-offs only need compiler ordering.  (A first version that let the same waves stream and then
 // place showed no gain: every workgroup was in the same phase at the same time.)
+// This file: the LB_GREEDY kernel and the tap_transition* entry points; the MACS / MUL kernels of the same shape live in
+// transition_macs.hip (tap_transition_macs_launch), so that the two halves compile side by side.
 #include <cstdlib>
 
 #include "tap_common.h"
@@ -48,165 +50,8 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
                             s_old + (tid - cell), s_new + (tid - cell));
 }
 
-// ---- the same fusion for MACS / MUL 2D (tap_macs.h): G = 8/16 lanes per env ---------------------
-// (Register cliff, measured in round 3: a workgroup is 5 waves and a CU gets 4 of them at B = 8192; at 71 VGPRs -- 7
-//  waves per SIMD -- the step takes 17.8 us, at 85 -- 5 per SIMD, where the 20 waves only fit if the dispatcher spreads
-//  them perfectly -- 23.6 us.  A window-maximum form of macs_adj (80 instead of 590 instructions, tie-break 5.1 k -> 2.6 k
-//  cycles stand-alone) crossed that line and was dropped; amdgpu_waves_per_eu(7, 8) brings either form to 72 VGPRs but
-//  costs 3 % by itself.)
-template <int G, int NC, int MODE>
-__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(TransArgs a)
-{
-    using Geo = TransGeom<G, 4>;
-    constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
-    extern __shared__ float trans_lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int env_base = blockIdx.x * EPB;
-    const int B = a.s.d.B, W = a.s.d.W, H = a.s.d.H;
-    if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
-                                     trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
-        return;
-    }
-    __builtin_amdgcn_s_setprio(3);   // (2 -> 3: +2 % at c4; without a raised priority the step takes 23.5 instead of 18.0 us)
-    int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
-    const bool fresh = a.flags & TAP_T_FRESH;
-    const int cell = tid % G, gl0 = lane - cell;
-    const int env = env_base + tid / G;
-    const bool ev = env < B, incell = cell < W;
-    const MacsLds L = macs_lds(macs_base + (tid / G) * macs_group_words(G, H, a.s.d.n_max, W), G, H, macs_ems_cap(W, a.s.d.n_max));
-    int hm = 0, cv = 0, bx = 1, bz = 1;
-    if (ev) {
-        if (!fresh) {
-            if (incell) hm = a.s.v.hm[(size_t)env * W + cell];
-            if (cell < 4) cv = a.s.v.cnt[(size_t)env * 4 + cell];
-        }
-        bool badp;
-        const long p = tap_col((long)a.s.ptr[env], a.s.nR, badp);
-        const float vx = a.s.static_[((size_t)env * a.s.static_rows + 1) * a.s.nR + p];
-        const float vz = a.s.static_[((size_t)env * a.s.static_rows + 2) * a.s.nR + p];
-        bx = badp ? 0 : (int)vx;
-        bz = badp ? 0 : (int)vz;
-    }
-    Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
-    int err = 0;
-    bool do_step = ev;
-    if (ev && cnt.count >= a.s.d.n_max) { err |= 2; do_step = false; }
-    if (ev && (bx < 1 || bz < 1)) { err |= 4; do_step = false; }
-    L.hm[cell] = hm;
-    for (int i = cell; i < H; i += G) L.taken[i] = 0;
-    if (ev)
-        for (int k = cell; k < cnt.count * 4 && k < a.s.d.n_max * 4; k += G) {
-            const int i = k >> 2, f = k & 3;
-            L.hist[k] = (f < 2 ? a.s.v.pos : a.s.v.blk)[(size_t)(i * 2 + (f & 1)) * B + env];
-        }
-    tap_wave_lds_sync();
-    const int step = cnt.count;
-    const PlaceCfg cfg = {W, 1, H, a.s.d.flags, nullptr};
-    const Placement pl = tap_macs_place<G>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
-    err = group_or<G>(err);
-    tap_wave_lds_sync();
-    L.hm[cell] = hm;
-    tap_wave_lds_sync();
-    const int gmax = (a.flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
-    if (ev) {
-        if (incell) a.s.v.hm[(size_t)env * W + cell] = hm;
-        if (a.s.feature_out)
-            tap_write_feature<2, G>(a.s.d.feature, W, 1, L.hm, cell, hm, a.s.feature_out + (size_t)env * a.s.flen);
-        if (cell == 0) {
-            if (do_step || fresh)
-                reinterpret_cast<int4 *>(a.s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
-            if (do_step) {
-                a.s.v.pos[(size_t)(step * 2) * B + env] = pl.x;
-                a.s.v.pos[(size_t)(step * 2 + 1) * B + env] = pl.z;
-                a.s.v.stable[(size_t)step * B + env] = (uint8_t)pl.stab;
-                a.s.v.blk[(size_t)(step * 2) * B + env] = bx;
-                a.s.v.blk[(size_t)(step * 2 + 1) * B + env] = bz;
-            }
-            if (fresh) a.s.v.err[env] = err;
-            else if (err) a.s.v.err[env] |= err;
-            if (a.flags & TAP_T_RATIO) {
-                double C = 0.0, P = 0.0, S = 0.0;
-                if (cnt.count != 0) {
-                    C = (double)cnt.valid / (double)((long long)W * gmax);
-                    P = (double)cnt.valid / (double)(cnt.empty + cnt.valid);
-                    S = (double)cnt.nstable / (double)cnt.count;
-                }
-                a.ratio_out[env] = (float)tap_ratio_formula(a.s.d.ratio_mode, C, P, S);
-            }
-        }
-    } else if (a.s.d.feature == TAP_FEAT_ZERO) {
-        (void)group_min<G>(INT_MAX);
-    }
-}
-
-// ---- and for MACS / MUL 3D (tap_macs3.h): G = 8..64 lanes per env --------------------------------
-template <int G, int NC, int MODE>
-__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3(TransArgs a)
-{
-    using Geo = TransGeom<G, 4>;
-    constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
-    extern __shared__ float trans_lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int env_base = blockIdx.x * EPB;
-    if (wave >= ENV_WAVES) {
-        trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
-                                     trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
-        return;
-    }
-    __builtin_amdgcn_s_setprio(2);
-    int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
-    tap_macs3_wave<G>(a.s, a.flags, a.ratio_out, env_base + tid / G, tid % G, lane,
-                      macs_base + (tid / G) * macs3_group_words(G, a.s.d.n_max, a.s.d.H));
-}
-
-template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
-{
-    constexpr int EPB = TransGeom<G, 4>::EPB, THREADS = TransGeom<G, 4>::THREADS;
-    const int grid = (a.s.d.B + EPB - 1) / EPB;
-    if (grid == 0) return TAP_OK;
-    const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
-                       (size_t)EPB * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
-    if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
-    const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
-    switch (mask_fast_path_cols(a.m)) {
-    case 1: TAP_LAUNCH_M(1, lds); break;
-    case 2: TAP_LAUNCH_M(2, lds); break;
-    case 4: TAP_LAUNCH_M(4, lds); break;
-    default: TAP_LAUNCH_T(0, 0, lds); break;
-    }
-#undef TAP_LAUNCH_M
-#undef TAP_LAUNCH_T
-    TAP_LAUNCH_CHECK(ctx, "k_transition_macs3");
-    return TAP_OK;
-}
-
-int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d); // macs.hip
-
-template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
-{
-    constexpr int EPB = TransGeom<G, 4>::EPB, THREADS = TransGeom<G, 4>::THREADS;
-    const int grid = (a.s.d.B + EPB - 1) / EPB;
-    if (grid == 0) return TAP_OK;
-    const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
-                       (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max, a.s.d.W) * sizeof(int);
-    if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
-    const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition_macs<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
-    switch (mask_fast_path_cols(a.m)) {
-    case 1: TAP_LAUNCH_M(1, lds); break;
-    case 2: TAP_LAUNCH_M(2, lds); break;
-    case 4: TAP_LAUNCH_M(4, lds); break;
-    default: TAP_LAUNCH_T(0, 0, lds); break;
-    }
-#undef TAP_LAUNCH_M
-#undef TAP_LAUNCH_T
-    TAP_LAUNCH_CHECK(ctx, "k_transition_macs");
-    return TAP_OK;
-}
+int tap_transition_macs_launch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);   // transition_macs.hip
+int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d);                                                    // macs.hip
 
 template <int D, int G, int SW>
 static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
@@ -369,17 +214,7 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream)
 {
     const int Gs = tap_group_size(d);
-    if (d->strategy == TAP_MACS && d->D == 3) {
-        switch (Gs) {
-        case 8: return launch_transition_macs3<8>(ctx, a, (hipStream_t)stream);
-        case 16: return launch_transition_macs3<16>(ctx, a, (hipStream_t)stream);
-        case 32: return launch_transition_macs3<32>(ctx, a, (hipStream_t)stream);
-        default: return launch_transition_macs3<64>(ctx, a, (hipStream_t)stream);
-        }
-    }
-    if (d->strategy == TAP_MACS)   // (16 lanes per container for W <= 8 measured 2.3 x slower at c4: the per-lane work grows with G)
-        return d->W <= 8 ? launch_transition_macs<8>(ctx, a, (hipStream_t)stream)
-                         : launch_transition_macs<16>(ctx, a, (hipStream_t)stream);
+    if (d->strategy == TAP_MACS) return tap_transition_macs_launch(ctx, d, a, (hipStream_t)stream);
     if (d->D == 2) {
         if (Gs == 8) return launch_transition<2, 8>(ctx, a, (hipStream_t)stream);
         if (Gs == 16) return launch_transition<2, 16>(ctx, a, (hipStream_t)stream);
