@@ -109,7 +109,7 @@ template <int G> __device__ __forceinline__ int macs_sum(const int (&hmr)[G], in
     return s;
 }
 
-// -DTAP_PROF: shader-clock deltas per phase, first lane of each workgroup (scratch/prof_m2.py reads them)
+// -DTAP_PROF: shader-clock deltas per phase, first lane of each workgroup (scripts/prof_macs2d.py reads them)
 #ifdef TAP_PROF
 static __device__ unsigned int tap_prof_m2[8192 * 8];
 #define M2_PROF(i) do { const long long t_ = clock64(); if ((threadIdx.x) == 0 && blockIdx.x < 8192) tap_prof_m2[blockIdx.x * 8 + (i)] = (unsigned)(t_ - tp2_); tp2_ = t_; } while (0)
