@@ -999,29 +999,44 @@ def variants_rolling(cfg, hp, dev, use_graph, trace):
             raise RuntimeError("skipped")
         g = torch.Generator(device=dev)
         g.manual_seed(4242)
-        pol = T.RandomFeasiblePolicy(g)
         blocks = hp.rw.blocks
         positions = torch.as_tensor(hp.positions_h, device=dev)
+        pair = [None]
 
-        def run():
-            return T.run_rolling_episode(blocks, positions, hp.init, pol, cs[0], cs[-1], child_graph_size=hp.nw,
-                                         reward_type=reward)
-        r = run()
-        torch.cuda.synchronize(dev)
-        steps = 5
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r = run()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        r["env"].check(); r["windows"].check()
-        out["policy_in_loop"] = dict(value=B * n * steps / dt, unit="env-steps/s", steps=steps,
-                                     what="rollout.run_rolling_episode (relation masks rebuilt per episode, one fused "
-                                          "tap_rolling_step per window, then the last window's episode), "
-                                          "RandomFeasiblePolicy (torch.multinomial on current_mask) between the steps, "
-                                          "eager launches, fresh output tensors every step")
+        def run(pol):
+            r = T.run_rolling_episode(blocks, positions, hp.init, pol, cs[0], cs[-1], child_graph_size=hp.nw,
+                                      reward_type=reward, steppers=pair[0])
+            pair[0] = r["steppers"]
+            return r
+
+        def eager(pol, steps):
+            run(pol)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = run(pol)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter()
+            r["env"].check(); r["windows"].check()
+            return B * n * steps / (t2 - t0), (t1 - t0) / (steps * n) * 1e6, r
+
+        class FirstSelectable(object):                           # null policy: the first selectable column, one torch op
+            def __call__(self, current_mask, **_):
+                return torch.argmax(current_mask, dim=1)
+        v0, host0, _ = eager(FirstSelectable(), 5)
+        out["host_us_per_step"] = dict(value=host0, unit="us", eager_env_steps_per_s=v0,
+                                       what="host time to ISSUE one decoding step of rolling.run_rolling_episode on a persistent "
+                                            "RollingStepper / EpisodeStepper pair with a one-op policy (argmax of current_mask): "
+                                            "one C call (tap_roller_step / tap_stepper_step) + the launch + the policy's op")
+        v1, host1, _ = eager(T.RandomFeasiblePolicy(g), 5)
+        out["policy_in_loop"] = dict(value=v1, unit="env-steps/s", steps=5, host_us_per_step=host1,
+                                     what="rollout.run_rolling_episode on a persistent RollingStepper / EpisodeStepper pair "
+                                          "(relation masks rebuilt per episode, one fused tap_rolling_step per window, then the "
+                                          "last window's episode), RandomFeasiblePolicy (exponential race on current_mask, 3 "
+                                          "torch ops) between the steps, eager launches")
     except Exception as ex:                                  # pragma: no cover
-        out["policy_in_loop"] = dict(error=str(ex))
+        out["policy_in_loop"] = dict(error=str(ex)[:300])
     return out
 
 
@@ -1063,92 +1078,118 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
         del hps
     except Exception as ex:                                  # pragma: no cover
         out["cold"] = dict(error=str(ex))
-    # (b) a policy between the steps: rollout.run_episode with RandomFeasiblePolicy (torch.multinomial on
-    #     current_mask), eager launches, fresh output tensors every step -- the loop a trainer would run
-    trace("policy_in_loop")
-    try:
-        if "eager" in skip:
-            raise RuntimeError("skipped")
-        g = torch.Generator(device=dev)
-        g.manual_seed(4242)
-        pol = T.RandomFeasiblePolicy(g)
-        st, dy = hp.static[0], hp.dynamic0[0]
-        cw, ch = cs[0], cs[-1]
+    # (b) the loop a trainer runs: its policy between the steps, eager launches, ONE persistent pack.EpisodeStepper
+    #     (buffers owned by the stepper, one C call per step; pack.set_binary_check('trust'): no host read per episode)
+    st, dy = hp.static[0], hp.dynamic0[0]
+    cw, ch = cs[0], cs[-1]
+    O = _oracle()
 
-        def run():
-            # a fresh tensor per episode, as a DataLoader would hand over: its bit shadow is built again
-            return T.run_episode(st, dy.clone(), pol, cw, ch, reward_type=reward, packing_strategy=strategy)
-        for _ in range(3):
-            r = run()
-        torch.cuda.synchronize(dev)
-        steps = 30
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            r = run()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        r["env"].check()
-        out["policy_in_loop"] = dict(value=B * hp.nw * steps / dt, unit="env-steps/s", steps=steps,
-                                     what="rollout.run_episode, RandomFeasiblePolicy (torch.multinomial on current_mask) "
-                                          "between the fused steps, eager launches, bit shadow built per episode")
-    except Exception as ex:                                  # pragma: no cover
-        out["policy_in_loop"] = dict(error=str(ex))
-    # (c) the same loop -- policy included -- captured once in a hipGraph: with pack.set_binary_check('trust') the
-    #     seams make no host read, so episode set-up (fresh container, shadow + initial mask in one launch), the
-    #     policy's torch ops and the fused steps all replay from one graph
-    trace("policy_in_loop_graph")
-    try:
-        T.pack.set_binary_check('trust')
-        g2 = torch.Generator(device=dev)
-        g2.manual_seed(4243)
-        u = torch.rand(B, hp.nw, device=dev, generator=g2)      # refreshed (eagerly) before every replay
-        pol2 = T.UniformPickPolicy(u)
-        st, dy = hp.static[0], hp.dynamic0[0]
-        cw, ch = cs[0], cs[-1]
-
-        def run2():
-            return T.run_episode(st, dy.clone(), pol2, cw, ch, reward_type=reward, packing_strategy=strategy)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            run2(); run2()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        trace("capture")
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            rec = run2()
-        trace("replay")
-        for _ in range(3):
-            u.uniform_(generator=g2)
-            graph.replay()
-        torch.cuda.synchronize(dev)
-        trace("timed replays")
-        steps = 100
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            u.uniform_(generator=g2)
-            graph.replay()
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-        rec["env"].check()
-        T.pack.check_binary()
-        # the replayed episode is a real one: its tour is feasible and its reward is what the oracle gives for it
-        O = _oracle()
+    def oracle_ok(rec):
         V = min(VERIFY_ENVS, B)
         tour = rec["tour_idx"][:V].cpu().numpy()
         stn = st[:V].cpu().numpy()
         blocks = np.stack([stn[np.arange(V), 1:, tour[:, k]] for k in range(hp.nw)], axis=1).astype(np.int32)
         want = O.run_episodes(O.make_desc(cs, hp.nw, reward, "diff", strategy), blocks, nthreads=_usable_cpus(),
                               want_heightmaps=False)
-        okv = want["nerr"] == 0 and np.array_equal(rec["reward"][:V].cpu().numpy(), -want["ratio"].astype(np.float32))
-        out["policy_in_loop_graph"] = dict(value=B * hp.nw * steps / dt, unit="env-steps/s", steps=steps, verified=bool(okv),
-                                           what="rollout.run_episode with UniformPickPolicy (k-th selectable column by "
-                                                "cumulative sum, from uniforms drawn before each replay) captured in one "
-                                                "hipGraph -- fresh container, shadow + initial mask, the policy's torch ops and "
-                                                "the fused steps (pack.set_binary_check('trust'): no host read in the seams)")
+        return bool(want["nerr"] == 0 and np.array_equal(rec["reward"][:V].cpu().numpy(), -want["ratio"].astype(np.float32)))
+
+    def eager(pol, steps, stepper, check=True):
+        """-> (env-steps/s incl. drain, host us per decoding step to ISSUE the loop, record of the last episode)"""
+        run = lambda: T.run_episode(st, dy, pol, cw, ch, reward_type=reward, packing_strategy=strategy, stepper=stepper)  # noqa: E731
+        for _ in range(3):
+            r = run()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = run()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        if check:
+            r["stepper"].check()
+            T.pack.check_binary()
+        return B * hp.nw * steps / (t2 - t0), (t1 - t0) / (steps * hp.nw) * 1e6, r
+
+    try:
+        T.pack.set_binary_check('trust')
+        if "eager" in skip:
+            raise RuntimeError("skipped")
+        trace("policy_in_loop")
+        env_v = T.BatchedContainer(B, cs, hp.nw, reward, "diff", packing_strategy=strategy, device=dev)
+        sp = T.EpisodeStepper(st, dy, env_v, steps=hp.nw)
+        # null policy: a recorded tour -- what the host pays per decoding step for OUR side of the loop
+        tape_pol = T.TapePolicy(hp.tape[0].t())                 # hp.tape: (nw, B) per window -> (B, nw)
+        v_tape, host_us, r = eager(tape_pol, 100, sp)
+        out["host_us_per_step"] = dict(value=host_us, unit="us", eager_env_steps_per_s=v_tape, verified=oracle_ok(r),
+                                       what="host time to ISSUE one decoding step of rollout.run_episode on a persistent "
+                                            "pack.EpisodeStepper with a null policy (a recorded tour): argument checks + one C "
+                                            "call (tap_stepper_step) + the launch; eager, no graph; the env-steps/s figure "
+                                            "includes the drain (barrier-to-barrier)")
+        g = torch.Generator(device=dev)
+        g.manual_seed(4242)
+        v_pol, host_pol, r = eager(T.RandomFeasiblePolicy(g), 60, sp)
+        out["policy_in_loop"] = dict(value=v_pol, unit="env-steps/s", steps=60, host_us_per_step=host_pol, verified=oracle_ok(r),
+                                     what="rollout.run_episode on a persistent pack.EpisodeStepper, RandomFeasiblePolicy "
+                                          "(uniformly random selectable column: an exponential race on current_mask, 3 torch "
+                                          "ops) between the fused steps, eager launches, bit shadow and initial mask built "
+                                          "per episode; pack.set_binary_check('trust')")
+        g.manual_seed(4242)
+        v_mn, host_mn, r = eager(T.rollout.MultinomialPolicy(g), 30, sp)
+        out["policy_in_loop_multinomial"] = dict(value=v_mn, unit="env-steps/s", steps=30, host_us_per_step=host_mn,
+                                                 what="the same loop with round 3's stand-in policy, torch.multinomial on "
+                                                      "current_mask (~85 us of host per call by itself on this stack)")
     except Exception as ex:                                  # pragma: no cover
-        out["policy_in_loop_graph"] = dict(error=str(ex)[:300])
+        out.setdefault("policy_in_loop", dict(error=str(ex)[:300]))
+    # (c) the same loop -- policy included -- captured once in a hipGraph: the seams make no host read, so episode set-up
+    #     (fresh container, shadow + initial mask in one launch), the policy's torch ops and the fused steps all replay
+    def graphed(pol, refresh, stepper, steps=100):
+        run2 = lambda: T.run_episode(st, dy, pol, cw, ch, reward_type=reward, packing_strategy=strategy, stepper=stepper)  # noqa: E731
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run2(); run2()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            rec = run2()
+        for _ in range(3):
+            refresh()
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            refresh()
+            graph.replay()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        rec["stepper"].check()
+        T.pack.check_binary()
+        return B * hp.nw * steps / dt, rec
+
+    try:
+        if "graph" in skip:
+            raise RuntimeError("skipped")
+        trace("policy_in_loop_graph")
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(4243)
+        env_g = T.BatchedContainer(B, cs, hp.nw, reward, "diff", packing_strategy=strategy, device=dev)
+        spg = T.EpisodeStepper(st, dy, env_g, steps=hp.nw)
+        u = torch.rand(B, hp.nw, device=dev, generator=g2)      # refreshed (eagerly) before every replay
+        val, rec = graphed(T.UniformPickPolicy(u), lambda: u.uniform_(generator=g2), spg)
+        out["policy_in_loop_graph"] = dict(value=val, unit="env-steps/s", steps=100, verified=oracle_ok(rec),
+                                           what="rollout.run_episode with UniformPickPolicy (k-th selectable column by "
+                                                "cumulative sum, ~10 torch ops per step, from uniforms drawn before each "
+                                                "replay) captured in one hipGraph -- shadow + initial mask, the policy's "
+                                                "torch ops and the fused steps; the replayed tour is checked against the oracle")
+        trace("policy_in_loop_graph_keys")
+        keys = torch.empty(hp.nw, B, st.shape[2], device=dev).uniform_(1e-7, 1.0, generator=g2)
+        val, rec = graphed(T.UniformKeysPolicy(keys), lambda: keys.uniform_(1e-7, 1.0, generator=g2), spg)
+        out["policy_in_loop_graph_keys"] = dict(value=val, unit="env-steps/s", steps=100, verified=oracle_ok(rec),
+                                                what="the same with UniformKeysPolicy: argmax of pre-drawn iid keys over the "
+                                                     "selectable columns (uniform over them), 2 torch ops per step")
+    except Exception as ex:                                  # pragma: no cover
+        out.setdefault("policy_in_loop_graph", dict(error=str(ex)[:300]))
     finally:
         T.pack.set_binary_check('check')
     return out

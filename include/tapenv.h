@@ -411,6 +411,99 @@ int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *state, int n
                          float *dyn_out, float *current_out, float *mask_out, float *feature_out,
                          float *ratio_out, int32_t *nonbinary_out, int flags, void *stream);
 
+/* ---- the step object of a decoding loop ----------------------------------------------------- */
+/* DRL.forward's loop (model.py:342-496) runs its policy network between the environment steps, so the loop is
+ * issued from the host, step by step, and what the host pays per step counts.  A tap_stepper is
+ * tap_transition_first / tap_transition_bits with everything that does not change during an episode resolved
+ * once: the caller allocates TWO phases of the step's outputs (the step of index k writes phase k & 1 and reads
+ * phase (k & 1) ^ 1), the stepper remembers the pointers, alternates the phases, starts from a fresh container at
+ * step 0 and emits calc_ratio at step `steps` - 1 -- one call with two arguments per step, no allocation, no
+ * per-step argument marshalling.  The buffers stay the caller's (the library keeps no memory, only the addresses;
+ * they must outlive the stepper).  Host-side object, not thread-safe; launches are asynchronous on `stream`. */
+typedef struct tap_stepper tap_stepper;
+
+typedef struct tap_stepper_buffers {
+    unsigned long long *bits[2]; /* (B, nR) uint64 -- (B, 2, nR) above 64 rows: the bit shadow of dyn[w] */
+    float *dyn[2];               /* (B, rows, nR): update_dynamic's result (pack.py:333-376) */
+    float *current[2];           /* (B, nR): update_mask's new_mask.float() (pack.py:329-331) */
+    float *mask[2];              /* (B, nR): update_mask's chosen_mask */
+    float *feature;              /* (B, feature_len) nullable: add_new_block's return, layout of model.py:456-465 */
+    float *decoder_static;       /* (B, D) nullable: static[:, 1:1+D, ptr], the gather of model.py:404-406 */
+    float *ratio;                /* (B,): calc_ratio, written by the last step (model.py:499-510) */
+    int64_t *tour;               /* (B, tour_stride) nullable: column tour_col0 + k = the ptr of step k (model.py:495, 512) */
+    int32_t *nonbinary;          /* device int32, nullable, caller zeroes it: see tap_mask_step_first */
+    int32_t tour_stride;         /* 0 = steps */
+    int32_t tour_col0;           /* first tour column this stepper writes (a rolling episode's last window: N - child) */
+} tap_stepper_buffers;
+
+/* d / state: the containers (tap_env_desc_init, a blob of tap_env_state_bytes); n, R, rows, update_rows,
+ * static_rows as in tap_transition_bits; steps = decoding steps per episode (model.py:342: blocks_num).
+ * TAP_E_UNSUPPORTED when the window has no bit shadow (nR % 4 != 0, nR > 256, rows > 128): drive those shapes
+ * with tap_transition. */
+int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                       int update_rows, int static_rows, int steps, const tap_stepper_buffers *buf,
+                       tap_stepper **out);
+void tap_stepper_destroy(tap_stepper *s);
+
+enum {
+    TAP_SB_INITIAL_MASK = 1, /* tap_stepper_begin: also produce the masks DRL.forward starts from */
+    TAP_SB_CONTINUE = 2      /* step 0 goes on with the containers as they are (rolling.py:428: one long-lived
+                                container across the windows); default: step 0 starts from fresh containers */
+};
+
+/* Bind the next instance batch: static_ (B, static_rows, nR) and the fresh fp32 dynamic (B, rows, nR) a
+ * DataLoader hands over (pack.py:195); both are only read and must stay valid for the episode.
+ * TAP_SB_INITIAL_MASK: one launch builds the shadow and the masks DRL.forward starts from (model.py:297-307)
+ * into phase 1 -- current[1] is what the policy sees before step 0.  Without it: no launch, step 0 reads the
+ * tensor itself (a replayed tape needs no initial mask). */
+int tap_stepper_begin(tap_stepper *s, const float *static_, const float *dyn_in, int flags, void *stream);
+
+/* The same for a window whose bit shadow the caller already holds (tap_rolling_window / tap_rolling_step emit it
+ * next to the tensor): step 0 reads `bits` (B, nR) -- not phase 0's buffer -- and starts from an all-ones mask.
+ * No launch. */
+int tap_stepper_begin_shadow(tap_stepper *s, const float *static_, const unsigned long long *bits, int flags);
+
+/* One decoding step (model.py:376-465 in one launch, or the two launches tap_transition_bits runs for the shapes
+ * without a single kernel): ptr (B,) int64.  Writes phase (k & 1) of bits / dyn / current / mask, plus feature,
+ * decoder_static, tour[:, k] and -- at the last step -- ratio.  TAP_E_STEPS after `steps` steps. */
+int tap_stepper_step(tap_stepper *s, const int64_t *ptr, void *stream);
+/* steps taken since tap_stepper_begin */
+int tap_stepper_steps_done(const tap_stepper *s);
+
+/* The same for rolling.validate's loop (rolling.py:589-637; tap_rolling_window / tap_rolling_step): the caller
+ * allocates two phases of the window's static tensor and node list (a step reads the current window's and writes
+ * the next one's), one buffer of everything else; a step is one call with two arguments and its launch also
+ * writes decoder_static, the tour column and the picked block's GLOBAL id (sub_graph_nodes[ptr], rolling.py:637).
+ * After tap_roller_begin the first window is in phase 0; after step k the next window is in phase (k + 1) & 1.
+ * After N - child steps the current window is the instance's last graph: run its episode with a tap_stepper
+ * (tap_stepper_begin_shadow on static_[phase] and bits, TAP_SB_CONTINUE, tour_col0 = N - child). */
+typedef struct tap_roller tap_roller;
+
+typedef struct tap_roller_buffers {
+    float *static_[2];              /* (B, 1+D, child*R) */
+    int32_t *nodes[2];              /* (B, child): sorted global block ids = static's columns */
+    float *dynamic;                 /* (B, 3*child, child*R) */
+    unsigned long long *bits;       /* (B, child*R) nullable: dynamic's bit shadow (needs 3*child <= 64) */
+    float *colsum;                  /* (B, 3, child*R) nullable */
+    float *current_mask;            /* (B, child*R) nullable (model.py:297-307) */
+    int32_t *err;                   /* (B,) nullable: raised to 1 when a window could not be filled; cleared by begin */
+    float *feature;                 /* (B, feature_len) nullable */
+    float *decoder_static;          /* (B, D) nullable */
+    int64_t *tour;                  /* (B, tour_stride) nullable: column k = the pick in window k */
+    int32_t *picked;                /* (B, tour_stride) nullable: column k = global id of the block picked in window k */
+    int32_t tour_stride;            /* >= N - child (N to leave room for the last window's episode) */
+} tap_roller_buffers;
+
+int tap_roller_create(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
+                      const tap_roller_buffers *buf, tap_roller **out);
+void tap_roller_destroy(tap_roller *r);
+/* blocks / rel / state as tap_rolling_init produced them (state is consumed: re-run tap_rolling_init, or restore
+ * a saved copy, per episode).  Emits the first window into phase 0. */
+int tap_roller_begin(tap_roller *r, const int32_t *blocks, const uint64_t *rel, uint64_t *state, void *stream);
+/* place the block picked in the current window + emit the next window: tap_rolling_step */
+int tap_roller_step(tap_roller *r, const int64_t *ptr, void *stream);
+int tap_roller_steps_done(const tap_roller *r);
+
 /* ---- measurement support ------------------------------------------------------------------ */
 
 /* Bandwidth calibration in the hot kernels' own access shape (16 bytes per lane, a wavefront covers 1 KiB): SURVEY

@@ -9,11 +9,11 @@ from . import _lib, build, datafiles, dist, env, generate, pack, rolling, rollou
 from ._lib import TapError, TapOverflowError                   # noqa: F401
 from .env import BatchedContainer, Container                   # noqa: F401
 from .generate import generate_instances                       # noqa: F401
-from .pack import (EnvTransition, MaskStepper, PACKDataset, episode_scores, initial_mask, render, reward,   # noqa: F401
+from .pack import (EnvTransition, EpisodeStepper, MaskStepper, PACKDataset, episode_scores, initial_mask, render, reward,   # noqa: F401
                    update_dynamic, update_mask)
-from .rolling import RollingDataset, RollingWindows, run_rolling_episode            # noqa: F401
-from .rollout import RandomFeasiblePolicy, TapePolicy, UniformPickPolicy, run_episode   # noqa: F401
+from .rolling import RollingDataset, RollingStepper, RollingWindows, run_rolling_episode            # noqa: F401
+from .rollout import RandomFeasiblePolicy, TapePolicy, UniformKeysPolicy, UniformPickPolicy, run_episode   # noqa: F401
 
-__all__ = ["BatchedContainer", "Container", "MaskStepper", "EnvTransition", "PACKDataset", "initial_mask", "reward", "render", "episode_scores", "RollingDataset",
-           "update_dynamic", "update_mask", "run_episode", "TapePolicy", "RandomFeasiblePolicy", "UniformPickPolicy",
-           "generate_instances", "RollingWindows", "run_rolling_episode", "TapError", "TapOverflowError"]
+__all__ = ["BatchedContainer", "Container", "MaskStepper", "EnvTransition", "EpisodeStepper", "PACKDataset", "initial_mask", "reward", "render", "episode_scores", "RollingDataset",
+           "update_dynamic", "update_mask", "run_episode", "TapePolicy", "RandomFeasiblePolicy", "UniformPickPolicy", "UniformKeysPolicy",
+           "generate_instances", "RollingWindows", "RollingStepper", "run_rolling_episode", "TapError", "TapOverflowError"]

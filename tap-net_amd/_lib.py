@@ -18,6 +18,10 @@ TAP_E_INVALID, TAP_E_UNSUPPORTED, TAP_E_HIP, TAP_E_OVERFLOW, TAP_E_NODEVICE, TAP
 TAP_LB_GREEDY, TAP_MACS, TAP_LB = 0, 1, 2
 TAP_DT_F32, TAP_DT_I32 = 0, 1
 TAP_T_FRESH, TAP_T_RATIO = 1, 2
+TAP_SB_INITIAL_MASK, TAP_SB_CONTINUE = 1, 2
+
+
+_vp_t = C.c_void_p
 
 
 class TapError(RuntimeError):
@@ -28,6 +32,20 @@ class TapError(RuntimeError):
 
 class TapOverflowError(TapError, IndexError):
     """A placement reached above the container height (the reference raises IndexError)."""
+
+
+class StepperBuffers(C.Structure):
+    """tapenv.h: tap_stepper_buffers"""
+    _fields_ = [("bits", _vp_t * 2), ("dyn", _vp_t * 2), ("current", _vp_t * 2), ("mask", _vp_t * 2),
+                ("feature", _vp_t), ("decoder_static", _vp_t), ("ratio", _vp_t), ("tour", _vp_t), ("nonbinary", _vp_t),
+                ("tour_stride", C.c_int32), ("tour_col0", C.c_int32)]
+
+
+class RollerBuffers(C.Structure):
+    """tapenv.h: tap_roller_buffers"""
+    _fields_ = [("static_", _vp_t * 2), ("nodes", _vp_t * 2), ("dynamic", _vp_t), ("bits", _vp_t), ("colsum", _vp_t),
+                ("current_mask", _vp_t), ("err", _vp_t), ("feature", _vp_t), ("decoder_static", _vp_t), ("tour", _vp_t),
+                ("picked", _vp_t), ("tour_stride", C.c_int32)]
 
 
 class EnvDesc(C.Structure):
@@ -86,6 +104,17 @@ _PROTOS = {
     "tap_transition_bits": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tap_bw_probe": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
+    "tap_stepper_create": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_vp)]),
+    "tap_stepper_destroy": (None, [_vp]),
+    "tap_stepper_begin": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "tap_stepper_begin_shadow": (_i, [_vp, _vp, _vp, _i]),
+    "tap_stepper_step": (_i, [_vp, _vp, _vp]),
+    "tap_stepper_steps_done": (_i, [_vp]),
+    "tap_roller_create": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _vp, C.POINTER(_vp)]),
+    "tap_roller_destroy": (None, [_vp]),
+    "tap_roller_begin": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "tap_roller_step": (_i, [_vp, _vp, _vp]),
+    "tap_roller_steps_done": (_i, [_vp]),
 }
 EXPORTS = tuple(_PROTOS)
 
@@ -164,6 +193,13 @@ def stream_of(device):
     if _raw_stream is not None and isinstance(device, torch.device) and device.index is not None:
         return _vp(_raw_stream(device.index))          # no Stream object, no device look-up: ~0.3 us instead of ~5
     return _vp(torch.cuda.current_stream(device).cuda_stream)
+
+
+def raw_stream(index):
+    """The current HIP stream of device ``index`` as an integer handle (what a c_void_p argument accepts)."""
+    if _raw_stream is not None:
+        return _raw_stream(index)
+    return torch.cuda.current_stream(index).cuda_stream
 
 
 def ptr(t):

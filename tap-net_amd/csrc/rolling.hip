@@ -17,6 +17,8 @@
 // the sorted order (generate.py:1758-1761 vs 1774, 1793).  pyset_* below re-states
 // Objects/setobject.c for small ints (hash(n) == n): 9 linear probes, perturb shift 5, growth x4
 // once fill*5 >= mask*3.
+#include <new>
+
 #include "tap_common.h"
 #include "tap_masks.h"
 #include "tap_place.h"
@@ -36,6 +38,7 @@ struct RollArgs {
     float *cur_mask_out;      // (B, child*R) nullable
     int32_t *nodes_out;       // (B, child) nullable
     int32_t *err_out;         // (B,) nullable: 1 = window could not be filled
+    int err_sticky;           // only ever raise err_out (tap_roller: one flag for the whole episode)
 };
 
 __device__ __forceinline__ bool rng_meet(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
@@ -707,7 +710,7 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
     tap_wave_lds_sync();
     if (v == 0) {
         stp[0] = e_lo; stp[1] = e_hi; stp[2] = w_lo; stp[3] = w_hi;
-        if (a.err_out) a.err_out[inst] = short_window;
+        if (a.err_out && (short_window || !a.err_sticky)) a.err_out[inst] = short_window;
     }
     if (short_window) return;
 
@@ -884,7 +887,7 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
     if (v == 0) {
         a.state[(size_t)inst * 2] = entered;
         a.state[(size_t)inst * 2 + 1] = window;
-        if (a.err_out) a.err_out[inst] = short_window;
+        if (a.err_out && (short_window || !a.err_sticky)) a.err_out[inst] = short_window;
     }
     if (short_window) return;
     PROF(2);
@@ -1081,7 +1084,7 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
     for (int k = 0; k < NW; ++k) { entered.w[k] |= added.w[k]; window.w[k] |= added.w[k]; }
     const int short_window = count != child;
     for (int k = 0; k < NW; ++k) { stp[k] = entered.w[k]; stp[NW + k] = window.w[k]; }
-    if (a.err_out) a.err_out[inst] = short_window;
+    if (a.err_out && (short_window || !a.err_sticky)) a.err_out[inst] = short_window;
     if (short_window) return;
     int tbl[PYSET_CAP], tmp[PYSET_CAP];                               // the set-order tables, thread-private
     if (2 * child < N) pyset_order(lst, child, ord, tbl, tmp);        // (3)
@@ -1181,16 +1184,33 @@ extern "C" int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t
     return TAP_OK;
 }
 
+static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
+                               const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
+                               float *static_out, float *dynamic_out, float *colsum_out,
+                               uint64_t *bits_out, float *current_mask_out, int32_t *nodes_out,
+                               int32_t *err_out, void *stream, int err_sticky);
+
 extern "C" int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
                                   const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
                                   float *static_out, float *dynamic_out, float *colsum_out,
                                   uint64_t *bits_out, float *current_mask_out, int32_t *nodes_out,
                                   int32_t *err_out, void *stream)
 {
+    return rolling_window_impl(ctx, B, D, N, child, blocks, rel, state, remove_ptr, static_out, dynamic_out, colsum_out,
+                               bits_out, current_mask_out, nodes_out, err_out, stream, 0);
+}
+
+static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
+                               const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
+                               float *static_out, float *dynamic_out, float *colsum_out,
+                               uint64_t *bits_out, float *current_mask_out, int32_t *nodes_out,
+                               int32_t *err_out, void *stream, int err_sticky)
+{
     int rc = roll_check(ctx, B, D, N, child);
     if (rc) return rc;
     if (!blocks || !rel || !state || !static_out || !dynamic_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     RollArgs a = {};
+    a.err_sticky = err_sticky;
     a.B = B; a.D = D; a.N = N; a.child = child; a.blocks = blocks;
     a.rel = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(rel));
     a.state = reinterpret_cast<unsigned long long *>(state);
@@ -1248,12 +1268,21 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
     return TAP_OK;
 }
 
-extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
-                                const int32_t *blocks, const uint64_t *rel, uint64_t *state,
-                                const int64_t *ptr, const float *static_cur, float *static_next,
-                                float *dynamic_out, float *colsum_out, uint64_t *bits_out,
-                                float *current_mask_out, int32_t *nodes_out, int32_t *err_out,
-                                float *feature_out, void *stream)
+// by-products of a roller's step (tap_common.h: StepArgs aux fields) + the sticky error flag
+struct RollAux {
+    float *dec_static_out;
+    int64_t *tour_out;
+    int32_t *picked_out;
+    const int32_t *nodes_cur;
+    int tour_stride, tour_col;
+};
+
+static int rolling_step_impl(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
+                             const int32_t *blocks, const uint64_t *rel, uint64_t *state,
+                             const int64_t *ptr, const float *static_cur, float *static_next,
+                             float *dynamic_out, float *colsum_out, uint64_t *bits_out,
+                             float *current_mask_out, int32_t *nodes_out, int32_t *err_out,
+                             float *feature_out, void *stream, const RollAux *aux)
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
@@ -1268,11 +1297,19 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
         // blocks): the same step as its two launches
         rc = tap_env_step_gather(ctx, d, env_state, static_cur, 1 + d->D, child * (d->D == 2 ? 2 : 6), ptr, nullptr,
                                  feature_out, stream);
-        return rc ? rc : tap_rolling_window(ctx, d->B, d->D, N, child, blocks, rel, state, ptr, static_next, dynamic_out,
-                                            colsum_out, bits_out, current_mask_out, nodes_out, err_out, stream);
+        if (rc == TAP_OK && aux) {
+            StepArgs s = {};
+            s.d = *d; s.static_ = static_cur; s.static_rows = 1 + d->D; s.nR = child * (d->D == 2 ? 2 : 6); s.ptr = ptr;
+            s.dec_static_out = aux->dec_static_out; s.tour_out = aux->tour_out; s.picked_out = aux->picked_out;
+            s.nodes_cur = aux->nodes_cur; s.child = child; s.tour_stride = aux->tour_stride; s.tour_col = aux->tour_col;
+            rc = tap_step_aux_launch(ctx, s, (hipStream_t)stream);
+        }
+        return rc ? rc : rolling_window_impl(ctx, d->B, d->D, N, child, blocks, rel, state, ptr, static_next, dynamic_out,
+                                             colsum_out, bits_out, current_mask_out, nodes_out, err_out, stream, aux != nullptr);
     }
     RollStepArgs a = {};
     const int R = d->D == 2 ? 2 : 6;
+    a.r.err_sticky = aux != nullptr;
     a.r.B = d->B; a.r.D = d->D; a.r.N = N; a.r.child = child; a.r.blocks = blocks;
     a.r.rel = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(rel));
     a.r.state = reinterpret_cast<unsigned long long *>(state);
@@ -1286,6 +1323,10 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     a.s.static_ = static_cur; a.s.static_rows = 1 + d->D; a.s.nR = child * R; a.s.ptr = ptr;
     a.s.feature_out = feature_out; a.s.flen = tap_env_feature_len(d);
     a.s.lut = ctx ? ctx->stab_lut : nullptr;
+    if (aux) {
+        a.s.dec_static_out = aux->dec_static_out; a.s.tour_out = aux->tour_out; a.s.picked_out = aux->picked_out;
+        a.s.nodes_cur = aux->nodes_cur; a.s.child = child; a.s.tour_stride = aux->tour_stride; a.s.tour_col = aux->tour_col;
+    }
     const int Gs = tap_group_size(d);
     hipStream_t st = (hipStream_t)stream;
     if (d->D == 2) {
@@ -1299,3 +1340,107 @@ extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_s
     if (Gs == 32) return launch_rolling_step<3, 32>(ctx, a, st);
     return launch_rolling_step<3, 64>(ctx, a, st);
 }
+
+extern "C" int tap_rolling_step(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
+                                const int32_t *blocks, const uint64_t *rel, uint64_t *state,
+                                const int64_t *ptr, const float *static_cur, float *static_next,
+                                float *dynamic_out, float *colsum_out, uint64_t *bits_out,
+                                float *current_mask_out, int32_t *nodes_out, int32_t *err_out,
+                                float *feature_out, void *stream)
+{
+    return rolling_step_impl(ctx, d, env_state, N, child, blocks, rel, state, ptr, static_cur, static_next, dynamic_out,
+                             colsum_out, bits_out, current_mask_out, nodes_out, err_out, feature_out, stream, nullptr);
+}
+
+// ---- tap_roller: the step object of rolling.validate's loop (tapenv.h) --------------------------------------------
+// Host-side only, like tap_stepper (transition.hip): remembers the caller's buffers, alternates the two phases of
+// the window's static tensor and node list, and has the step's launch write decoder_static, the tour column and
+// the picked block's global id.
+struct tap_roller {
+    tap_ctx *ctx;
+    tap_env_desc d;
+    void *env_state;
+    int N, child;
+    tap_roller_buffers b;
+    const int32_t *blocks;
+    const uint64_t *rel;
+    uint64_t *state;
+    int k;   // windows emitted so far minus one = index of the next step; -1 before begin
+};
+
+__global__ void __launch_bounds__(TAP_BLOCK) k_roll_zero_i32(int32_t *p, int n)
+{
+    const int i = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
+struct RollDeviceGuard {
+    int prev, want;
+    explicit RollDeviceGuard(int dev) : prev(-1), want(dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~RollDeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
+extern "C" int tap_roller_create(tap_ctx *ctx, const tap_env_desc *d, void *env_state, int N, int child,
+                                 const tap_roller_buffers *buf, tap_roller **out)
+{
+    if (!ctx || !d || !buf || !out) return TAP_E_INVALID;
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    rc = roll_check(ctx, d->B, d->D, N, child);
+    if (rc) return rc;
+    if (!env_state || !buf->static_[0] || !buf->static_[1] || buf->static_[0] == buf->static_[1] || !buf->dynamic ||
+        !buf->nodes[0] || !buf->nodes[1] || buf->nodes[0] == buf->nodes[1])
+        return tap_fail(ctx, TAP_E_INVALID, "roller needs both phases of static / nodes (distinct) and dynamic");
+    if ((buf->tour || buf->picked) && buf->tour_stride < N - child)
+        return tap_fail(ctx, TAP_E_INVALID, "roller tour_stride must hold the N - child single-step windows");
+    tap_roller *r = new (std::nothrow) tap_roller();
+    if (!r) return tap_fail(ctx, TAP_E_INVALID, "out of host memory");
+    r->ctx = ctx; r->d = *d; r->env_state = env_state; r->N = N; r->child = child; r->b = *buf;
+    r->blocks = nullptr; r->rel = nullptr; r->state = nullptr; r->k = -1;
+    *out = r;
+    return TAP_OK;
+}
+
+extern "C" void tap_roller_destroy(tap_roller *r) { delete r; }
+
+extern "C" int tap_roller_begin(tap_roller *r, const int32_t *blocks, const uint64_t *rel, uint64_t *state, void *stream)
+{
+    if (!r) return TAP_E_INVALID;
+    if (!blocks || !rel || !state) return tap_fail(r->ctx, TAP_E_INVALID, "roller_begin needs blocks, rel and state");
+    r->blocks = blocks; r->rel = rel; r->state = state; r->k = -1;
+    if (r->d.B == 0) { r->k = 0; return TAP_OK; }
+    RollDeviceGuard g(r->ctx->device);
+    if (r->b.err) {
+        hipLaunchKernelGGL(k_roll_zero_i32, dim3((r->d.B + TAP_BLOCK - 1) / TAP_BLOCK), dim3(TAP_BLOCK), 0, (hipStream_t)stream,
+                           r->b.err, r->d.B);
+        TAP_LAUNCH_CHECK(r->ctx, "k_roll_zero_i32");
+    }
+    const int rc = rolling_window_impl(r->ctx, r->d.B, r->d.D, r->N, r->child, blocks, rel, state, nullptr, r->b.static_[0],
+                                       r->b.dynamic, r->b.colsum, reinterpret_cast<uint64_t *>(r->b.bits), r->b.current_mask,
+                                       r->b.nodes[0], r->b.err, stream, 1);
+    if (rc == TAP_OK) r->k = 0;
+    return rc;
+}
+
+extern "C" int tap_roller_step(tap_roller *r, const int64_t *ptr, void *stream)
+{
+    if (!r) return TAP_E_INVALID;
+    if (r->k < 0) return tap_fail(r->ctx, TAP_E_INVALID, "tap_roller_begin has not been called");
+    if (r->k >= r->N - r->child) return tap_fail(r->ctx, TAP_E_STEPS, "all %d single-step windows are done", r->N - r->child);
+    if (!ptr) return tap_fail(r->ctx, TAP_E_INVALID, "null ptr");
+    const int k = r->k, cur = k & 1, nxt = cur ^ 1;
+    const RollAux aux = {r->b.decoder_static, r->b.tour, r->b.picked, r->b.nodes[cur], r->b.tour_stride, k};
+    RollDeviceGuard g(r->ctx->device);
+    const int rc = rolling_step_impl(r->ctx, &r->d, r->env_state, r->N, r->child, r->blocks, r->rel, r->state, ptr,
+                                     r->b.static_[cur], r->b.static_[nxt], r->b.dynamic, r->b.colsum,
+                                     reinterpret_cast<uint64_t *>(r->b.bits), r->b.current_mask, r->b.nodes[nxt], r->b.err,
+                                     r->b.feature, stream, &aux);
+    if (rc == TAP_OK) r->k = k + 1;
+    return rc;
+}
+
+extern "C" int tap_roller_steps_done(const tap_roller *r) { return r ? r->k : TAP_E_INVALID; }

@@ -134,7 +134,32 @@ struct StepArgs {
     float *feature_out;
     int flen;
     const uint32_t *lut; // ctx->stab_lut
+    // by-products of the gather for a caller that drives the decoding loop (stepper.hip; model.py:404-406, 512):
+    // the chosen block's sides as the floats `static` holds -- decoder_static (B, D, 1) -- and the pick itself
+    // into column tour_col of a (B, tour_stride) int64 tour.  Null = not wanted.  Written by the fused kernels'
+    // placement waves (tap_step_aux); the stand-alone steps ignore them.
+    float *dec_static_out;
+    int64_t *tour_out;
+    int tour_stride, tour_col;
+    // rolling windows (rolling.py:637 sub_graph_nodes[ptr]): the global id of the picked block -- entry ptr % child of
+    // the CURRENT window's node list (B, child) -- into column tour_col of a (B, tour_stride) int32 array
+    const int32_t *nodes_cur;
+    int32_t *picked_out;
+    int child;
 };
+
+// model.py:404-406 (decoder_static = static[:, 1:, ptr]) and the tour column of model.py:512, by the lane that
+// holds the gathered sides; v = the D floats read from `static` (0 for an index outside [0, nR))
+__device__ __forceinline__ void tap_step_aux(const StepArgs &s, int env, int D, const float *v, long ptr_raw)
+{
+    if (s.dec_static_out)
+        for (int k = 0; k < D; ++k) s.dec_static_out[(size_t)env * D + k] = v[k];
+    if (s.tour_out) s.tour_out[(size_t)env * s.tour_stride + s.tour_col] = (int64_t)ptr_raw;
+    if (s.picked_out) {
+        const bool ok = ptr_raw >= 0 && ptr_raw < s.nR;
+        s.picked_out[(size_t)env * s.tour_stride + s.tour_col] = ok ? s.nodes_cur[(size_t)env * s.child + (int)(ptr_raw % s.child)] : -1;
+    }
+}
 
 int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d);
 // lanes per env: smallest of 8/16/32/64 that holds W*L cells, 0 if unsupported
@@ -143,6 +168,8 @@ inline int tap_group_size(const tap_env_desc *d)
     const int cells = d->W * d->L;
     return cells <= 8 ? 8 : cells <= 16 ? 16 : cells <= 32 ? 32 : cells <= 64 ? 64 : 0;
 }
+// the same by-products from a launch of their own, for the steps that run as two launches (transition.hip)
+int tap_step_aux_launch(tap_ctx *ctx, const StepArgs &s, hipStream_t st);
 int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st);                                      // big.hip
 int tap_big_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, int flen, hipStream_t st);   // big.hip
 

@@ -805,13 +805,15 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     if (ev) {
         if (a.static_) {
             bool badp;
-            const long p = tap_col((long)a.ptr[env], a.nR, badp);
+            const long praw = (long)a.ptr[env];
+            const long p = tap_col(praw, a.nR, badp);
             const float vx = a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
             const float vy = a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
             const float vz = a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
             bx = badp ? 0 : (int)vx;
             by = badp ? 0 : (int)vy;
             bz = badp ? 0 : (int)vz;
+            if (cell == 0) { const float fv[3] = {badp ? 0.f : vx, badp ? 0.f : vy, badp ? 0.f : vz}; tap_step_aux(a, env, 3, fv, praw); }
         } else if (a.blocks_dtype == TAP_DT_F32) {
             const float *b = (const float *)a.blocks + (size_t)env * 3;
             bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];

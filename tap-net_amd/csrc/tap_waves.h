@@ -26,11 +26,15 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
         }
         if (s.static_) { // gather of model.py:404-412
             bool badp;
-            const long p = tap_col((long)s.ptr[env], s.nR, badp);
+            const long praw = (long)s.ptr[env];
+            const long p = tap_col(praw, s.nR, badp);
+            float fv[3];
             for (int k = 0; k < D; ++k) { // unconditional load of a valid column, then the select
                 const float v = s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
                 dims[k] = badp ? 0 : (int)v;
+                fv[k] = badp ? 0.f : v;
             }
+            if (cell == 0) tap_step_aux(s, env, D, fv, praw);
         } else if (s.blocks_dtype == TAP_DT_F32) { // block.astype(int), tools.py:3689
             for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)s.blocks)[(size_t)env * D + k];
         } else {

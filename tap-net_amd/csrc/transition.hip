@@ -17,6 +17,7 @@
 // This file: the LB_GREEDY kernel and the tap_transition* entry points; the MACS / MUL kernels of the same shape live in
 // transition_macs.hip (tap_transition_macs_launch), so that the two halves compile side by side.
 #include <cstdlib>
+#include <new>
 
 #include "tap_common.h"
 #include "tap_macs.h"
@@ -103,23 +104,55 @@ static bool transition_single_kernel(const tap_env_desc *d, int nR)
     return true;
 }
 
+// The by-products a decoding loop wants from the step's gather (tap_common.h: StepArgs::dec_static_out / tour_out):
+// the fused kernels' placement waves write them; for the shapes that run as two launches this kernel does.
+struct StepAux {
+    float *dec_static_out;
+    int64_t *tour_out;
+    int tour_stride, tour_col;
+};
+
+__global__ void __launch_bounds__(TAP_BLOCK) k_step_aux(StepArgs s)
+{
+    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    if (env >= s.d.B) return;
+    bool badp;
+    const long praw = (long)s.ptr[env];
+    const long p = tap_col(praw, s.nR, badp);
+    float fv[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < s.d.D; ++k) {
+        const float v = s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
+        fv[k] = badp ? 0.f : v;
+    }
+    tap_step_aux(s, env, s.d.D, fv, praw);
+}
+
+int tap_step_aux_launch(tap_ctx *ctx, const StepArgs &s, hipStream_t st)
+{
+    if (!(s.dec_static_out || s.tour_out || s.picked_out) || s.d.B == 0) return TAP_OK;
+    hipLaunchKernelGGL(k_step_aux, dim3((s.d.B + TAP_BLOCK - 1) / TAP_BLOCK), dim3(TAP_BLOCK), 0, st, s);
+    TAP_LAUNCH_CHECK(ctx, "k_step_aux");
+    return TAP_OK;
+}
+
 static int transition_tail(tap_ctx *ctx, const tap_env_desc *d, void *state, const TransArgs &a, void *stream)
 {
     int rc = tap_env_step_gather(ctx, d, state, a.s.static_, a.s.static_rows, a.s.nR, a.s.ptr, nullptr, a.s.feature_out, stream);
     if (rc == TAP_OK && (a.flags & TAP_T_RATIO)) rc = tap_env_ratio(ctx, d, state, a.ratio_out, nullptr, nullptr, stream);
-    return rc;
+    return rc ? rc : tap_step_aux_launch(ctx, a.s, (hipStream_t)stream);
 }
 
 static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                              int update_rows, const float *static_, int static_rows, const int64_t *ptr,
                              const float *mask_in, float *current_out, float *mask_out, float *feature_out,
-                             float *ratio_out, int flags, TransArgs &a)
+                             float *ratio_out, int flags, TransArgs &a, const StepAux *aux = nullptr)
 {
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     if (d->strategy == TAP_MACS && (rc = tap_macs_validate(ctx, *d)) != TAP_OK) return rc;
-    if (!state || !static_ || !ptr || !mask_in || !current_out || !mask_out || n < 1 || R < 1 || rows < 1 ||
+    // mask_in null = ones (the mask DRL.forward starts from, model.py:297): only the stepper's first step passes it
+    if (!state || !static_ || !ptr || (!mask_in && !aux) || !current_out || !mask_out || n < 1 || R < 1 || rows < 1 ||
         static_rows < 1 + d->D || update_rows < 0 || update_rows > 3 || ((flags & TAP_T_RATIO) && !ratio_out))
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     a.s.d = *d;
@@ -129,6 +162,12 @@ static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, i
     a.s.lut = ctx ? ctx->stab_lut : nullptr;
     a.flags = flags;
     a.ratio_out = ratio_out;
+    if (aux) {
+        a.s.dec_static_out = aux->dec_static_out;
+        a.s.tour_out = aux->tour_out;
+        a.s.tour_stride = aux->tour_stride;
+        a.s.tour_col = aux->tour_col;
+    }
     return TAP_OK;
 }
 
@@ -158,17 +197,17 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     return transition_dispatch(ctx, d, a, stream);
 }
 
-extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
-                                   int update_rows, const unsigned long long *bits_in, const float *static_,
-                                   int static_rows, const int64_t *ptr, const float *mask_in,
-                                   unsigned long long *bits_out, float *dyn_out, float *current_out,
-                                   float *mask_out, float *feature_out, float *ratio_out, int flags,
-                                   void *stream)
+static int transition_bits_impl(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                int update_rows, const unsigned long long *bits_in, const float *static_,
+                                int static_rows, const int64_t *ptr, const float *mask_in,
+                                unsigned long long *bits_out, float *dyn_out, float *current_out,
+                                float *mask_out, float *feature_out, float *ratio_out, int flags,
+                                void *stream, const StepAux *aux)
 {
     if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     TransArgs a = {};
     int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
-                               current_out, mask_out, feature_out, ratio_out, flags, a);
+                               current_out, mask_out, feature_out, ratio_out, flags, a, aux);
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
@@ -185,16 +224,27 @@ extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *st
     return transition_dispatch(ctx, d, a, stream);
 }
 
-extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
-                                    int update_rows, const float *dyn_in, const float *static_, int static_rows,
-                                    const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
-                                    float *dyn_out, float *current_out, float *mask_out, float *feature_out,
-                                    float *ratio_out, int32_t *nonbinary_out, int flags, void *stream)
+extern "C" int tap_transition_bits(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                   int update_rows, const unsigned long long *bits_in, const float *static_,
+                                   int static_rows, const int64_t *ptr, const float *mask_in,
+                                   unsigned long long *bits_out, float *dyn_out, float *current_out,
+                                   float *mask_out, float *feature_out, float *ratio_out, int flags,
+                                   void *stream)
+{
+    return transition_bits_impl(ctx, d, state, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
+                                dyn_out, current_out, mask_out, feature_out, ratio_out, flags, stream, nullptr);
+}
+
+static int transition_first_impl(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                 int update_rows, const float *dyn_in, const float *static_, int static_rows,
+                                 const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
+                                 float *dyn_out, float *current_out, float *mask_out, float *feature_out,
+                                 float *ratio_out, int32_t *nonbinary_out, int flags, void *stream, const StepAux *aux)
 {
     if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     TransArgs a = {};
     int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
-                               current_out, mask_out, feature_out, ratio_out, flags, a);
+                               current_out, mask_out, feature_out, ratio_out, flags, a, aux);
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
@@ -209,6 +259,16 @@ extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *s
     if (!mask_bits_ok(a.m))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);
+}
+
+extern "C" int tap_transition_first(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                    int update_rows, const float *dyn_in, const float *static_, int static_rows,
+                                    const int64_t *ptr, const float *mask_in, unsigned long long *bits_out,
+                                    float *dyn_out, float *current_out, float *mask_out, float *feature_out,
+                                    float *ratio_out, int32_t *nonbinary_out, int flags, void *stream)
+{
+    return transition_first_impl(ctx, d, state, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,
+                                 dyn_out, current_out, mask_out, feature_out, ratio_out, nonbinary_out, flags, stream, nullptr);
 }
 
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream)
@@ -226,3 +286,123 @@ static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransA
     if (Gs == 32) return launch_transition<3, 32>(ctx, a, (hipStream_t)stream);
     return launch_transition<3, 64>(ctx, a, (hipStream_t)stream);
 }
+
+// ---- tap_stepper: the step object of a decoding loop (tapenv.h) --------------------------------------------------
+// Host-side only: the buffers stay the caller's; the stepper remembers them, alternates the two phases and tells
+// the fused launch which by-products to write.  A step is then one C call with two arguments.
+struct tap_stepper {
+    tap_ctx *ctx;
+    tap_env_desc d;
+    void *state;
+    int n, R, rows, update_rows, static_rows, steps;
+    tap_stepper_buffers b;
+    const float *static_;
+    const float *dyn_in;                // step 0 builds the shadow from this fp32 tensor ...
+    const unsigned long long *bits0;    // ... or reads this one (begin's own launch, or the caller's)
+    const float *mask0;                 // the mask step 0 starts from (null = ones)
+    int k;                              // index of the next step
+    int keep;                           // TAP_SB_CONTINUE: step 0 does not start from a fresh container
+};
+
+struct DeviceGuard { // the launches must be issued with the context's device current (callers may sit on another one)
+    int prev, want;
+    explicit DeviceGuard(int dev) : prev(-1), want(dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != want) (void)hipSetDevice(want);
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
+extern "C" int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                  int update_rows, int static_rows, int steps, const tap_stepper_buffers *buf,
+                                  tap_stepper **out)
+{
+    if (!ctx || !d || !buf || !out) return TAP_E_INVALID;
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (!state || n < 1 || R < 1 || rows < 1 || update_rows < 0 || update_rows > 3 || static_rows < 1 + d->D || steps < 1)
+        return tap_fail(ctx, TAP_E_INVALID, "bad stepper arguments");
+    for (int w = 0; w < 2; ++w)
+        if (!buf->bits[w] || !buf->dyn[w] || !buf->current[w] || !buf->mask[w])
+            return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of bits / dyn / current / mask");
+    if (buf->bits[0] == buf->bits[1] || buf->dyn[0] == buf->dyn[1] || buf->current[0] == buf->current[1] ||
+        buf->mask[0] == buf->mask[1] || !buf->ratio)
+        return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers and ratio is required");
+    const int nR = n * R;
+    if (buf->tour_stride < 0 || buf->tour_col0 < 0 || (buf->tour_stride > 0 && buf->tour_col0 + steps > buf->tour_stride))
+        return tap_fail(ctx, TAP_E_INVALID, "stepper tour columns [col0, col0 + steps) must fit tour_stride");
+    if (nR % 4 != 0 || nR > 256 || rows > 128)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "the stepper carries `dynamic` as its bit shadow: nR %% 4 == 0, nR <= 256, rows <= 128");
+    tap_stepper *s = new (std::nothrow) tap_stepper();
+    if (!s) return tap_fail(ctx, TAP_E_INVALID, "out of host memory");
+    s->ctx = ctx; s->d = *d; s->state = state;
+    s->n = n; s->R = R; s->rows = rows; s->update_rows = update_rows; s->static_rows = static_rows; s->steps = steps;
+    s->b = *buf;
+    s->static_ = nullptr; s->dyn_in = nullptr; s->bits0 = nullptr; s->mask0 = nullptr; s->k = 0; s->keep = 0;
+    *out = s;
+    return TAP_OK;
+}
+
+extern "C" void tap_stepper_destroy(tap_stepper *s) { delete s; }
+
+extern "C" int tap_stepper_begin(tap_stepper *s, const float *static_, const float *dyn_in, int flags, void *stream)
+{
+    if (!s) return TAP_E_INVALID;
+    if (!static_ || !dyn_in) return tap_fail(s->ctx, TAP_E_INVALID, "stepper_begin needs static and dynamic");
+    s->static_ = static_;
+    s->dyn_in = dyn_in;
+    s->bits0 = nullptr;
+    s->mask0 = nullptr;
+    s->k = 0;
+    s->keep = (flags & TAP_SB_CONTINUE) != 0;
+    if (!(flags & TAP_SB_INITIAL_MASK) || s->d.B == 0) return TAP_OK;
+    // shadow + the masks DRL.forward starts from (model.py:297-307) in one launch that reads the tensor once; they
+    // land in phase 1, which step 0 (writing phase 0) reads
+    DeviceGuard g(s->ctx->device);
+    const int rc = tap_mask_step_first(s->ctx, s->d.B, s->n, s->R, s->rows, 0, dyn_in, nullptr, 0, nullptr, nullptr,
+                                       s->b.bits[1], nullptr, s->b.current[1], s->b.mask[1], s->b.nonbinary, stream);
+    if (rc != TAP_OK) { s->static_ = nullptr; return rc; }
+    s->bits0 = s->b.bits[1];
+    s->mask0 = s->b.mask[1];
+    return TAP_OK;
+}
+
+extern "C" int tap_stepper_begin_shadow(tap_stepper *s, const float *static_, const unsigned long long *bits, int flags)
+{
+    if (!s) return TAP_E_INVALID;
+    if (!static_ || !bits || bits == s->b.bits[0])
+        return tap_fail(s->ctx, TAP_E_INVALID, "stepper_begin_shadow needs static and a shadow that is not phase 0's buffer");
+    s->static_ = static_;
+    s->dyn_in = nullptr;
+    s->bits0 = bits;
+    s->mask0 = nullptr;
+    s->k = 0;
+    s->keep = (flags & TAP_SB_CONTINUE) != 0;
+    return TAP_OK;
+}
+
+extern "C" int tap_stepper_step(tap_stepper *s, const int64_t *ptr, void *stream)
+{
+    if (!s) return TAP_E_INVALID;
+    if (!s->static_) return tap_fail(s->ctx, TAP_E_INVALID, "tap_stepper_begin has not been called");
+    if (s->k >= s->steps) return tap_fail(s->ctx, TAP_E_STEPS, "the episode already took its %d steps", s->steps);
+    const int k = s->k, w = k & 1, r = w ^ 1;
+    const int flags = ((k == 0 && !s->keep) ? TAP_T_FRESH : 0) | (k == s->steps - 1 ? TAP_T_RATIO : 0);
+    const StepAux aux = {s->b.decoder_static, s->b.tour, s->b.tour_stride > 0 ? s->b.tour_stride : s->steps, s->b.tour_col0 + k};
+    DeviceGuard g(s->ctx->device);
+    int rc;
+    if (k == 0 && !s->bits0)
+        rc = transition_first_impl(s->ctx, &s->d, s->state, s->n, s->R, s->rows, s->update_rows, s->dyn_in, s->static_,
+                                   s->static_rows, ptr, nullptr, s->b.bits[w], s->b.dyn[w], s->b.current[w], s->b.mask[w],
+                                   s->b.feature, s->b.ratio, s->b.nonbinary, flags, stream, &aux);
+    else
+        rc = transition_bits_impl(s->ctx, &s->d, s->state, s->n, s->R, s->rows, s->update_rows,
+                                  k == 0 ? s->bits0 : s->b.bits[r], s->static_, s->static_rows, ptr,
+                                  k == 0 ? s->mask0 : s->b.mask[r], s->b.bits[w], s->b.dyn[w], s->b.current[w], s->b.mask[w],
+                                  s->b.feature, s->b.ratio, flags, stream, &aux);
+    if (rc == TAP_OK) s->k = k + 1;
+    return rc;
+}
+
+extern "C" int tap_stepper_steps_done(const tap_stepper *s) { return s ? s->k : TAP_E_INVALID; }

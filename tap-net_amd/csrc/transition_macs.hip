@@ -47,11 +47,13 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
             if (cell < 4) cv = a.s.v.cnt[(size_t)env * 4 + cell];
         }
         bool badp;
-        const long p = tap_col((long)a.s.ptr[env], a.s.nR, badp);
+        const long praw = (long)a.s.ptr[env];
+        const long p = tap_col(praw, a.s.nR, badp);
         const float vx = a.s.static_[((size_t)env * a.s.static_rows + 1) * a.s.nR + p];
         const float vz = a.s.static_[((size_t)env * a.s.static_rows + 2) * a.s.nR + p];
         bx = badp ? 0 : (int)vx;
         bz = badp ? 0 : (int)vz;
+        if (cell == 0) { const float fv[2] = {badp ? 0.f : vx, badp ? 0.f : vz}; tap_step_aux(a.s, env, 2, fv, praw); }
     }
     Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
     int err = 0;

@@ -84,6 +84,7 @@ def dynamic_colsum(dynamic, blocks_num):
 _bshadow = {}
 _binary_mode = 'check'
 _deferred = {}          # device index -> int32 counter of non-0/1 elements seen in 'trust' mode
+_steppers = weakref.WeakSet()   # live EpisodeSteppers: each counts the non-0/1 elements of the tensors it was given
 
 
 def set_binary_check(mode):
@@ -104,8 +105,9 @@ def check_binary(device=None):
     """Deferred form of the 0/1 test in 'trust' mode (synchronises): raises ValueError if any tensor handed to
     the seams since the last call held a value other than 0 or 1 -- results computed from it are invalid."""
     bad = 0
-    for idx, cnt in list(_deferred.items()):
-        if device is None or _lib.resolve_device(device).index == idx:
+    want = None if device is None else _lib.resolve_device(device).index
+    for idx, cnt in list(_deferred.items()) + [(sp._idx, sp._nonbinary) for sp in list(_steppers)]:
+        if want is None or want == idx:
             bad += int(cnt.item())
             cnt.zero_()
     if bad:
@@ -454,6 +456,172 @@ class EnvTransition(MaskStepper):
                 _lib.stream_of(out.device)), c)
         self.dynamic, self.colsum, self.current_mask, self.mask = out, cs, cur, new
         return out, cur, new, feat, ratio
+
+
+class NonBinaryDynamic(ValueError):
+    """A ``dynamic`` tensor handed to an EpisodeStepper held values other than 0 and 1 (it carries the tensor as
+    its bit shadow); rollout.run_episode falls back to the general EnvTransition path."""
+
+
+class EpisodeStepper(object):
+    """The step object of a decoding loop (tapenv.h: tap_stepper) -- EnvTransition for callers that pay per step
+    on the host: it OWNS two phases of every per-step output (new ``dynamic``, its bit shadow, both masks), the
+    feature, ``decoder_static`` (the gather of model.py:404-406, written by the step's own launch), the tour and the
+    ratio; an episode is ``begin(static, dynamic)`` + ``steps`` calls of ``step(ptr)``, each ONE C call with two
+    arguments -- no tensor is allocated and no torch op is issued between the policy's calls.
+
+    After ``begin`` / ``step`` the attributes ``dynamic``, ``current_mask``, ``mask``, ``decoder_dynamic``,
+    ``decoder_static`` hold the values model.py's loop variables of the same names would; they are views of the
+    stepper's buffers: a step overwrites the phase written two steps ago, the next ``begin`` everything -- clone
+    what must outlive that.  ``static`` / ``dynamic`` given to ``begin`` are only read (the trainer re-uses them,
+    trainer.py:214) and are kept referenced for the episode.
+
+    Shapes are fixed at construction from the example tensors; needs a window with a bit shadow
+    (``bits_supported``) and 0/1-valued ``dynamic`` tensors: under ``set_binary_check('check')`` ``begin`` reads
+    the launch's counter of other values (one host sync per episode) and raises NonBinaryDynamic, under 'trust'
+    the count stays on the device until ``check_binary()`` (or ``check()``) asks for it."""
+
+    def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True, steps=None, want_tour=True,
+                 tour=None, tour_col0=0):
+        import ctypes as C
+        self.block_dim = _block_dim(static, input_type)
+        self.R = _rotate_types(self.block_dim, allow_rot)
+        self.B, self.rows, self.nR = (int(v) for v in dynamic.shape)
+        self.n = self.nR // self.R
+        self.static_rows = int(static.shape[1])
+        self.update_rows = _UPDATE_ROWS[input_type]
+        self.steps = self.n if steps is None else int(steps)
+        if not bits_supported(self.rows, self.nR):
+            raise ValueError("EpisodeStepper needs a window with a bit shadow (rows <= 128, nR % 4 == 0, nR <= 256)")
+        if env.batch_size != self.B or env.block_dim != self.block_dim:
+            raise ValueError("container batch / dimension does not match the instance tensors")
+        self.env = env
+        dev = self._dev = env.device
+        self._idx = dev.index
+        f32 = dict(dtype=torch.float32, device=dev)
+        D = self.block_dim
+        words = _bit_planes(self.rows) * self.nR
+        self._bits = [torch.empty(self.B, words, dtype=torch.int64, device=dev) for _ in range(2)]
+        self._dyn = [torch.empty(self.B, self.rows, self.nR, **f32) for _ in range(2)]
+        self._cur = [torch.empty(self.B, self.nR, **f32) for _ in range(2)]
+        self._mask = [torch.empty(self.B, self.nR, **f32) for _ in range(2)]
+        # the decoder inputs are zeros before step 0 (pack.py:258-264); one flat buffer so that begin() clears both
+        # with one launch
+        fshape = env._feature_shape()
+        flen = int(np.prod(fshape[1:]))
+        self._dec = torch.zeros(self.B * (flen + D), **f32)
+        self.decoder_dynamic = self._dec[:self.B * flen].view(fshape)
+        self.decoder_static = self._dec[self.B * flen:].view(self.B, D, 1)
+        self.ratio = torch.empty(self.B, **f32)
+        # ``tour``: write the picks into columns tour_col0 .. tour_col0 + steps - 1 of the caller's (B, stride) int64
+        # tensor (a rolling episode's last window continues the roller's tour) instead of an own (B, steps) one
+        self._tour_buf, col0 = tour, int(tour_col0)
+        if tour is not None:
+            if tour.dtype is not torch.int64 or not tour.is_contiguous() or tour.device != dev or tour.dim() != 2 or \
+                    tour.shape[0] != self.B or col0 < 0 or col0 + self.steps > tour.shape[1]:
+                raise ValueError("tour must be a contiguous (B, >= tour_col0 + steps) int64 tensor on %s" % (dev,))
+            self.tour = tour[:, col0:col0 + self.steps]
+        else:
+            self.tour = self._tour_buf = torch.zeros(self.B, self.steps, dtype=torch.int64, device=dev) if want_tour else None
+        cnt = self._nonbinary = torch.zeros(1, dtype=torch.int32, device=dev)   # read by begin() / check_binary()
+        _steppers.add(self)
+        buf = _lib.StepperBuffers()
+        for w in range(2):
+            buf.bits[w], buf.dyn[w] = self._bits[w].data_ptr(), self._dyn[w].data_ptr()
+            buf.current[w], buf.mask[w] = self._cur[w].data_ptr(), self._mask[w].data_ptr()
+        buf.feature, buf.decoder_static = self.decoder_dynamic.data_ptr(), self.decoder_static.data_ptr()
+        buf.ratio = self.ratio.data_ptr()
+        buf.tour = self._tour_buf.data_ptr() if self._tour_buf is not None else None
+        buf.tour_stride = int(self._tour_buf.shape[1]) if self._tour_buf is not None else 0
+        buf.tour_col0 = col0 if tour is not None else 0
+        buf.nonbinary = cnt.data_ptr()
+        self._ctx = _lib.ctx(dev)
+        L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(L.tap_stepper_create(self._ctx, C.byref(env.desc), _lib.ptr(env._state), self.n, self.R, self.rows,
+                                        self.update_rows, self.static_rows, self.steps, C.byref(buf), C.byref(h)), self._ctx)
+        self._h = h
+        self._destroy = L.tap_stepper_destroy
+        self._step_fn, self._begin_fn, self._begin_shadow_fn = L.tap_stepper_step, L.tap_stepper_begin, L.tap_stepper_begin_shadow
+        self._views = [(self._dyn[w], self._cur[w], self._mask[w]) for w in range(2)]
+        self._ones = None
+        self.static = self.dynamic = self.current_mask = self.mask = None
+        self.k = 0
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self._destroy(h)
+
+    def _check_instances(self, static, what, shape):
+        if (static.dtype is not torch.float32 or not static.is_contiguous() or static.device != self._dev or
+                tuple(static.shape) != shape):
+            raise ValueError("%s must be a contiguous float32 tensor of shape %s on %s" % (what, shape, self._dev))
+
+    def begin(self, static, dynamic, initial_mask=True, keep_container=False, current_mask=None):
+        """Bind the next instance batch.  ``initial_mask``: one launch builds the shadow and the masks of
+        model.py:297-307 (``current_mask`` is then what the policy sees before step 0); False: no launch, step 0
+        reads ``dynamic`` itself and ``current_mask`` / ``mask`` are None until then (a replayed tour needs neither).
+        ``keep_container``: step 0 goes on with the containers as they are."""
+        self._check_instances(static, "static", (self.B, self.static_rows, self.nR))
+        self._check_instances(dynamic, "dynamic", (self.B, self.rows, self.nR))
+        flags = (_lib.TAP_SB_INITIAL_MASK if initial_mask else 0) | (_lib.TAP_SB_CONTINUE if keep_container else 0)
+        rc = self._begin_fn(self._h, static.data_ptr(), dynamic.data_ptr(), flags, _lib.raw_stream(self._idx))
+        if rc:
+            _lib.check(rc, self._ctx)
+        self.static, self.dynamic, self.k = static, dynamic, 0
+        self._dec.zero_()
+        if initial_mask:
+            self.current_mask, self.mask = self._cur[1], self._mask[1]
+            if _binary_mode == 'check':
+                self._raise_nonbinary()
+        else:
+            self.current_mask, self.mask = current_mask, None     # the caller's, if it has one (rolling windows)
+        return self
+
+    def begin_shadow(self, static, dynamic, bits, current_mask=None, keep_container=False):
+        """The same for a window whose bit shadow the caller holds (rolling windows emit it next to the tensor):
+        no launch; ``dynamic`` / ``current_mask`` are only recorded as the values before step 0."""
+        self._check_instances(static, "static", (self.B, self.static_rows, self.nR))
+        if bits.dtype is not torch.int64 or not bits.is_contiguous() or bits.device != self._dev or \
+                bits.numel() != self._bits[0].numel():
+            raise ValueError("bits must be the (B, %d) int64 shadow of the window" % (self._bits[0].shape[1],))
+        rc = self._begin_shadow_fn(self._h, static.data_ptr(), bits.data_ptr(), _lib.TAP_SB_CONTINUE if keep_container else 0)
+        if rc:
+            _lib.check(rc, self._ctx)
+        if self._ones is None:
+            self._ones = torch.ones(self.B, self.nR, dtype=torch.float32, device=self._dev)
+        self.static, self.dynamic, self.k, self._bits0 = static, dynamic, 0, bits
+        self.current_mask, self.mask = current_mask, self._ones
+        return self
+
+    def step(self, ptr):
+        """One decoding step (model.py:376-465): ptr (B,) int64 on the device -> the phase (0 | 1) the step wrote.
+        Afterwards ``dynamic``, ``current_mask``, ``mask``, ``decoder_dynamic``, ``decoder_static`` are the loop
+        variables of model.py after that step; ``ratio`` is valid after the last step, ``tour[:, k]`` = ptr."""
+        if ptr.dtype is not torch.int64 or not ptr.is_contiguous() or ptr.device != self._dev or ptr.numel() != self.B:
+            ptr = ptr.to(device=self._dev, dtype=torch.int64).contiguous()
+            if ptr.numel() != self.B:
+                raise ValueError("ptr must be (%d,), got %s" % (self.B, tuple(ptr.shape)))
+        rc = self._step_fn(self._h, ptr.data_ptr(), _lib.raw_stream(self._idx))
+        if rc:
+            _lib.check(rc, self._ctx)
+        w = self.k & 1
+        self.k += 1
+        self.dynamic, self.current_mask, self.mask = self._views[w]
+        return w
+
+    def _raise_nonbinary(self):
+        bad = int(self._nonbinary.item())
+        if bad:
+            self._nonbinary.zero_()
+            raise NonBinaryDynamic("%d element(s) of `dynamic` are neither 0 nor 1: no bit shadow" % bad)
+
+    def check(self):
+        """Synchronises: container errors (TapOverflowError like the reference's IndexError) and the count of
+        non-0/1 elements seen since the last check (NonBinaryDynamic)."""
+        self.env.check()
+        self._raise_nonbinary()
 
 
 def _reward_mul(static, tour_indices, reward_type, input_type, allow_rot, container_width, container_height):

@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from .env import BatchedContainer
-from .pack import EnvTransition
+from .pack import EnvTransition, EpisodeStepper, bits_supported
 
 
 class RollingWindows(object):
@@ -110,6 +110,112 @@ class RollingWindows(object):
             raise _lib.TapError(_lib.TAP_E_INVALID, "a precedence window could not be filled")
 
 
+class RollingStepper(object):
+    """The step object of rolling.validate's loop (tapenv.h: tap_roller) -- ``RollingWindows.step`` for callers that
+    pay per step on the host: it OWNS the window buffers (two phases of ``static`` and the node list, one of
+    everything else), the feature, ``decoder_static``, the tour and the list of picked global block ids; a step is
+    ONE C call with two arguments, whose launch also writes decoder_static, the tour column and the picked id.
+
+    ``begin(windows)`` emits the first window of a freshly initialised ``RollingWindows`` (of the shape given at
+    construction); after it and after every ``step(ptr)`` the attributes ``static``, ``dynamic``, ``nodes``,
+    ``bits`` / ``colsum``, ``current_mask``, ``decoder_dynamic``, ``decoder_static`` describe the CURRENT window --
+    views of the stepper's buffers, overwritten by later steps."""
+
+    def __init__(self, windows, env, want_masks=True):
+        rw = self.windows = windows
+        self.env = env
+        dev = self._dev = rw.device
+        self._idx = dev.index
+        B, N, D, child, R = rw.B, rw.N, rw.D, rw.child, rw.R
+        if env.batch_size != B or env.block_dim != D:
+            raise ValueError("container batch / dimension does not match the instances")
+        self.B, self.N, self.D, self.child, self.R = B, N, D, child, R
+        nRc = child * R
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._static = [torch.empty(B, 1 + D, nRc, **f32) for _ in range(2)]
+        self._nodes = [torch.empty(B, child, dtype=torch.int32, device=dev) for _ in range(2)]
+        self.dynamic = torch.empty(B, 3 * child, nRc, **f32)
+        self.bits = rw._new_bits(nRc) if want_masks else None
+        self.colsum = torch.empty(B, 3, nRc, **f32) if want_masks and self.bits is None else None
+        self.current_mask = torch.empty(B, nRc, **f32) if want_masks else None
+        self._err = torch.zeros(B, dtype=torch.int32, device=dev)
+        self._ones = torch.ones(B, nRc, **f32)            # the `mask` of a one-step window (rolling.py:353: a fresh forward)
+        fshape = env._feature_shape()
+        flen = 1
+        for v in fshape[1:]:
+            flen *= int(v)
+        self._dec = torch.zeros(B * (flen + D), **f32)
+        self.decoder_dynamic = self._dec[:B * flen].view(fshape)
+        self.decoder_static = self._dec[B * flen:].view(B, D, 1)
+        self.tour = torch.zeros(B, N, dtype=torch.int64, device=dev)
+        self.picked = torch.zeros(B, N, dtype=torch.int32, device=dev)
+        buf = _lib.RollerBuffers()
+        for w in range(2):
+            buf.static_[w], buf.nodes[w] = self._static[w].data_ptr(), self._nodes[w].data_ptr()
+        buf.dynamic = self.dynamic.data_ptr()
+        buf.bits = self.bits.data_ptr() if self.bits is not None else None
+        buf.colsum = self.colsum.data_ptr() if self.colsum is not None else None
+        buf.current_mask = self.current_mask.data_ptr() if self.current_mask is not None else None
+        buf.err, buf.feature = self._err.data_ptr(), self.decoder_dynamic.data_ptr()
+        buf.decoder_static, buf.tour, buf.picked = self.decoder_static.data_ptr(), self.tour.data_ptr(), self.picked.data_ptr()
+        buf.tour_stride = N
+        self._ctx = _lib.ctx(dev)
+        L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(L.tap_roller_create(self._ctx, C.byref(env.desc), _lib.ptr(env._state), N, child, C.byref(buf), C.byref(h)),
+                   self._ctx)
+        self._h, self._destroy, self._step_fn, self._begin_fn = h, L.tap_roller_destroy, L.tap_roller_step, L.tap_roller_begin
+        self.static = self.nodes = None
+        self.k = -1
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self._destroy(h)
+
+    def begin(self, windows=None):
+        """First window of ``windows`` (default: the RollingWindows given at construction; any freshly initialised
+        one of the same shape) -- its ``state`` is consumed by the episode."""
+        rw = self.windows if windows is None else windows
+        if (rw.B, rw.N, rw.D, rw.child) != (self.B, self.N, self.D, self.child) or rw.device != self._dev:
+            raise ValueError("windows of another shape / device than this stepper was built for")
+        if rw.steps_done != 0:
+            raise ValueError("the windows have been rolled already: build (or re-initialise) a RollingWindows per episode")
+        self.windows = rw
+        rc = self._begin_fn(self._h, rw.blocks.data_ptr(), rw.rel.data_ptr(), rw.state.data_ptr(), _lib.raw_stream(self._idx))
+        if rc:
+            _lib.check(rc, self._ctx)
+        rw.steps_done = 1
+        rw._err = self._err
+        self._dec.zero_()
+        self.k = 0
+        self.static, self.nodes = self._static[0], self._nodes[0]
+        return self
+
+    def step(self, ptr):
+        """Place the block picked in the current window (column ``ptr`` (B,) int64 of ``static``) into the containers
+        and emit the next window (tap_rolling_step): one launch for the single-kernel shapes."""
+        if ptr.dtype is not torch.int64 or not ptr.is_contiguous() or ptr.device != self._dev or ptr.numel() != self.B:
+            ptr = ptr.to(device=self._dev, dtype=torch.int64).contiguous()
+            if ptr.numel() != self.B:
+                raise ValueError("ptr must be (%d,), got %s" % (self.B, tuple(ptr.shape)))
+        rc = self._step_fn(self._h, ptr.data_ptr(), _lib.raw_stream(self._idx))
+        if rc:
+            _lib.check(rc, self._ctx)
+        self.k += 1
+        self.windows.steps_done += 1
+        w = self.k & 1
+        self.static, self.nodes = self._static[w], self._nodes[w]
+        return w
+
+    def is_last_graph(self):
+        return self.k >= self.N - self.child
+
+    def check(self):
+        if int(self._err.sum().item()):
+            raise _lib.TapError(_lib.TAP_E_INVALID, "a precedence window could not be filled")
+
+
 class RollingDataset(object):
     """rolling.RollingDataset (rolling.py:462-536): the reference's data files of ``total_blocks_num``-block
     instances -> the initial containers ``rolling.validate`` rolls over, here ONE batched ``RollingWindows``
@@ -167,16 +273,79 @@ class RollingDataset(object):
 
 def run_rolling_episode(blocks, positions, initial_container_size, policy, container_width, container_height,
                         child_graph_size=10, reward_type='C+P+S-lb-soft', heightmap_type='diff',
-                        packing_strategy='LB_GREEDY', record=False, fused=True):
+                        packing_strategy='LB_GREEDY', record=False, fused=True, steppers=None):
     """rolling.validate's loop for a batch (rolling.py:589-637 around DRL.forward(one_step),
     rolling.py:294-460): N - child windows of ONE decoding step each, then a full episode on the
     last window; one long-lived target container per instance.
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
     -> ptr (B,) int64 as in rollout.run_episode.  Returns dict(tour (B, N) of window-local picks,
-    nodes (B, N) global block ids in packing order, reward, env)."""
-    from . import pack as tpack
+    nodes (B, N) global block ids in packing order, reward, env).
+
+    ``fused`` runs on a RollingStepper + pack.EpisodeStepper pair: per decoding step the policy's call and one C
+    call (decoder_static, the tour and the picked ids are written by the step's own launch).  ``steppers``: the
+    pair returned by an earlier call (``out['steppers']``) to re-use across episodes -- nothing but the relation
+    masks is then allocated per episode, and the returned tensors are views of the pair's buffers."""
     rw = RollingWindows(blocks, positions, initial_container_size, child_graph_size)
+    if fused and bits_supported(3 * rw.child, rw.child * rw.R):
+        return _run_rolling_steppers(rw, policy, container_width, container_height, reward_type, heightmap_type,
+                                     packing_strategy, record, steppers)
+    return _run_rolling_eager(rw, policy, container_width, container_height, reward_type, heightmap_type,
+                              packing_strategy, record, fused)
+
+
+def _run_rolling_steppers(rw, policy, container_width, container_height, reward_type, heightmap_type, packing_strategy,
+                          record, steppers):
+    B, N, D, child = rw.B, rw.N, rw.D, rw.child
+    dev = rw.device
+    if steppers is None:
+        cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
+        env = BatchedContainer(B, cs, N, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
+        roll = RollingStepper(rw, env)
+        last = EpisodeStepper(roll._static[0], roll.dynamic, env, steps=child, tour=roll.tour, tour_col0=N - child)
+    else:
+        roll, last = steppers
+        env = roll.env
+    env.reset()
+    roll.begin(rw)
+    feats = []
+    step = 0
+    for _ in range(N - child):                                   # one_step windows (rolling.py:353-354)
+        ptr = policy(step=step, static=roll.static, dynamic=roll.dynamic, current_mask=roll.current_mask,
+                     mask=roll._ones, decoder_static=roll.decoder_static, decoder_dynamic=roll.decoder_dynamic)
+        roll.step(ptr)                                           # placement + next window: one launch
+        if record:
+            feats.append(roll.decoder_dynamic.clone())
+        step += 1
+    assert roll.is_last_graph()                                  # the current window is the last graph: a whole episode on it
+    nodes_last = roll.nodes
+    if roll.bits is not None:
+        last.begin_shadow(roll.static, roll.dynamic, roll.bits, current_mask=roll.current_mask, keep_container=True)
+    else:                                                        # two-word shadow: step 0 builds it from the tensor
+        last.begin(roll.static, roll.dynamic, initial_mask=False, keep_container=True, current_mask=roll.current_mask)
+        last.mask = roll._ones
+    last._dec.copy_(roll._dec)                                   # the decoder inputs go on from the last rolling step
+    static_last = roll.static
+    for t in range(child):
+        ptr = policy(step=step, static=static_last, dynamic=last.dynamic, current_mask=last.current_mask,
+                     mask=last.mask, decoder_static=last.decoder_static, decoder_dynamic=last.decoder_dynamic)
+        last.step(ptr)
+        if record:
+            feats.append(last.decoder_dynamic.clone())
+        step += 1
+    tour = roll.tour
+    roll.picked[:, N - child:] = torch.gather(nodes_last, 1, (tour[:, N - child:] % child))   # sub_graph_nodes[ptr]
+    out = dict(tour_idx=tour, nodes=roll.picked, reward=-last.ratio, env=env, windows=rw, steppers=(roll, last))
+    if record:
+        out['features'] = feats
+    return out
+
+
+def _run_rolling_eager(rw, policy, container_width, container_height, reward_type, heightmap_type, packing_strategy,
+                       record, fused):
+    """The same loop on fresh tensors per step (RollingWindows.step / next, pack.EnvTransition): every window shape,
+    also the ones without a bit shadow."""
+    from . import pack as tpack
     B, N, D, child = rw.B, rw.N, rw.D, rw.child
     dev = rw.device
     cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]

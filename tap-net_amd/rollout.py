@@ -11,21 +11,42 @@ import torch
 
 from . import _lib
 from .env import BatchedContainer
-from .pack import EnvTransition, MaskStepper
+from .pack import EnvTransition, EpisodeStepper, MaskStepper, NonBinaryDynamic, bits_supported
 
 
 class TapePolicy(object):
-    """Replays a recorded tour (B, steps) -- e.g. the reference actor's greedy choices."""
+    """Replays a recorded tour (B, steps) -- e.g. the reference actor's greedy choices.  The tour is kept
+    step-major, so a step's picks are a contiguous (B,) view: no copy kernel between the steps."""
 
     def __init__(self, tour):
         self.tour = tour
+        self._steps = tour.to(torch.int64).t().contiguous()
 
     def __call__(self, step, **_):
-        return self.tour[:, step]
+        return self._steps[step]
 
 
 class RandomFeasiblePolicy(object):
-    """Uniformly random selectable column of ``current_mask`` (torch.multinomial on device)."""
+    """Uniformly random selectable column of ``current_mask``: an exponential race -- the column with the smallest
+    Exp(1) draw among the selectable ones, argmax(mask / q) -- which is what torch.multinomial(mask, 1) computes
+    after its input checks (three torch ops on buffers the policy keeps, instead of ~85 us of host per
+    torch.multinomial call on this stack)."""
+
+    def __init__(self, generator=None):
+        self.generator = generator
+        self._q = self._r = None
+
+    def __call__(self, step, current_mask, **_):
+        if self._q is None or self._q.shape != current_mask.shape or self._q.device != current_mask.device:
+            self._q = torch.empty_like(current_mask)
+            self._r = torch.empty_like(current_mask)
+        self._q.exponential_(generator=self.generator)
+        torch.div(current_mask, self._q, out=self._r)
+        return torch.argmax(self._r, dim=1)
+
+
+class MultinomialPolicy(object):
+    """The same distribution through torch.multinomial on ``current_mask`` (round 3's stand-in policy)."""
 
     def __init__(self, generator=None):
         self.generator = generator
@@ -50,18 +71,38 @@ class UniformPickPolicy(object):
         return (current_mask.cumsum(1) > k.unsqueeze(1)).to(torch.float32).argmax(1)
 
 
+class UniformKeysPolicy(object):
+    """Uniformly random selectable column from PRE-DRAWN iid keys ``v`` (steps, B, nR) in [0, 1): the selectable
+    column with the largest key -- the argmax of iid keys over a set is uniform over the set.  Two torch ops per step
+    (a multiply and an argmax), deterministic given ``v``, so an episode with it can be captured in a HIP graph and
+    replayed on refreshed keys.  (A key of exactly 0 on the only selectable column would tie with the masked ones;
+    torch.rand draws from [0, 1), so add a tiny offset when that matters.)"""
+
+    def __init__(self, v):
+        self.v = v
+
+    def __call__(self, step, current_mask, **_):
+        return torch.argmax(current_mask * self.v[step], dim=1)
+
+
 def run_episode(static, dynamic, policy, container_width, container_height,
                 reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
                 input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True, bits=None,
-                container_length=None):
+                container_length=None, stepper=None):
     """One episode for a batch (model.py:254-515 minus the network).
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
-    returns ptr (B,) int64.  With ``fused`` (LB_GREEDY) every step is ONE launch (tap_transition),
-    the first one starting from a fresh container and the last one emitting calc_ratio; otherwise
-    a step is two launches (tap_mask_step, tap_env_step_gather).  Returns a dict: tour_idx (B, steps), reward = -scores (B,) fp32
-    (model.py:515), env, and with ``record`` the per-step features / masks.  ``bits``: carry
-    ``dynamic`` as its bit shadow between the steps (pack.MaskStepper), None = when possible.
+    returns ptr (B,) int64.  With ``fused`` every step is ONE launch (tap_transition*; the two launches behind the
+    same entry for the shapes without a single kernel), the first one starting from a fresh container and the last
+    one emitting calc_ratio; otherwise a step is two launches (tap_mask_step, tap_env_step_gather).  Returns a dict:
+    tour_idx (B, steps), reward = -scores (B,) fp32 (model.py:515), env, and with ``record`` the per-step features /
+    masks.  ``bits``: carry ``dynamic`` as its bit shadow between the steps, None = when possible.
+
+    The fused loop runs on a ``pack.EpisodeStepper`` whenever the window has a bit shadow: between two calls of the
+    policy the host makes ONE C call and issues no torch op (the step's launch also writes ``decoder_static`` and
+    the tour column).  ``stepper``: a stepper to re-use across episodes (a trainer builds one per run: nothing is
+    allocated per episode; the returned tensors are then views of its buffers, valid until its next ``begin``);
+    None builds one for this call.
     """
     if input_type in ('mul', 'mul-with'):
         return _run_episode_mul(static, dynamic, policy, container_width, container_height, reward_type,
@@ -69,10 +110,22 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     block_dim = int(static.shape[1]) - 1
     n = int(dynamic.shape[-1]) // (math.factorial(block_dim) if allow_rot else 1)
     B, D = int(static.shape[0]), block_dim
+    nsteps = n if steps is None else steps
+    dev = _lib.resolve_device(static.device)
+    if stepper is not None or (fused and bits is not False and not isinstance(bits, torch.Tensor) and
+                               bits_supported(int(dynamic.shape[1]), int(dynamic.shape[2]))):
+        try:
+            return _run_episode_stepper(static, dynamic, policy, container_width, container_height, reward_type,
+                                        heightmap_type, packing_strategy, input_type, allow_rot, env, record, nsteps,
+                                        container_length, stepper, dev, n, D)
+        except NonBinaryDynamic:
+            if bits is True or stepper is not None:
+                raise ValueError("dynamic cannot be carried as a bit shadow (it holds values other than 0 and 1)")
+            if env is not None:
+                env.reset()
     # model.py:279 builds square 3D containers (L = W); container_length lifts that for callers that want it
     cs = [container_width, container_height] if D == 2 else \
         [container_width, container_length or container_width, container_height]
-    dev = _lib.resolve_device(static.device)
     if env is None:
         env = BatchedContainer(B, cs, n, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
     if fused:
@@ -83,7 +136,6 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     static_part = masks.static[:, 1:, :]
     decoder_static = torch.zeros(B, D, 1, device=dev)
     decoder_dynamic = torch.zeros(env._feature_shape(), device=dev)
-    nsteps = n if steps is None else steps
     tour, feats, curs, msks = [], [], [], []
     ratio = None
     for step in range(nsteps):
@@ -105,6 +157,41 @@ def run_episode(static, dynamic, policy, container_width, container_height,
         ratio = env.calc_ratios()                                 # model.py:499-510
     out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -ratio, 'env': env,
            'dynamic': masks.dynamic, 'mask': masks.mask}
+    if record:
+        out.update(features=feats, current_masks=curs, masks=msks)
+    return out
+
+
+def _as_instances(t, dev):
+    if t.dtype is not torch.float32 or not t.is_contiguous() or t.device != dev:
+        t = t.to(device=dev, dtype=torch.float32).contiguous()
+    return t
+
+
+def _run_episode_stepper(static, dynamic, policy, container_width, container_height, reward_type, heightmap_type,
+                         packing_strategy, input_type, allow_rot, env, record, nsteps, container_length, stepper, dev, n, D):
+    """run_episode's loop on a pack.EpisodeStepper: per decoding step the policy's call and one C call."""
+    static, dynamic = _as_instances(static, dev), _as_instances(dynamic, dev)
+    if stepper is None:
+        if env is None:
+            cs = [container_width, container_height] if D == 2 else \
+                [container_width, container_length or container_width, container_height]   # model.py:279: L = W
+            env = BatchedContainer(int(static.shape[0]), cs, n, reward_type, heightmap_type,
+                                   packing_strategy=packing_strategy, device=dev)
+        stepper = EpisodeStepper(static, dynamic, env, input_type, allow_rot, steps=nsteps)
+    elif stepper.steps != nsteps:
+        raise ValueError("the stepper was built for %d steps per episode, not %d" % (stepper.steps, nsteps))
+    sp = stepper
+    sp.begin(static, dynamic)
+    feats, curs, msks = [], [], []
+    for step in range(nsteps):
+        ptr = policy(step=step, static=static, dynamic=sp.dynamic, current_mask=sp.current_mask, mask=sp.mask,
+                     decoder_static=sp.decoder_static, decoder_dynamic=sp.decoder_dynamic)
+        sp.step(ptr)                                              # model.py:376-465, one launch
+        if record:
+            feats.append(sp.decoder_dynamic.clone()); curs.append(sp.current_mask.clone()); msks.append(sp.mask.clone())
+    out = {'tour_idx': sp.tour, 'reward': -sp.ratio, 'env': sp.env, 'dynamic': sp.dynamic, 'mask': sp.mask,
+           'stepper': sp}
     if record:
         out.update(features=feats, current_masks=curs, masks=msks)
     return out
