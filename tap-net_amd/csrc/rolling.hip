@@ -1392,8 +1392,8 @@ extern "C" int tap_roller_create(tap_ctx *ctx, const tap_env_desc *d, void *env_
     if (rc) return rc;
     rc = roll_check(ctx, d->B, d->D, N, child);
     if (rc) return rc;
-    if (!env_state || !buf->static_[0] || !buf->static_[1] || buf->static_[0] == buf->static_[1] || !buf->dynamic ||
-        !buf->nodes[0] || !buf->nodes[1] || buf->nodes[0] == buf->nodes[1])
+    if (d->B > 0 && (!env_state || !buf->static_[0] || !buf->static_[1] || buf->static_[0] == buf->static_[1] || !buf->dynamic ||
+                     !buf->nodes[0] || !buf->nodes[1] || buf->nodes[0] == buf->nodes[1]))
         return tap_fail(ctx, TAP_E_INVALID, "roller needs both phases of static / nodes (distinct) and dynamic");
     if ((buf->tour || buf->picked) && buf->tour_stride < N - child)
         return tap_fail(ctx, TAP_E_INVALID, "roller tour_stride must hold the N - child single-step windows");
@@ -1410,9 +1410,9 @@ extern "C" void tap_roller_destroy(tap_roller *r) { delete r; }
 extern "C" int tap_roller_begin(tap_roller *r, const int32_t *blocks, const uint64_t *rel, uint64_t *state, void *stream)
 {
     if (!r) return TAP_E_INVALID;
+    if (r->d.B == 0) { r->k = 0; return TAP_OK; }
     if (!blocks || !rel || !state) return tap_fail(r->ctx, TAP_E_INVALID, "roller_begin needs blocks, rel and state");
     r->blocks = blocks; r->rel = rel; r->state = state; r->k = -1;
-    if (r->d.B == 0) { r->k = 0; return TAP_OK; }
     RollDeviceGuard g(r->ctx->device);
     if (r->b.err) {
         hipLaunchKernelGGL(k_roll_zero_i32, dim3((r->d.B + TAP_BLOCK - 1) / TAP_BLOCK), dim3(TAP_BLOCK), 0, (hipStream_t)stream,
@@ -1431,6 +1431,7 @@ extern "C" int tap_roller_step(tap_roller *r, const int64_t *ptr, void *stream)
     if (!r) return TAP_E_INVALID;
     if (r->k < 0) return tap_fail(r->ctx, TAP_E_INVALID, "tap_roller_begin has not been called");
     if (r->k >= r->N - r->child) return tap_fail(r->ctx, TAP_E_STEPS, "all %d single-step windows are done", r->N - r->child);
+    if (r->d.B == 0) { r->k += 1; return TAP_OK; }
     if (!ptr) return tap_fail(r->ctx, TAP_E_INVALID, "null ptr");
     const int k = r->k, cur = k & 1, nxt = cur ^ 1;
     const RollAux aux = {r->b.decoder_static, r->b.tour, r->b.picked, r->b.nodes[cur], r->b.tour_stride, k};

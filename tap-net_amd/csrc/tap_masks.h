@@ -39,6 +39,21 @@ inline MaskArgs mask_finish(MaskArgs a)
 
 __host__ __device__ __forceinline__ bool mask_builds_bits(const MaskArgs &a) { return !a.bits_in && a.bits_out && a.dyn_in; }
 
+// -DTAP_PROF (scripts/decompose_step.py): a timeline of the fused step.  Every wave of the first TAP_PROF_WGS workgroups
+// records the constant-rate 100 MHz clock (s_memrealtime: comparable across CUs) at four points -- stream waves: entry,
+// first store (all inputs have arrived), last store issued, stores acknowledged; placement waves: entry, state + block
+// loaded, placement decided, results stored.  The product build has none of this.
+#ifdef TAP_PROF
+constexpr int TAP_PROF_WGS = 2048, TAP_PROF_WAVES = 8;
+static __device__ unsigned long long tap_prof_tl[TAP_PROF_WGS * TAP_PROF_WAVES * 4];
+#define TL_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < TAP_PROF_WGS) \
+        tap_prof_tl[(blockIdx.x * TAP_PROF_WAVES + (threadIdx.x >> 6)) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define TL_WAIT_VM() __builtin_amdgcn_s_waitcnt(0)     /* every outstanding load / store of the wave has completed */
+#else
+#define TL_STAMP(i) do { } while (0)
+#define TL_WAIT_VM() do { } while (0)
+#endif
+
 // LDS hand-off between lanes of ONE wavefront (same as tap_wave_lds_sync in tap_place.h)
 __device__ __forceinline__ void tap_wave_lds_sync_m()
 {
@@ -47,13 +62,34 @@ __device__ __forceinline__ void tap_wave_lds_sync_m()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 16-byte store of a tensor this kernel will not touch again (nontemporal: measured +9 % on the
-// write-bound bit-shadow step at B = 8192)
+// 16-byte store of a tensor this kernel will not touch again: WRITE-THROUGH (`sc0 sc1`).  A plain or nontemporal
+// store leaves the line dirty in the XCD's L2, and what is still dirty when the kernel ends is written back at the
+// kernel boundary, after the last wave -- at c2 most of the 19.7 MB a step writes (the eight L2s hold 32 MB).  A
+// write-through store sends the bytes on while the kernel is still running and drops the line.  Measured in round 4
+// (scripts/ab_transition.sh, B = 8192 / 4096, per launch inside the replayed graph): c2 7.10-7.31 us nontemporal ->
+// 6.70 `sc0 sc1` (6.87 `sc1`, 8.03-8.12 plain, 8.69-8.86 `sc1 nt`), c3 8.80-8.84 -> 8.33-8.36; whole passes c2 1 139 ->
+// 1 221 M env-steps/s, c3 458 -> 485 M, c4 441 -> 480 M, c6 125.5 -> 130.7 M.  Writing the step's SMALL outputs (masks,
+// shadow words) through as well lost 4-8 % at c2 (4-byte `sc1` stores are one fabric write each).  (Round 1 had measured
+// nontemporal against plain only: +9 %.)  -DTAP_STORE_MODE=k builds the other forms:
+// 0 nt, 1 sc1, 2 sc0 sc1 (product), 3 sc1 nt, 4 plain
+#ifndef TAP_STORE_MODE
+#define TAP_STORE_MODE 2
+#endif
 __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f nv = {v.x, v.y, v.z, v.w};
+#if TAP_STORE_MODE == 0
     __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
+#elif TAP_STORE_MODE == 1
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(nv) : "memory");
+#elif TAP_STORE_MODE == 2
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(nv) : "memory");
+#elif TAP_STORE_MODE == 3
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(nv) : "memory");
+#else
+    *reinterpret_cast<v4f *>(dst) = nv;
+#endif
 }
 
 // bit r of a 64-bit column word as 0.f / 1.f without a 64-bit variable shift (quarter rate on CDNA)
@@ -386,6 +422,9 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
         }
         if (lane_on) {
             const u64 n0 = w[k][0].x & ~clr, n1 = w[k][0].y & ~clr, n2 = w[k][1].x & ~clr, n3 = w[k][1].y & ~clr;
+#ifdef TAP_PROF
+            if (k == 0) { TL_WAIT_VM(); TL_STAMP(1); }
+#endif
             if (a.dyn_out) {
                 float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
                 if (rows <= 32) {

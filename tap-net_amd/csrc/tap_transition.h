@@ -7,6 +7,9 @@
 #include "tap_masks.h"
 #include "tap_place.h"
 
+// -DTAP_PROF / -DTAP_PROF_SWITCH builds only: flag bits (beside TAP_T_*) that switch one kind of wave off (scripts/decompose_step.py)
+constexpr int TAP_T_PROF_NOSTREAM = 1 << 8, TAP_T_PROF_NOPLACE = 1 << 9;
+
 struct TransArgs {
     StepArgs s;   // placement (always the gather form: s.static_, s.ptr)
     MaskArgs m;   // precedence update
@@ -23,10 +26,14 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
     bool on[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
+    TL_STAMP(0);
     if (NC > 0) {
         if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false>(m, senv0, lane, on, lds);
         else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true>(m, senv0, lane, on, lds);
         else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
+        TL_STAMP(2);
+        TL_WAIT_VM();
+        TL_STAMP(3);
         return;
     }
     const size_t slab = (size_t)m.rows * m.nR;

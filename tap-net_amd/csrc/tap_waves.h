@@ -7,6 +7,7 @@
 
 #include "tap_common.h"
 #include "tap_place.h"
+#include "tap_masks.h"
 
 // env: this group's container; cell / lane: lane index inside the group / the wave;
 // g_old, g_new: the group's two G-int LDS slices.  Every lane of the wave must call this.
@@ -51,12 +52,16 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
     if (act && cnt.count >= s.d.n_max) { err |= 2; do_step = false; }  // tools.py:3677 IndexError
     if (act && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
     g_old[cell] = hm;
+#ifdef TAP_PROF
+    TL_WAIT_VM(); TL_STAMP(1);
+#endif
     tap_wave_lds_sync();
     const PlaceCfg cfg = {W, L, s.d.H, s.d.flags, s.lut};
     const int step = cnt.count;
     const Placement pl = tap_place<D, G, HARDOK>(cfg, g_old, cell, hm, cnt, err, bx, by, bz, do_step);
     err = group_or<G>(err);
     g_new[cell] = hm;
+    TL_STAMP(2);
     tap_wave_lds_sync();
     const int gmax = (flags & TAP_T_RATIO) ? group_max<G>(incell ? hm : 0) : 0;
     if (ev) {

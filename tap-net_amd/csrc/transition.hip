@@ -38,6 +38,10 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
 
+#if defined(TAP_PROF) || defined(TAP_PROF_SWITCH)
+    // decomposition switches (scripts/decompose_step.py): run only one kind of wave, or none ("empty kernel of the geometry")
+    if (wave >= ENV_WAVES ? (a.flags & TAP_T_PROF_NOSTREAM) : (a.flags & TAP_T_PROF_NOPLACE)) return;
+#endif
     if (wave >= ENV_WAVES) {
         trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
@@ -47,9 +51,24 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(Tran
     // ---- placement waves (tools.py:3663-3744): their latency chain runs beside the stream --------
     __builtin_amdgcn_s_setprio(2);
     const int cell = tid % G;
+    TL_STAMP(0);
     tap_lb_place_wave<D, G>(a.s, a.flags, a.ratio_out, env_base + tid / G, cell, lane,
                             s_old + (tid - cell), s_new + (tid - cell));
+    TL_WAIT_VM();
+    TL_STAMP(3);
 }
+
+#ifdef TAP_PROF
+extern "C" int tap_prof_read_timeline(unsigned long long *out, int clear)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(tap_prof_tl), sizeof(unsigned long long) * TAP_PROF_WGS * TAP_PROF_WAVES * 4);
+    if (clear) {
+        static unsigned long long zeros[TAP_PROF_WGS * TAP_PROF_WAVES * 4];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(tap_prof_tl), zeros, sizeof(zeros));
+    }
+    return 0;
+}
+#endif
 
 int tap_transition_macs_launch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);   // transition_macs.hip
 int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d);                                                    // macs.hip
@@ -78,7 +97,10 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 
 template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-    return launch_transition_v<D, G, 4>(ctx, a, st); // 4 stream waves: best of 1/2/4/8 for both forms of the update
+#ifndef TAP_TRANS_SW
+#define TAP_TRANS_SW 4   // 4 stream waves: best of 1/2/4/8 for both forms of the update (re-measured in round 4, scripts/ab_transition.sh)
+#endif
+    return launch_transition_v<D, G, TAP_TRANS_SW>(ctx, a, st);
 }
 
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
@@ -321,14 +343,17 @@ extern "C" int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *sta
     if (!ctx || !d || !buf || !out) return TAP_E_INVALID;
     int rc = tap_desc_validate(ctx, d);
     if (rc) return rc;
-    if (!state || n < 1 || R < 1 || rows < 1 || update_rows < 0 || update_rows > 3 || static_rows < 1 + d->D || steps < 1)
+    if (n < 1 || R < 1 || rows < 1 || update_rows < 0 || update_rows > 3 || static_rows < 1 + d->D || steps < 1)
         return tap_fail(ctx, TAP_E_INVALID, "bad stepper arguments");
-    for (int w = 0; w < 2; ++w)
-        if (!buf->bits[w] || !buf->dyn[w] || !buf->current[w] || !buf->mask[w])
-            return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of bits / dyn / current / mask");
-    if (buf->bits[0] == buf->bits[1] || buf->dyn[0] == buf->dyn[1] || buf->current[0] == buf->current[1] ||
-        buf->mask[0] == buf->mask[1] || !buf->ratio)
-        return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers and ratio is required");
+    if (d->B > 0) {                                  // an empty batch has no buffers to check
+        if (!state) return tap_fail(ctx, TAP_E_INVALID, "bad stepper arguments");
+        for (int w = 0; w < 2; ++w)
+            if (!buf->bits[w] || !buf->dyn[w] || !buf->current[w] || !buf->mask[w])
+                return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of bits / dyn / current / mask");
+        if (buf->bits[0] == buf->bits[1] || buf->dyn[0] == buf->dyn[1] || buf->current[0] == buf->current[1] ||
+            buf->mask[0] == buf->mask[1] || !buf->ratio)
+            return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers and ratio is required");
+    }
     const int nR = n * R;
     if (buf->tour_stride < 0 || buf->tour_col0 < 0 || (buf->tour_stride > 0 && buf->tour_col0 + steps > buf->tour_stride))
         return tap_fail(ctx, TAP_E_INVALID, "stepper tour columns [col0, col0 + steps) must fit tour_stride");
@@ -349,7 +374,8 @@ extern "C" void tap_stepper_destroy(tap_stepper *s) { delete s; }
 extern "C" int tap_stepper_begin(tap_stepper *s, const float *static_, const float *dyn_in, int flags, void *stream)
 {
     if (!s) return TAP_E_INVALID;
-    if (!static_ || !dyn_in) return tap_fail(s->ctx, TAP_E_INVALID, "stepper_begin needs static and dynamic");
+    if ((!static_ || !dyn_in) && s->d.B > 0) return tap_fail(s->ctx, TAP_E_INVALID, "stepper_begin needs static and dynamic");
+    if (s->d.B == 0) static_ = reinterpret_cast<const float *>(s); // any non-null token: "begun"
     s->static_ = static_;
     s->dyn_in = dyn_in;
     s->bits0 = nullptr;
@@ -371,8 +397,9 @@ extern "C" int tap_stepper_begin(tap_stepper *s, const float *static_, const flo
 extern "C" int tap_stepper_begin_shadow(tap_stepper *s, const float *static_, const unsigned long long *bits, int flags)
 {
     if (!s) return TAP_E_INVALID;
-    if (!static_ || !bits || bits == s->b.bits[0])
+    if (s->d.B > 0 && (!static_ || !bits || bits == s->b.bits[0]))
         return tap_fail(s->ctx, TAP_E_INVALID, "stepper_begin_shadow needs static and a shadow that is not phase 0's buffer");
+    if (s->d.B == 0) static_ = reinterpret_cast<const float *>(s);
     s->static_ = static_;
     s->dyn_in = nullptr;
     s->bits0 = bits;
@@ -387,6 +414,7 @@ extern "C" int tap_stepper_step(tap_stepper *s, const int64_t *ptr, void *stream
     if (!s) return TAP_E_INVALID;
     if (!s->static_) return tap_fail(s->ctx, TAP_E_INVALID, "tap_stepper_begin has not been called");
     if (s->k >= s->steps) return tap_fail(s->ctx, TAP_E_STEPS, "the episode already took its %d steps", s->steps);
+    if (s->d.B == 0) { s->k += 1; return TAP_OK; }
     const int k = s->k, w = k & 1, r = w ^ 1;
     const int flags = ((k == 0 && !s->keep) ? TAP_T_FRESH : 0) | (k == s->steps - 1 ? TAP_T_RATIO : 0);
     const StepAux aux = {s->b.decoder_static, s->b.tour, s->b.tour_stride > 0 ? s->b.tour_stride : s->steps, s->b.tour_col0 + k};
