@@ -39,6 +39,7 @@ struct RollArgs {
     int32_t *nodes_out;       // (B, child) nullable
     int32_t *err_out;         // (B,) nullable: 1 = window could not be filled
     int err_sticky;           // only ever raise err_out (tap_roller: one flag for the whole episode)
+    int wt;                   // flavour of dynamic_out's stores (tap_masks.h: store_stream / tap_write_through)
 };
 
 __device__ __forceinline__ bool rng_meet(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
@@ -473,7 +474,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
                            h2 = sh < 32 ? (unsigned)w2 : (unsigned)(w2 >> 32), h3 = sh < 32 ? (unsigned)w3 : (unsigned)(w3 >> 32);
             const int s5 = sh & 31;
             store_stream(&dst[(size_t)sh * C4], make_float4((float)((h0 >> s5) & 1u), (float)((h1 >> s5) & 1u),
-                                                            (float)((h2 >> s5) & 1u), (float)((h3 >> s5) & 1u)));
+                                                            (float)((h2 >> s5) & 1u), (float)((h3 >> s5) & 1u)), a.wt);
         }
     }
     PROF(7);
@@ -556,7 +557,7 @@ __device__ __forceinline__ void rolling_emit_fast_tail(const RollArgs &a, int in
             for (int q = 0; q < QN; ++q) {
                 if (RP * q + rsub < ROWS) {
                     const unsigned nib = (il >> (RP * q)) & 15u;
-                    store_stream(&dst[(size_t)RP * q * C4], *reinterpret_cast<const float4 *>(&S.f.lut[nib][0]));
+                    store_stream(&dst[(size_t)RP * q * C4], *reinterpret_cast<const float4 *>(&S.f.lut[nib][0]), a.wt);
                 }
             }
         }
@@ -812,7 +813,7 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
         float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
         for (int rw = rsub; rw < rows; rw += RP)
             store_stream(&dst[(size_t)rw * C4], make_float4(bit_as_float(c0, rw), bit_as_float(c1, rw), bit_as_float(c2, rw),
-                                                            bit_as_float(c3, rw)));
+                                                            bit_as_float(c3, rw)), a.wt);
     }
 }
 
@@ -1211,6 +1212,7 @@ static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, con
     if (!blocks || !rel || !state || !static_out || !dynamic_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     RollArgs a = {};
     a.err_sticky = err_sticky;
+    a.wt = tap_write_through((size_t)B * 3 * child * child * (D == 2 ? 2 : 6) * sizeof(float));
     a.B = B; a.D = D; a.N = N; a.child = child; a.blocks = blocks;
     a.rel = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(rel));
     a.state = reinterpret_cast<unsigned long long *>(state);
@@ -1310,6 +1312,7 @@ static int rolling_step_impl(tap_ctx *ctx, const tap_env_desc *d, void *env_stat
     RollStepArgs a = {};
     const int R = d->D == 2 ? 2 : 6;
     a.r.err_sticky = aux != nullptr;
+    a.r.wt = tap_write_through((size_t)d->B * 3 * child * child * R * sizeof(float));
     a.r.B = d->B; a.r.D = d->D; a.r.N = N; a.r.child = child; a.r.blocks = blocks;
     a.r.rel = reinterpret_cast<unsigned long long *>(const_cast<uint64_t *>(rel));
     a.r.state = reinterpret_cast<unsigned long long *>(state);

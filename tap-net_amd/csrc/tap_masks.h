@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
+
+constexpr size_t TAP_WT_MAX_BYTES = 64u << 20;   // write-through up to this many bytes of fp32 tensor per launch (see store_stream)
 
 struct MaskArgs {
     int B, n, R, nR, rows, update_rows, static_rows;
@@ -27,13 +30,17 @@ struct MaskArgs {
     // lane mapping of the 16-byte row accesses (lane = (row group, column quad)), filled by mask_finish() on the
     // host so that no kernel divides by a run-time value: c4_magic = ceil(2^16 / (nR/4)), rp = 64 / (nR/4)
     int c4_magic, rp;
+    int wt;   // flavour of the fp32 expansion's stores (store_stream), set by mask_finish()
 };
+
+inline int tap_write_through(size_t bytes);
 
 inline MaskArgs mask_finish(MaskArgs a)
 {
     const int c4 = a.nR >> 2;
     a.c4_magic = c4 > 0 ? 65536 / c4 + 1 : 0;
     a.rp = c4 > 0 ? 64 / c4 : 0;
+    a.wt = tap_write_through((size_t)a.B * a.rows * a.nR * sizeof(float));
     return a;
 }
 
@@ -62,35 +69,40 @@ __device__ __forceinline__ void tap_wave_lds_sync_m()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 16-byte store of a tensor this kernel will not touch again: WRITE-THROUGH (`sc0 sc1`).  A plain or nontemporal
-// store leaves the line dirty in the XCD's L2, and what is still dirty when the kernel ends is written back at the
-// kernel boundary, after the last wave -- at c2 most of the 19.7 MB a step writes (the eight L2s hold 32 MB).  A
-// write-through store sends the bytes on while the kernel is still running and drops the line.  Measured in round 4
-// (scripts/ab_transition.sh, B = 8192 / 4096, per launch inside the replayed graph): c2 7.10-7.31 us nontemporal ->
-// 6.70 `sc0 sc1` (6.87 `sc1`, 8.03-8.12 plain, 8.69-8.86 `sc1 nt`), c3 8.80-8.84 -> 8.33-8.36; whole passes c2 1 139 ->
-// 1 221 M env-steps/s, c3 458 -> 485 M, c4 441 -> 480 M, c6 125.5 -> 130.7 M.  Writing the step's SMALL outputs (masks,
-// shadow words) through as well lost 4-8 % at c2 (4-byte `sc1` stores are one fabric write each).  (Round 1 had measured
-// nontemporal against plain only: +9 %.)  -DTAP_STORE_MODE=k builds the other forms:
-// 0 nt, 1 sc1, 2 sc0 sc1 (product), 3 sc1 nt, 4 plain
-#ifndef TAP_STORE_MODE
-#define TAP_STORE_MODE 2
-#endif
-__device__ __forceinline__ void store_stream(float4 *dst, const float4 &v)
+// 16-byte store of a tensor this kernel will not touch again, in one of two flavours chosen per launch (`wt`,
+// wave-uniform, tap_write_through() below):
+//   write-through (`sc0 sc1`)  A plain or nontemporal store leaves the line dirty in the XCD's L2, and what is still
+//       dirty when the kernel ends is written back at the kernel boundary, after the last wave -- at c2 most of the
+//       19.7 MB a step writes (the eight L2s hold 32 MB).  A write-through store sends the bytes on while the kernel
+//       is still running and drops the line.  Round 4, B = 8192 / 4096, per launch inside the replayed graph
+//       (scripts/ab_transition.sh): c2 7.10-7.31 us nontemporal -> 6.70 (6.87 `sc1`, 8.03-8.12 plain, 8.69-8.86
+//       `sc1 nt`), c3 8.80-8.84 -> 8.33-8.36; whole passes c2 1 139 -> 1 221 M env-steps/s, c3 458 -> 485 M, c4 441 ->
+//       480 M, c6 125.5 -> 130.7 M.  Writing the step's SMALL outputs (masks, shadow words) through as well lost 4-8 %
+//       at c2 (4-byte `sc1` stores are one fabric write each).
+//   nontemporal  what round 1 chose against plain stores (+9 %); still the better one once a launch writes more than
+//       the L2s hold, where the write-back overlaps the kernel anyway and write-through only adds fabric transactions.
+//       Crossover (bench.py --sweep with TAP_WRITE_THROUGH=1 / 0, us per step): c2's shape 6.54 / 7.26 at B = 8 192
+//       (19.7 MB), 12.5 / 13.0 at 16 384, 24.4 / 21.6 at 32 768 (78.6 MB), 65.5 / 38.3 at 65 536, 0.90 / 1.15 G
+//       env-steps/s beyond; c3's shape 15.5 / 17.5 at 8 192 (59 MB), 37.0 / 30.8 at 16 384 -> write-through up to
+//       TAP_WT_MAX_BYTES = 64 MB per launch.  (The MACS step, whose launches last 17 us and more, still gains at c4's
+//       78.6 MB -- 480 against 441 M env-steps/s -- and takes a higher limit, transition_macs.hip.)
+__device__ __forceinline__ void store_stream(float4 *dst, const float4 &v, int wt)
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f nv = {v.x, v.y, v.z, v.w};
-#if TAP_STORE_MODE == 0
-    __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
-#elif TAP_STORE_MODE == 1
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(nv) : "memory");
-#elif TAP_STORE_MODE == 2
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(nv) : "memory");
-#elif TAP_STORE_MODE == 3
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(dst), "v"(nv) : "memory");
-#else
-    *reinterpret_cast<v4f *>(dst) = nv;
-#endif
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(nv) : "memory");
+    else __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
 }
+
+// Which flavour a launch that writes `bytes` of expanded fp32 tensor takes.  TAP_WRITE_THROUGH=0|1 in the
+// environment forces one (A/B runs; read once).
+inline int tap_write_through(size_t bytes, size_t limit)
+{
+    static const int forced = [] { const char *e = getenv("TAP_WRITE_THROUGH"); return e ? (e[0] != '0') : -1; }();
+    if (forced >= 0) return forced;
+    return bytes <= limit;
+}
+inline int tap_write_through(size_t bytes) { return tap_write_through(bytes, TAP_WT_MAX_BYTES); }
 
 // bit r of a 64-bit column word as 0.f / 1.f without a 64-bit variable shift (quarter rate on CDNA)
 __device__ __forceinline__ float bit_as_float(unsigned long long w, int r)
@@ -434,13 +446,13 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
                     for (int r = rsub; r < rows; r += RP) {
                         const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
                                                      (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
-                        store_stream(&dst[(size_t)r * C4], v);
+                        store_stream(&dst[(size_t)r * C4], v, a.wt);
                     }
                 } else {
                     for (int r = rsub; r < rows; r += RP) {
                         const float4 v = make_float4(bit_as_float(n0, r), bit_as_float(n1, r), bit_as_float(n2, r),
                                                      bit_as_float(n3, r));
-                        store_stream(&dst[(size_t)r * C4], v);
+                        store_stream(&dst[(size_t)r * C4], v, a.wt);
                     }
                 }
             }
@@ -577,7 +589,7 @@ __device__ __forceinline__ void stream_wave_bits2(const MaskArgs &a, int env, in
                 const int rb = r & 63;
                 const float4 v = make_float4(bit_as_float(up ? w4[1][0] : w4[0][0], rb), bit_as_float(up ? w4[1][1] : w4[0][1], rb),
                                              bit_as_float(up ? w4[1][2] : w4[0][2], rb), bit_as_float(up ? w4[1][3] : w4[0][3], rb));
-                store_stream(&dst[(size_t)r * C4], v);
+                store_stream(&dst[(size_t)r * C4], v, a.wt);
             }
         }
         if (rsub == 0 && a.bits_out) {

@@ -94,3 +94,4 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
         (void)group_min<G>(INT_MAX);
     }
 }
+

@@ -70,6 +70,13 @@ extern "C" int tap_prof_read_timeline(unsigned long long *out, int clear)
 }
 #endif
 
+// (Round 4, measured and removed: ONE LANE per container for the 2D placement inside this kernel -- the corners walked
+//  one after the other with the height-map in registers, no LDS, no cross-lane step -- to cut the placement's vector
+//  instructions for large batches.  SQ_INSTS_VALU per launch at c2 went UP, 1.94 M -> 2.27 M (the corner and footprint
+//  loops run predicated over 8 x 8 register cells on every lane), the step from 6.86 to 7.48 us at B = 8192 (the serial
+//  chain of up to five scored corners becomes the launch's tail), and at B = 1 M nothing moved (877 against 898 M
+//  env-steps/s): the saturated regime is not bound by vector issue -- 248 M vector instructions per 1.16 ms launch are
+//  35 % of the SIMDs' issue slots.)
 int tap_transition_macs_launch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);   // transition_macs.hip
 int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d);                                                    // macs.hip
 

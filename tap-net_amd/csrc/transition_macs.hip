@@ -176,8 +176,12 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
 }
 
 
-int tap_transition_macs_launch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st)
+int tap_transition_macs_launch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a0, hipStream_t st)
 {
+    // these launches last 17 us and more, so the fp32 expansion's stores stay write-through up to a higher limit than
+    // the LB_GREEDY step's (tap_masks.h: store_stream; c4's 78.6 MB per launch: 480 against 441 M env-steps/s)
+    TransArgs a = a0;
+    a.m.wt = tap_write_through((size_t)a.m.B * a.m.rows * a.m.nR * sizeof(float), (size_t)128 << 20);
     const int Gs = tap_group_size(d);
     if (d->D == 3) {
         switch (Gs) {
