@@ -112,8 +112,8 @@ int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream
 
 /* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy
  * 2027-2351, is_stable_2d 839-868, is_stable 710-765; with strategy TAP_MACS ->
- * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 64, H <= 256;
- * 3D: W, L <= 8, H <= 512 and block sides <= container sides, else error bit 4); model.py:451-465 is
+ * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 64, H <= 4096;
+ * 3D: W, L <= 8, H <= 4096 and block sides <= container sides, else error bit 4); model.py:451-465 is
  * the loop it replaces).
  *   blocks      (B, D) TAP_DT_F32 | TAP_DT_I32, one block per env; f32 is truncated like
  *               block.astype(int) (tools.py:3689)
@@ -383,7 +383,7 @@ enum {
  * tap_mask_step + tap_env_step_gather fused, so the placement's latency hides under the HBM-bound
  * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
  * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
- * One kernel for LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D with H <= 512); every other
+ * One kernel for LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D up to 8 x 8), as long as a workgroup's candidate lists fit the device's LDS (160 KiB per workgroup on gfx950); every other
  * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY above 64 cells, MACS 2D up to 64 columns, a MACS
  * container whose candidate lists do not fit a fused workgroup's LDS) runs the same step as its two launches behind
  * this entry.  feature_out nullable; ratio_out (B,) f32 required with
@@ -393,6 +393,11 @@ int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int 
                    const int64_t *ptr, const float *mask_in, const float *colsum_in,
                    float *dyn_out, float *colsum_out, float *current_out, float *mask_out,
                    float *feature_out, float *ratio_out, int flags, void *stream);
+
+/* 1 when the tap_transition* entry points run a step of this shape as ONE kernel, 2 when they run it as the
+ * precedence update followed by the placement (see above; for MACS the answer depends on the device's LDS).
+ * on_bits != 0: tap_transition_bits / _first (the single kernels carry the one-word shadow: rows <= 64). */
+int tap_transition_launches(const tap_ctx *ctx, const tap_env_desc *d, int n, int R, int rows, int on_bits);
 
 /* tap_transition with the precedence update done on the bit shadow (tap_mask_step_bits).  The single kernels
  * carry the one-word shadow (rows <= 64); with the two-word shadow the step runs as its two launches. */

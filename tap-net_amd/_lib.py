@@ -103,6 +103,7 @@ _PROTOS = {
                                   _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "tap_transition_bits": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "tap_transition_launches": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _i, _i]),
     "tap_bw_probe": (_i, [_vp, _i, _vp, _vp, _sz, _vp]),
     "tap_stepper_create": (_i, [_vp, C.POINTER(EnvDesc), _vp, _i, _i, _i, _i, _i, _i, _vp, C.POINTER(_vp)]),
     "tap_stepper_destroy": (None, [_vp]),

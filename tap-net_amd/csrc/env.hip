@@ -53,6 +53,9 @@ extern "C" int tap_ctx_create(int device, tap_ctx **out)
     (void)hipGetDevice(&prev);
     c->chk = nullptr;
     c->chk_next = 0;
+    int lds = 0;
+    c->lds_limit = (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds > 0)
+                       ? (size_t)lds : (size_t)64 * 1024;
     bool ok = hipSetDevice(device) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&c->chk), 2 * TAP_CHK_SLOTS * sizeof(int32_t)) == hipSuccess &&
               hipMalloc(reinterpret_cast<void **>(&c->stab_lut), TAP_LUT_WORDS * sizeof(uint32_t)) == hipSuccess &&

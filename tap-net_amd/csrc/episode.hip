@@ -219,15 +219,15 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode_macs2(EpisodeArgs a)
 template <int G, bool WIDE> static int launch_episode_macs2(tap_ctx *ctx, const EpisodeArgs &a, hipStream_t st)
 {
     const tap_env_desc &d = a.d;
-    int threads = TAP_BLOCK; // as many containers per workgroup as fit the 64 KB dynamic-LDS window
     const size_t per_env = (size_t)(WIDE ? macs_wide_group_words(G, d.H, a.n, d.W) : macs_group_words(G, d.H, a.n, d.W)) * sizeof(int);
-    const size_t budget = 64 * 1024 - (TAP_BLOCK / G) * EP_PF * sizeof(int4);   // the block-list rows are static LDS
-    while (threads > 64 && (threads / G) * per_env > budget) threads /= 2;
+    // the block-list rows are static LDS
+    const int threads = tap_lds_threads(per_env, G, tap_lds_limit(ctx), (TAP_BLOCK / G) * EP_PF * sizeof(int4));
+    if (threads == 0)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS episode: W=%d H=%d n=%d need %zu bytes of LDS per container", d.W, d.H, a.n, per_env);
     const int epb = threads / G, grid = (a.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > budget)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS episode: W=%d H=%d n=%d need %zu bytes of LDS per workgroup", d.W, d.H, a.n, lds);
+    TAP_HIP_CHECK(ctx, tap_allow_lds(k_episode_macs2<G, WIDE>, lds));
     hipLaunchKernelGGL((k_episode_macs2<G, WIDE>), dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_episode_macs2");
     return TAP_OK;
@@ -291,15 +291,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode_macs3(EpisodeArgs a)
 template <int G> static int launch_episode_macs3(tap_ctx *ctx, const EpisodeArgs &a, hipStream_t st)
 {
     const tap_env_desc &d = a.d;
-    int threads = TAP_BLOCK;
     const size_t per_env = (size_t)macs3_group_words(G, a.n, d.H) * sizeof(int);
-    const size_t budget = 64 * 1024 - (TAP_BLOCK / G) * EP_PF * sizeof(int4);
-    while (threads > 64 && (threads / G) * per_env > budget) threads /= 2;
+    const int threads = tap_lds_threads(per_env, G, tap_lds_limit(ctx), (TAP_BLOCK / G) * EP_PF * sizeof(int4));
+    if (threads == 0)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D episode: H=%d n=%d need %zu bytes of LDS per container", d.H, a.n, per_env);
     const int epb = threads / G, grid = (a.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > budget)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D episode: n=%d needs %zu bytes of LDS per workgroup", a.n, lds);
+    TAP_HIP_CHECK(ctx, tap_allow_lds(k_episode_macs3<G>, lds));
     hipLaunchKernelGGL(k_episode_macs3<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_episode_macs3");
     return TAP_OK;

@@ -82,14 +82,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_step(StepArgs a)
 template <int G> static int launch_macs(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     const tap_env_desc &d = a.d;
-    int threads = TAP_BLOCK; // as many envs per workgroup as fit the 64 KB dynamic-LDS window
     const size_t per_env = (size_t)macs_group_words(G, d.H, d.n_max, d.W) * sizeof(int);
-    while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
+    const int threads = tap_lds_threads(per_env, G, tap_lds_limit(ctx));   // containers per workgroup by the device's LDS
+    if (threads == 0)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS: H=%d blocks_num=%d need %zu bytes of LDS per container", d.H, d.n_max, per_env);
     const int epb = threads / G, grid = (d.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > 64 * 1024)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS: H=%d blocks_num=%d need %zu bytes of LDS per workgroup", d.H, d.n_max, lds);
+    TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs2d_step<G>, lds));
     hipLaunchKernelGGL(k_macs2d_step<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_macs2d_step");
     return TAP_OK;
@@ -108,14 +108,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wide_step(StepArgs a)
 template <int G> static int launch_macs_wide(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     const tap_env_desc &d = a.d;
-    int threads = TAP_BLOCK;
     const size_t per_env = (size_t)macs_wide_group_words(G, d.H, d.n_max, d.W) * sizeof(int);
-    while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
+    const int threads = tap_lds_threads(per_env, G, tap_lds_limit(ctx));
+    if (threads == 0)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS: W=%d H=%d blocks_num=%d need %zu bytes of LDS per container", d.W, d.H, d.n_max, per_env);
     const int epb = threads / G, grid = (d.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > 64 * 1024)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS: W=%d H=%d blocks_num=%d need %zu bytes of LDS per workgroup", d.W, d.H, d.n_max, lds);
+    TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs2d_wide_step<G>, lds));
     hipLaunchKernelGGL(k_macs2d_wide_step<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_macs2d_wide_step");
     return TAP_OK;
@@ -134,14 +134,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_step(StepArgs a)
 template <int G> static int launch_macs3(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     const tap_env_desc &d = a.d;
-    int threads = TAP_BLOCK;
     const size_t per_env = (size_t)macs3_group_words(G, d.n_max, d.H) * sizeof(int);
-    while (threads > 64 && (threads / G) * per_env > 64 * 1024) threads /= 2;
+    const int threads = tap_lds_threads(per_env, G, tap_lds_limit(ctx));
+    if (threads == 0)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D: H=%d blocks_num=%d need %zu bytes of LDS per container", d.H, d.n_max, per_env);
     const int epb = threads / G, grid = (d.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
-    if (lds > 64 * 1024)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D: blocks_num=%d needs %zu bytes of LDS per workgroup", d.n_max, lds);
+    TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_step<G>, lds));
     hipLaunchKernelGGL(k_macs3d_step<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_macs3d_step");
     return TAP_OK;

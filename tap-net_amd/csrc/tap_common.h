@@ -11,14 +11,41 @@
 #include "tapenv.h"
 
 constexpr int TAP_CHK_SLOTS = 64;
+constexpr int TAP_BLOCK = 256; // threads per workgroup (4 wave64)
 
 struct tap_ctx {
     int device;
     uint32_t *stab_lut; // device: tap_stable3d for footprints <= 4x4 (tap_place.h), built at create
     int32_t *chk;       // device: TAP_CHK_SLOTS x 2 ints (flagged envs, OR of their error words) for tap_env_check
     unsigned chk_next;  //   next slot
+    size_t lds_limit;   // LDS a workgroup may allocate on this device (gfx950: 160 KiB per CU), queried at create
     char err[512];
 };
+
+// LDS budget of one workgroup: what the device reports (hipDeviceAttributeMaxSharedMemoryPerBlock; 160 KiB on
+// gfx950), never the 64 KiB of earlier CDNA parts
+inline size_t tap_lds_limit(const tap_ctx *ctx) { return (ctx && ctx->lds_limit) ? ctx->lds_limit : (size_t)64 * 1024; }
+
+// Threads per workgroup for kernels that keep `per_env` bytes of dynamic LDS per container (G lanes each): the
+// containers resident on a CU are bounded by LDS / per_env whatever the workgroup size, so a workgroup is sized to
+// leave room for a second one (<= limit / 2) where that is possible -- smaller workgroups pack the CU's LDS better --
+// and only a container that needs more than half the LDS gets a workgroup to itself.  0 = does not fit at all.
+inline int tap_lds_threads(size_t per_env, int G, size_t limit, size_t static_bytes = 0)
+{
+    const size_t budget = limit > static_bytes ? limit - static_bytes : 0;
+    int threads = TAP_BLOCK;
+    while (threads > 64 && (size_t)(threads / G) * per_env > budget / 2) threads /= 2;
+    if (threads < G) threads = G;
+    while (threads > G && threads > 64 && (size_t)(threads / G) * per_env > budget) threads /= 2;
+    return (size_t)(threads / G) * per_env <= budget ? threads : 0;
+}
+
+// a launch whose dynamic LDS exceeds the 64 KiB default window must raise the kernel's limit first
+template <typename K> inline hipError_t tap_allow_lds(K kernel, size_t bytes)
+{
+    if (bytes <= (size_t)64 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
 inline int tap_fail(tap_ctx *ctx, int code, const char *fmt, ...)
 {
@@ -47,7 +74,6 @@ inline int tap_fail(tap_ctx *ctx, int code, const char *fmt, ...)
                             hipGetErrorString(e_));                                          \
     } while (0)
 
-constexpr int TAP_BLOCK = 256; // threads per workgroup (4 wave64)
 
 // A column index handed in by the caller (ptr / tour).  The reference raises IndexError for a value
 // outside [0, nR); here it must never become an out-of-bounds read: the index is replaced by column 0

@@ -34,7 +34,7 @@ __host__ __device__ constexpr int macs_ems_cap(int W, int n_max)
     const int cap = ((W + 1) * ((W + 1) / 2) + 2 * n_max + 1) & ~1;
     return cap < 16 ? 16 : cap;   // the slot list (2 cap ints) doubles as the 2 G-entry scratch of phase 1 (b), G <= 16
 }
-constexpr int MACS_MAX_H = 256;
+constexpr int MACS_MAX_H = 4096;   // the per-level `taken` masks live in LDS (2 bytes per level); EMS entries hold z in 15 bits
 
 // LDS words per env group: hm | ems[cap] | slots[2 cap] | taken (uint16 per level) | history (x, z, bx, bz)
 __host__ __device__ constexpr int macs_group_words(int G, int H, int n_max, int W)

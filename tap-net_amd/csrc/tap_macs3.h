@@ -33,8 +33,7 @@
 #include "tap_place.h"
 
 constexpr int MACS3_EMS_CAP = 192; // packed EMS entries per env (<= 61 seen at 8x8, 40 blocks)
-constexpr int MACS3_MAX_H = 512;   // HW = ceil(H / 64) <= 8 words per cell
-constexpr int MACS3_MAX_HW = MACS3_MAX_H / 64;
+constexpr int MACS3_MAX_H = 4096;  // HW = ceil(H / 64) words per cell, in LDS and in the state blob; no register array scales with it
 constexpr int MACS3_HIST = 2;      // ints per history entry: x | y<<4 | xx<<8 | yy<<12 | placed<<16,  z | zz<<16
 
 __host__ __device__ constexpr int macs3_hw(int H) { return (H + 63) / 64; }
@@ -742,12 +741,12 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
         res.placed = 1; res.x = px; res.y = py; res.z = Z; res.stab = stab;
         const int cx = tap_div_small(cell, L), cy = cell - cx * L;
         const bool foot = cell < cells && cx >= px && cx < px + bx && cy >= py && cy < py + by;
-        u64 nw[MACS3_MAX_HW] = {};
-        if (foot) {
-            // update_level_free_space (:2989-3041) on this cell's column of F, 64 levels at a time
-#pragma unroll
-            for (int w = 0; w < MACS3_MAX_HW; ++w) {
-                if (w >= HW) break;
+        // update_level_free_space (:2989-3041) on this cell's column of F, 64 levels at a time.  A cell's new word w
+        // depends on its neighbours' OLD word w only, so the column is rewritten word by word -- read, wave-level
+        // hand-off, write -- with one word in registers whatever the container's height
+        for (int w = 0; w < HW; ++w) {
+            u64 nw = 0;
+            if (foot) {
                 u64 keep = 0;
                 if (px > 0 && px + bx < W) {
                     keep = ~0ull;
@@ -756,15 +755,12 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
                 const int lo = Z - 64 * w, hi = Z + bz - 64 * w;        // block = bits [lo, hi) of this word
                 const u64 below = lo <= 0 ? 0ull : (lo >= 64 ? ~0ull : ((1ull << lo) - 1ull));
                 const u64 upto = hi <= 0 ? 0ull : (hi >= 64 ? ~0ull : ((1ull << hi) - 1ull));
-                nw[w] = S.occ[(size_t)cell * HW + w] | (upto & ~below) | (below & ~keep);
+                nw = S.occ[(size_t)cell * HW + w] | (upto & ~below) | (below & ~keep);
             }
-            hm = Z + bz;                                                             // :3161
+            tap_wave_lds_sync(); // every neighbour's word w is read before any is replaced
+            if (foot) S.occ[(size_t)cell * HW + w] = nw;
         }
-        tap_wave_lds_sync(); // every neighbour word is read before any is replaced
-        if (foot) {
-#pragma unroll
-            for (int w = 0; w < MACS3_MAX_HW; ++w) if (w < HW) S.occ[(size_t)cell * HW + w] = nw[w];
-        }
+        if (foot) hm = Z + bz;                                                       // :3161
         cnt.valid += vol;
         cnt.empty = emp;
         cnt.nstable += stab;

@@ -119,16 +119,17 @@ static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransA
 // register-heavy work, the stream waves hide nothing and their wave slots cost a quarter of the resident envs.)
 // The tap_transition* entry points then run the same step as its two launches (precedence update, placement) plus
 // reset / calc_ratio where the flags ask for them, so a caller drives every shape through one entry point.
-static bool transition_single_kernel(const tap_env_desc *d, int nR)
+static bool transition_single_kernel(const tap_ctx *ctx, const tap_env_desc *d, int nR)
 {
     if (d->strategy == TAP_LB || tap_is_big(d) || (d->strategy == TAP_MACS && d->D == 2 && d->W > 16)) return false;
     if (d->strategy == TAP_MACS) {
         // the MACS placement keeps its lists in LDS: a container too tall (or an episode too long) for one workgroup's
-        // 64 KB next to the stream tiles takes the two launches as well (the stand-alone step runs fewer envs per workgroup)
+        // LDS (160 KiB on gfx950) next to the stream tiles takes the two launches as well (the stand-alone step runs
+        // fewer envs per workgroup)
         const int G = tap_group_size(d), epb = G == 64 ? 4 : 8;
         const size_t words = d->D == 3 ? (size_t)macs3_group_words(G, d->n_max, d->H)
                                        : (size_t)macs_group_words(d->W <= 8 ? 8 : 16, d->H, d->n_max, d->W);
-        if ((size_t)epb * 3 * nR * sizeof(float) + (size_t)epb * words * sizeof(int) > 64 * 1024) return false;
+        if ((size_t)epb * 3 * nR * sizeof(float) + (size_t)epb * words * sizeof(int) > tap_lds_limit(ctx)) return false;
     }
     return true;
 }
@@ -162,6 +163,12 @@ int tap_step_aux_launch(tap_ctx *ctx, const StepArgs &s, hipStream_t st)
     hipLaunchKernelGGL(k_step_aux, dim3((s.d.B + TAP_BLOCK - 1) / TAP_BLOCK), dim3(TAP_BLOCK), 0, st, s);
     TAP_LAUNCH_CHECK(ctx, "k_step_aux");
     return TAP_OK;
+}
+
+extern "C" int tap_transition_launches(const tap_ctx *ctx, const tap_env_desc *d, int n, int R, int rows, int on_bits)
+{
+    if (!d || n < 1 || R < 1 || rows < 1) return TAP_E_INVALID;
+    return (transition_single_kernel(ctx, d, n * R) && (!on_bits || rows <= 64)) ? 1 : 2;
 }
 
 static int transition_tail(tap_ctx *ctx, const tap_env_desc *d, void *state, const TransArgs &a, void *stream)
@@ -215,7 +222,7 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
     if (dyn_in == dyn_out) return tap_fail(ctx, TAP_E_INVALID, "transition is out of place (pack.py:370)");
-    if (!transition_single_kernel(d, n * R)) {
+    if (!transition_single_kernel(ctx, d, n * R)) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, colsum_in, dyn_out,
                            colsum_out, current_out, mask_out, stream);
@@ -240,7 +247,7 @@ static int transition_bits_impl(tap_ctx *ctx, const tap_env_desc *d, void *state
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
-    if (!transition_single_kernel(d, n * R) || rows > 64) {      // the fused kernels carry the one-word shadow only
+    if (!transition_single_kernel(ctx, d, n * R) || rows > 64) {      // the fused kernels carry the one-word shadow only
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_bits(ctx, d->B, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
                                 dyn_out, current_out, mask_out, stream);
@@ -277,7 +284,7 @@ static int transition_first_impl(tap_ctx *ctx, const tap_env_desc *d, void *stat
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
-    if (!transition_single_kernel(d, n * R) || rows > 64) {
+    if (!transition_single_kernel(ctx, d, n * R) || rows > 64) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_first(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,
                                  dyn_out, current_out, mask_out, nonbinary_out, stream);

@@ -134,9 +134,10 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
                        (size_t)EPB * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
-    if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
+    if (lds > tap_lds_limit(ctx)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
+#define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs3<G, NC_, M_>, LDS_)); \
+        hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
 #define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
@@ -159,9 +160,10 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
                        (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max, a.s.d.W) * sizeof(int);
-    if (lds > 64 * 1024) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
+    if (lds > tap_lds_limit(ctx)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition_macs<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a)
+#define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs<G, NC_, M_>, LDS_)); \
+        hipLaunchKernelGGL((k_transition_macs<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
 #define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;

@@ -553,6 +553,13 @@ class EpisodeStepper(object):
         if h:
             self._destroy(h)
 
+    @property
+    def launches_per_step(self):
+        """1 when a step of this shape is ONE kernel, 2 when the entry point runs the precedence update and the
+        placement as two launches (tapenv.h: tap_transition_launches)."""
+        import ctypes as C
+        return int(_lib.lib().tap_transition_launches(self._ctx, C.byref(self.env.desc), self.n, self.R, self.rows, 1))
+
     def _check_instances(self, static, what, shape):
         if (static.dtype is not torch.float32 or not static.is_contiguous() or static.device != self._dev or
                 tuple(static.shape) != shape):
