@@ -107,10 +107,11 @@ def compulsory_bytes(kind, D, cs, n, bits=True, static_rows=None):
     flen = cs[0] - 1 if D == 2 else 2 * cells
     # container: hm + 4 counters in and out, position + stable flag out, feature out, the block's D sides in
     env = 2 * (cells * 4 + 16) + D * 4 + 1 + flen * 4 + D * 4
-    # precedence update on the bit shadow: ptr, row 0 of static (block id), mask in; shadow in + out; fp32 tensor
-    # out; both masks out
-    shadow = 8 + nR * 4 + nR * 4 + 2 * nR * 8 + rows * nR * 4 + 2 * nR * 4
-    copy = 8 + nR * 4 + nR * 4 + 2 * 3 * nR * 4 + 2 * rows * nR * 4 + 2 * nR * 4     # column-sum shadow in + out, tensor in + out
+    # precedence update on the bit shadow: ptr, ONE float of row 0 of static (the block id of the picked column; the
+    # stream wave fetches the whole 4 nR-byte row and shuffles, but 4 bytes are what the step needs), mask in; shadow
+    # in + out; fp32 tensor out; both masks out
+    shadow = 8 + 4 + nR * 4 + 2 * nR * 8 + rows * nR * 4 + 2 * nR * 4
+    copy = 8 + 4 + nR * 4 + 2 * 3 * nR * 4 + 2 * rows * nR * 4 + 2 * nR * 4     # column-sum shadow in + out, tensor in + out
     if kind == "mask_step":
         return shadow if bits else copy
     if kind == "env_step":
@@ -1344,13 +1345,23 @@ def main():
     total_steps = B * world * n * args.steps
     value = total_steps / dt
     # who ran where, and how fast each rank was on its own clock (the job's figure is the MAX over ranks)
+    props = torch.cuda.get_device_properties(local)
     mine = dict(rank=rank, device_index=local, device=torch.cuda.get_device_name(local), pid=os.getpid(),
+                host=socket.gethostname(), pci_bus_id=getattr(props, "pci_bus_id", None),
                 value=B * n * args.steps / statistics.median(hp.local_bracket_times))
     per_rank = [mine]
     if world > 1:
         import torch.distributed as dist
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
+        # one process per GPU: under RCCL two ranks on one device would still produce a line, at half the speed and
+        # with an exchange that never left the chip -- refuse loudly instead (the gloo self-test shares a GPU on purpose)
+        distinct = len({(r["host"], r["device_index"]) for r in per_rank})
+        if dist.get_backend() == "nccl" and distinct != world:
+            if rank == 0:
+                print("bench.py: %d RCCL ranks on %d distinct device(s): %s -- refusing to report a line"
+                      % (world, distinct, [(r["rank"], r["host"], r["device_index"]) for r in per_rank]), file=sys.stderr)
+            sys.exit(3)
     # every rank checks its own last pass against the oracle; the line says "verified" only if all did
     ver = dict(verified=None, why="--no-verify") if args.no_verify else hp.verify()
     if getattr(hp, "gathered_ok", None) is not None and not args.no_verify:
@@ -1495,6 +1506,7 @@ def main():
             "ranks": dict(world_size=world, backend=(torch.distributed.get_backend() if world > 1 else None),
                           rccl_ranks=(torch.distributed.get_world_size() if world > 1 and
                                       torch.distributed.get_backend() == "nccl" else (1 if world == 1 else 0)),
+                          distinct_devices=len({(r["host"], r["device_index"]) for r in per_rank}),
                           spawned_by_bench=os.environ.get("TAP_BENCH_SPAWNED") == "1",
                           first_all_gather_ms=getattr(hp, "first_gather_ms", None),
                           per_rank=per_rank),

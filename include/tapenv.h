@@ -155,6 +155,11 @@ int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32
 int tap_stable3d_eval(tap_ctx *ctx, int bx, int by, const unsigned long long *masks, int n,
                       int use_lut, uint8_t *stable_out, void *stream);
 
+/* The containers' sticky error words, asynchronously: err_out (B,) int32 with bit 1 = a placement reached above H
+ * (the reference raises IndexError, tools.py:2109), 2 = add_new_block called more than blocks_num times, 4 = bad
+ * block / column index, 8 / 16 = MACS list guards.  For callers that report per container instead of raising. */
+int tap_env_errors(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32_t *err_out, void *stream);
+
 /* Synchronous.  Returns TAP_OK, or TAP_E_OVERFLOW / TAP_E_STEPS if any env has raised its sticky
  * error word; *n_bad_out (host, nullable) = number of such envs. */
 int tap_env_check(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32_t *n_bad_out,
@@ -343,13 +348,18 @@ int tap_mask_step(tap_ctx *ctx, int B, int n, int R, int rows, int update_rows,
  * step WRITES rows*nR*4 bytes per env and reads nR*8.  Outputs are bit-identical to tap_mask_step /
  * tap_transition for 0/1 input. */
 
-/* bits_out = shadow of dynamic; *nonbinary_out (device int32, nullable, caller zeroes it) is
- * incremented by the number of elements that are neither 0 nor 1 -- the shadow is only valid at 0.
+/* uint64 words PER ENV of the shadow of a (rows, nR) window: nR up to 64 rows, 2 * nR for 65 .. 128 rows, 0 when the
+ * shape has no shadow.  Every bits_in / bits_out buffer below holds B * tap_bits_words(rows, nR) words; the library
+ * cannot see the allocation, so size it with this. */
+int tap_bits_words(int rows, int nR);
+
+/* bits_out (B, tap_bits_words(rows, nR)) = shadow of dynamic; *nonbinary_out (device int32, nullable, caller zeroes
+ * it) is incremented by the number of elements that are neither 0 nor 1 -- the shadow is only valid at 0.
  * bits_out NULL: count only (then rows may exceed 128). */
 int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
                  unsigned long long *bits_out, int32_t *nonbinary_out, void *stream);
 
-/* tap_mask_step on the shadow.  Every output is nullable (at least one must be given) and mask_in
+/* tap_mask_step on the shadow (bits_in / bits_out: B * tap_bits_words(rows, nR) words each).  Every output is nullable (at least one must be given) and mask_in
  * NULL means ones, so the same entry serves pack.update_dynamic alone (no mask outputs) and
  * pack.update_mask alone (update_rows = 0, masks only); ptr NULL (with update_rows = 0; static_ is then
  * unused) gives the initial mask of model.py:297-307.  A ptr outside [0, nR) -- the reference's gather

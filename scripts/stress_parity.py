@@ -55,6 +55,9 @@ for seed in range(int(sys.argv[1])):
         W, L = rs.randint(2, 8), rs.randint(2, 8)
         cs = [int(W), int(L), int(rs.choice([40, 64, 100, 200]))]; n = int(rs.randint(6, 22)); hi = int(min(W, L, 5)) + 1
         reward = str(rs.choice(["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "C+P+S-mul-hard", "mcs-soft", "mcs-hard", "C+P-mcs-soft"])); strat = "MACS"
+        if seed % 20 == 0:                                   # one in four of the family: 30 .. 70 small blocks into a tall container --
+            r2 = np.random.RandomState(7000 + seed)          # the voxel-identity masks of tap_macs3_place change regime at 32 and 64
+            n = int(r2.randint(30, 71)); cs[2] = int(r2.choice([300, 600, 1000])); hi = 3   # placed blocks (narrow -> by_bits -> fallback)
     elif kind == 1:  # MACS 2D
         W = int(rs.randint(2, 14)); cs = [W, int(rs.choice([60, 100, 200]))]; n = int(rs.randint(6, 24)); hi = min(W, 6) + 1
         reward = str(rs.choice(["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft", "C+P-mcs-hard"])); strat = "MACS"

@@ -76,6 +76,8 @@ _PROTOS = {
     "tap_env_export": (_i, [_vp, C.POINTER(EnvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_stable3d_eval": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "tap_env_check": (_i, [_vp, C.POINTER(EnvDesc), _vp, C.POINTER(C.c_int32), _vp]),
+    "tap_env_errors": (_i, [_vp, C.POINTER(EnvDesc), _vp, _vp, _vp]),
+    "tap_bits_words": (_i, [_i, _i]),
     "tap_episode_reward": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "tap_episode_scores": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "tap_pack_blocks": (_i, [_vp, C.POINTER(EnvDesc), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

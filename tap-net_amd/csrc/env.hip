@@ -413,6 +413,25 @@ extern "C" int tap_env_export(tap_ctx *ctx, const tap_env_desc *d, const void *s
     return TAP_OK;
 }
 
+__global__ void __launch_bounds__(TAP_BLOCK) k_env_errors(int B, const int32_t *err, int32_t *out)
+{
+    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    if (env < B) out[env] = err[env];
+}
+
+extern "C" int tap_env_errors(tap_ctx *ctx, const tap_env_desc *d, const void *state, int32_t *err_out, void *stream)
+{
+    int rc = tap_desc_validate(ctx, d);
+    if (rc) return rc;
+    if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
+    if (!state || !err_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    EnvView v;
+    tap_env_layout(d, const_cast<void *>(state), &v);
+    hipLaunchKernelGGL(k_env_errors, dim3((d->B + TAP_BLOCK - 1) / TAP_BLOCK), dim3(TAP_BLOCK), 0, (hipStream_t)stream, d->B, v.err, err_out);
+    TAP_LAUNCH_CHECK(ctx, "k_env_errors");
+    return TAP_OK;
+}
+
 __global__ void __launch_bounds__(TAP_BLOCK) k_env_check(int B, const int32_t *err, int32_t *out)
 {
     int bad = 0, bits = 0;

@@ -144,6 +144,12 @@ extern "C" int tap_dyn_colsum(tap_ctx *ctx, int B, int n, int nR, int rows, cons
     return TAP_OK;
 }
 
+extern "C" int tap_bits_words(int rows, int nR)
+{
+    if (rows < 1 || rows > 128 || nR < 1 || nR > 256 || nR % 4 != 0) return 0;
+    return mask_bit_planes(rows) * nR;
+}
+
 extern "C" int tap_dyn_bits(tap_ctx *ctx, int B, int nR, int rows, const float *dynamic,
                             unsigned long long *bits_out, int32_t *nonbinary_out, void *stream)
 {

@@ -1149,10 +1149,11 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
 
 static int roll_check(tap_ctx *ctx, int B, int D, int N, int child)
 {
+    // windows: at most 64 nodes (one 64-bit word of sub-graph rows per node); instances of 65 .. 128 blocks keep the
+    // one-wavefront kernels while the window has at most 32 nodes (roll_wide_ok), beyond that one thread per instance
     if ((D != 2 && D != 3) || B < 0 || N < 1 || N > ROLL_MAX_N || child < 1 || child > N || child > 64)
-        return tap_fail(ctx, TAP_E_INVALID, "bad rolling arguments (total blocks <= %d, window <= min(total, 64))", ROLL_MAX_N);
-    if (2 * child < N && child > 76)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "window too large for the set-order table");
+        return tap_fail(ctx, TAP_E_INVALID, "bad rolling arguments (total blocks <= %d, window <= min(total, 64); instances above 64 "
+                                            "blocks run on one wavefront each up to 128 blocks with windows of at most 32 nodes)", ROLL_MAX_N);
     return TAP_OK;
 }
 
@@ -1230,7 +1231,6 @@ static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, con
         return TAP_OK;
     }
     if (N > 64) {                                                     // one thread per instance
-        if (child > 76) return tap_fail(ctx, TAP_E_UNSUPPORTED, "window too large for the set-order table");
         const int g2 = (B + 63) / 64;
         if (D == 2) hipLaunchKernelGGL(k_rolling_window_big<2>, dim3(g2), dim3(64), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL(k_rolling_window_big<3>, dim3(g2), dim3(64), 0, (hipStream_t)stream, a);

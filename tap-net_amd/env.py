@@ -150,6 +150,14 @@ class BatchedContainer(object):
         self._call(_lib.lib().tap_env_ratio, _lib.ptr(self._state), None, None, _lib.ptr(cps))
         return cps
 
+    @property
+    def errors(self):
+        """(B,) int32 sticky error words (tapenv.h: tap_env_errors), asynchronously: bit 1 = a placement reached above
+        the container height, 2 = too many steps, 4 = bad block / column index, 8 / 16 = MACS list guards."""
+        err = torch.empty(self.batch_size, dtype=torch.int32, device=self.device)
+        self._call(_lib.lib().tap_env_errors, _lib.ptr(self._state), _lib.ptr(err))
+        return err
+
     def check(self):
         """Synchronises; raises TapOverflowError (an IndexError, like the reference) if any env
         was pushed above its height, TapError for other sticky errors."""

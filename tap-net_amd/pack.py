@@ -275,9 +275,9 @@ def first_shadow_and_mask(dynamic, blocks_num, counter=None):
 
 
 def bits_supported(rows, nR):
-    """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_mask_step_bits): one word per column up to 64
+    """Shapes the bit shadow of `dynamic` covers (tapenv.h: tap_bits_words): one word per column up to 64
     rows (windows of at most 21 nodes), two up to 128 rows (42 nodes)."""
-    return rows <= 128 and nR % 4 == 0 and nR <= 256
+    return _lib.lib().tap_bits_words(int(rows), int(nR)) > 0
 
 
 def _bit_planes(rows):
@@ -715,9 +715,11 @@ _NET_REWARD_TYPES = ('C+P+S-SL-soft', 'C+P+S-RL-soft', 'C+P+S-G-soft', 'C+P+S-LG
 RENDER_FILES = ('ratio', 'valid_size', 'box_size', 'empty_size', 'stable_num', 'packing_height', 'time', 'ids')
 
 
-def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target):
+def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target, check=True):
     """The whole-episode figures for shapes the one-launch kernels do not take (LB_GREEDY above 64 cells): the same
-    episode as n placement launches on a state blob, ``active`` selecting one container's blocks."""
+    episode as n placement launches on a state blob, ``active`` selecting one container's blocks.  ``check`` as in
+    episode_scores: raise like the reference (one host sync), or report per container -- NaN ratio where the error
+    word is set, like the one-launch path."""
     from .env import BatchedContainer
     B = st.shape[0]
     env = BatchedContainer(B, container_size, n, reward_type, 'full', packing_strategy=strategy, device=st.device)
@@ -727,7 +729,8 @@ def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target):
         if target is not None:
             act = torch.gather(st[:, -1, :], 1, col.unsqueeze(1)).squeeze(1) == float(target)
         env.add_new_blocks_gather(st, col, active=act, want_feature=False)
-    env.check()
+    if check:
+        env.check()
     cnt = env.counters.to(torch.int64)
     max_h = env.heightmap.reshape(B, -1).max(dim=1).values.to(torch.int64)
     box = max_h * int(np.prod(container_size[:-1]))
@@ -737,6 +740,10 @@ def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target):
     S = nst.double() / count.double()
     live = count > 0
     ratio = torch.where(live, (C + P) + S, torch.zeros_like(C))
+    if not check:                                     # containers that raised an error bit report NaN (episode_finish)
+        err = torch.empty(B, dtype=torch.int32, device=st.device)
+        env._call(_lib.lib().tap_env_errors, _lib.ptr(env._state), _lib.ptr(err))
+        ratio = torch.where(err != 0, torch.full_like(ratio, float('nan')), ratio)
     scores = torch.stack((valid, torch.where(live, box, torch.zeros_like(box)), empty, nst, max_h), 1)
     return ratio, scores
 
@@ -744,7 +751,8 @@ def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target):
 def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, container_size, packing_strategy='LB_GREEDY',
                    target=None, check=True):
     """tools.calc_positions_lb_greedy (tools.py:2393-2449) / tools.calc_positions_mcs (tools.py:3213-3315) for
-    every sample of a batch in one launch: blocks in tour order into an empty container.
+    every sample of a batch in one launch (LB_GREEDY containers above 64 cells: one placement launch per block,
+    _stepped_scores): blocks in tour order into an empty container.
     -> (ratio (B,) float64, scores (B, 5) int64 = valid_size, box_size, empty_size, stable_num, max height).
     ``target`` 0 | 1: only the blocks whose target id (last row of ``static``, the two-container input types) equals
     it; an empty list scores zeros (pack.py:760-769).  ``check``: raise like the reference when a container
@@ -767,7 +775,7 @@ def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, con
     strategy = 'MACS' if mcs else 'LB_GREEDY'
     desc = _lib.make_desc(B, container_size, n, reward_type, 'full', strategy)
     if (not mcs) and (desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))):
-        return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target)
+        return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target, check)
     ratio = torch.empty(B, dtype=torch.float64, device=st.device)
     scores = torch.empty(B, 5, dtype=torch.int64, device=st.device)
     err = torch.empty(B, dtype=torch.int32, device=st.device)

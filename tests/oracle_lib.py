@@ -11,7 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
-_LIB_PATH = os.path.join(ORACLE_DIR, "libtap_oracle.so")
+_LIB_PATH = os.environ.get("TAP_ORACLE_LIB") or os.path.join(ORACLE_DIR, "libtap_oracle.so")   # TAP_ORACLE_LIB: the sanitizer build (oracle/Makefile: check-asan)
 
 LB_GREEDY, MACS, LB = 0, 1, 2
 F_HARD, F_USE_P, F_USE_S, F_MCS_ZERO, F_MCS_TIE = 1, 2, 4, 8, 16
