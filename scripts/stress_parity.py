@@ -63,6 +63,8 @@ for seed in range(int(sys.argv[1])):
         reward = str(rs.choice(["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft", "C+P-mcs-hard"])); strat = "MACS"
         if seed % 25 == 1:                                   # one in five of the family: 17 .. 64 columns (tap_macs_wide.h)
             W = int(np.random.RandomState(5000 + seed).randint(17, 65)); cs[0] = W; hi = int(np.random.RandomState(6000 + seed).randint(4, 12))
+        if seed % 25 == 6:                                   # and one in five above 64 columns (macs_big.hip)
+            W = int(np.random.RandomState(5000 + seed).randint(65, 160)); cs[0] = W; hi = int(np.random.RandomState(6000 + seed).randint(4, 16))
     elif kind == 2:  # LB 3D
         W, L = rs.randint(1, 9), rs.randint(1, 9)
         cs = [int(W), int(L), int(rs.choice([60, 120, 250]))]; n = int(rs.randint(4, 30)); hi = int(rs.randint(2, 8))

@@ -17,6 +17,7 @@ TAP_OK = 0
 TAP_E_INVALID, TAP_E_UNSUPPORTED, TAP_E_HIP, TAP_E_OVERFLOW, TAP_E_NODEVICE, TAP_E_STEPS = -1, -2, -3, -4, -5, -6
 TAP_LB_GREEDY, TAP_MACS, TAP_LB = 0, 1, 2
 TAP_DT_F32, TAP_DT_I32 = 0, 1
+TAP_R_C, TAP_R_CxS, TAP_R_CP, TAP_R_CPxS, TAP_R_CPS, TAP_R_2CPS, TAP_R_CxPxS, TAP_R_CP_HALF = range(8)
 TAP_T_FRESH, TAP_T_RATIO = 1, 2
 TAP_SB_INITIAL_MASK, TAP_SB_CONTINUE = 1, 2
 

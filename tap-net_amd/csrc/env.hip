@@ -166,9 +166,11 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
         if (d->W * d->L > 4096) return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 4096", d->W * d->L);
     } else if (d->strategy == TAP_LB) {                            // one thread per container (lb.hip)
         if (d->W > 248 || (d->D == 3 && d->L > 248)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "legacy LB: side > 248");
+    } else if (tap_is_big_macs(d)) {                               // one thread per container (macs_big.hip)
+        if (d->W > 4096) return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 2D: W = %d columns > 4096", d->W);
     } else {
         if (tap_group_size(d) == 0)
-            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL: W*L = %d cells > 64 lanes per container", d->W * d->L);
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: W*L = %d cells > 64 lanes per container", d->W * d->L);
         if (d->D == 3 && (d->W > 8 || d->L > 8))
             return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: sides above 8 are not supported");
     }
@@ -336,7 +338,7 @@ extern "C" int tap_env_feature(tap_ctx *ctx, const tap_env_desc *d, const void *
     if (!state || !feature_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
-    if (tap_is_big(d) || d->strategy == TAP_LB)
+    if (tap_is_big(d) || tap_is_big_macs(d) || d->strategy == TAP_LB)
         return tap_big_feature(ctx, d, v, feature_out, tap_env_feature_len(d), (hipStream_t)stream);
     TAP_DISPATCH_DG(launch_feature, d, ctx, d, v, feature_out, (hipStream_t)stream);
 }

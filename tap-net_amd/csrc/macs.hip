@@ -154,8 +154,8 @@ int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d)
             return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D supports W, L <= 8 and H <= %d", MACS3_MAX_H);
         return TAP_OK;
     }
-    if (d.W > 64 || d.H > MACS_MAX_H)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS supports W <= 64 and H <= %d", MACS_MAX_H);
+    if (d.W > 4096 || d.H > MACS_MAX_H)
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS supports W <= 4096 and H <= %d", MACS_MAX_H);
     return TAP_OK;
 }
 
@@ -171,6 +171,7 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
         default: return launch_macs3<64>(ctx, a, st);
         }
     }
+    if (a.d.W > 64) return tap_macs_big_step(ctx, a, st);              // one thread per container (macs_big.hip)
     if (a.d.W > 32) return launch_macs_wide<64>(ctx, a, st);
     if (a.d.W > 16) return launch_macs_wide<32>(ctx, a, st);
     return a.d.W <= 8 ? launch_macs<8>(ctx, a, st) : launch_macs<16>(ctx, a, st);

@@ -55,7 +55,7 @@ class BatchedContainer(object):
         tap_transition* / tap_rolling_step take them all the same and run the two launches themselves."""
         d = self.desc
         big = d.strategy == _lib.TAP_LB_GREEDY and (d.W * d.L > 64 or (d.D == 3 and (d.W > 8 or d.L > 8)))
-        wide_macs = d.strategy == _lib.TAP_MACS and d.D == 2 and d.W > 16
+        wide_macs = d.strategy == _lib.TAP_MACS and d.D == 2 and d.W > 16           # above 64 columns: one thread per container
         return not (big or wide_macs or d.strategy == _lib.TAP_LB)
 
     # ---- plumbing ---------------------------------------------------------------------------

@@ -716,7 +716,8 @@ RENDER_FILES = ('ratio', 'valid_size', 'box_size', 'empty_size', 'stable_num', '
 
 
 def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target, check=True):
-    """The whole-episode figures for shapes the one-launch kernels do not take (LB_GREEDY above 64 cells): the same
+    """The whole-episode figures for shapes the one-launch kernels do not take (LB_GREEDY above 64 cells, MACS 2D
+    above 64 columns): the same
     episode as n placement launches on a state blob, ``active`` selecting one container's blocks.  ``check`` as in
     episode_scores: raise like the reference (one host sync), or report per container -- NaN ratio where the error
     word is set, like the one-launch path."""
@@ -739,7 +740,11 @@ def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target, 
     P = valid.double() / (empty + valid).double()
     S = nst.double() / count.double()
     live = count > 0
-    ratio = torch.where(live, (C + P) + S, torch.zeros_like(C))
+    mode = env.desc.ratio_mode if strategy == 'MACS' else _lib.TAP_R_CPS           # tools.py:2442-2445 / :3285-3308
+    by_mode = {_lib.TAP_R_C: lambda: C, _lib.TAP_R_CxS: lambda: C * S, _lib.TAP_R_CP: lambda: C + P,
+               _lib.TAP_R_CPxS: lambda: (C + P) * S, _lib.TAP_R_2CPS: lambda: (2 * C + P) + S,
+               _lib.TAP_R_CxPxS: lambda: (C * P) * S}
+    ratio = torch.where(live, by_mode.get(mode, lambda: (C + P) + S)(), torch.zeros_like(C))
     if not check:                                     # containers that raised an error bit report NaN (episode_finish)
         err = torch.empty(B, dtype=torch.int32, device=st.device)
         env._call(_lib.lib().tap_env_errors, _lib.ptr(env._state), _lib.ptr(err))
@@ -774,7 +779,8 @@ def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, con
                                 "scores)" % (reward_type, 'calc_positions_mcs' if mcs else 'calc_positions_lb_greedy'))
     strategy = 'MACS' if mcs else 'LB_GREEDY'
     desc = _lib.make_desc(B, container_size, n, reward_type, 'full', strategy)
-    if (not mcs) and (desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))):
+    if (desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))) and (not mcs or desc.D == 2):
+        # beyond the whole-episode kernels' container size (LB_GREEDY above 64 cells, MACS 2D above 64 columns)
         return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target, check)
     ratio = torch.empty(B, dtype=torch.float64, device=st.device)
     scores = torch.empty(B, 5, dtype=torch.int64, device=st.device)

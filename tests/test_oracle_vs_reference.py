@@ -18,11 +18,13 @@ def ref():
     return ref_loader.load()
 
 
-def _diff(tools, cs, n, reward, feat, strategy, episodes, seed, lo=1, hi=5):
+def _diff(tools, cs, n, reward, feat, strategy, episodes, seed, lo=1, hi=5, hz=None):
     rng = np.random.RandomState(seed)
     D = len(cs)
     for ep in range(episodes):
         blocks = rng.randint(lo, hi, size=(n, D))
+        if hz is not None:                                   # wide blocks, heights below hz
+            blocks[:, -1] = rng.randint(1, hz, size=n)
         r = tools.Container(list(cs), n, reward, feat, packing_strategy=strategy)
         o = O.Env(cs, n, reward, feat, strategy)
         for t in range(n):
@@ -72,6 +74,10 @@ def test_macs2d(ref, reward):
     _diff(ref[0], [20, 60], 24, reward, "diff", "MACS", 4, 33, 1, 7)
     _diff(ref[0], [40, 40], 30, reward, "full", "MACS", 2, 34, 1, 9)
     _diff(ref[0], [64, 30], 24, reward, "zero", "MACS", 2, 35, 1, 9)
+    # above 64 columns (the kernels' one-thread-per-container form, macs_big.hip), blocks up to 70 wide
+    _diff(ref[0], [100, 40], 30, reward, "diff", "MACS", 2, 36, 1, 14)
+    _diff(ref[0], [70, 60], 16, reward, "full", "MACS", 2, 37, 1, 30, hz=7)
+    _diff(ref[0], [130, 50], 12, reward, "zero", "MACS", 1, 38, 2, 71, hz=6)
 
 
 @pytest.mark.parametrize("reward", ["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft"])
