@@ -5,7 +5,7 @@ update_mask / reward, PACKDataset) backed by hand-written HIP kernels behind the
 include/tapenv.h.  The directory name is not a Python identifier; import it as ``tap_net_amd``
 (the alias module at the repository root) or via importlib.
 """
-from . import _lib, build, datafiles, dist, env, generate, pack, rolling, rollout, synth   # noqa: F401
+from . import _lib, build, datafiles, dist, env, generate, pack, rolling, rollout, synth, tools   # noqa: F401
 from ._lib import TapError, TapOverflowError                   # noqa: F401
 from .env import BatchedContainer, Container                   # noqa: F401
 from .generate import generate_instances                       # noqa: F401

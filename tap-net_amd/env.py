@@ -219,26 +219,155 @@ class BatchedContainer(object):
         self._state.copy_(sd['state'])
 
 
+# ---- lock-step pooling of per-env Containers -------------------------------------------------------------------------
+# model.py:294 builds `batch_size` tools.Container objects and model.py:451-453 calls each of them once per decoding
+# step before it stacks the results (torch.FloatTensor(heightmaps), model.py:454-465); model.py:509-510 does the same
+# with calc_ratio.  With pooling on, the Containers built back to back with the same arguments share ONE
+# BatchedContainer: a member's add_new_block / get_heightmap only records its request and hands back ITS ROW of the
+# step's result array; the call that completes the round (every member has been called once) runs one launch for the
+# whole pool and fills the array in place -- the rows handed out earlier are views of it.  One launch, one host->device
+# and one device->host copy per decoding step instead of batch_size of each, with model.py unchanged.
+# The contract is model.py's own call pattern: read the rows only after the round's last call.  A member called twice
+# within a round, or any attribute / calc_ratio read, completes the round early (the members not yet called just do
+# not step), so nothing is ever left un-run -- but a row read before its round completed holds no data.  Off by
+# default (every Container is then its own one-env launch + sync, correct for any pattern); switch it on with
+# tools.lockstep_containers(True) or TAP_LOCKSTEP_CONTAINERS=1.
+import os as _os
+
+_lockstep = _os.environ.get("TAP_LOCKSTEP_CONTAINERS", "0") not in ("", "0")
+_open_pool = None
+
+
+def lockstep_containers(on=True):
+    """Pool the Containers built from now on (see above) -> the previous setting."""
+    global _lockstep, _open_pool
+    prev, _lockstep, _open_pool = _lockstep, bool(on), None
+    return prev
+
+
+class _Pool(object):
+    def __init__(self, key, args):
+        self.key, self.args = key, args
+        self.members = 0
+        self.env = None                 # built when the first member is used: the pool is sealed then
+
+    def join(self):
+        i = self.members
+        self.members += 1
+        return i
+
+    def seal(self):
+        global _open_pool
+        if self.env is not None:
+            return
+        if _open_pool is self:
+            _open_pool = None
+        (cs, n, reward, hm_type, init_cs, max_h, strategy, device) = self.args
+        B = self.members
+        self.env = BatchedContainer(B, cs, n, reward, hm_type, init_cs, max_h, strategy, device)
+        D = self.env.block_dim
+        self.blocks = np.zeros((B, D), np.float32)
+        self.active = np.zeros(B, np.uint8)
+        self.called = np.zeros(B, bool)
+        self.n_called = 0
+        self.out = None                                          # this round's result rows
+        self.ratios = None
+        self._fshape = tuple(self.env._feature_shape()[1:])
+        if D == 2:
+            self._fshape = self._fshape[:1]                      # (W-1,) / (W,): the facade returns the 1-D map
+        elif hm_type != 'diff':
+            self._fshape = self._fshape[1:]                      # (W, L)
+
+    def request(self, i, block):
+        """member i's call of this round: block = None for get_heightmap (report only)"""
+        self.seal()
+        if self.called[i]:
+            self.flush()                                         # second call within a round: complete it first
+        if self.out is None:
+            self.out = np.empty((self.members,) + self._fshape, np.int64)
+        if block is not None:
+            self.blocks[i] = block
+            self.active[i] = 1
+        self.called[i] = True
+        self.n_called += 1
+        row = self.out[i]
+        if self.n_called == self.members:
+            self.flush()
+        return row
+
+    def flush(self):
+        if self.env is None or self.n_called == 0:
+            return
+        env = self.env
+        feat = env.add_new_blocks(torch.from_numpy(self.blocks), active=torch.from_numpy(self.active))
+        self.out[...] = feat.detach().cpu().numpy().reshape(self.out.shape)
+        env.check()
+        self.active[:] = 0
+        self.called[:] = False
+        self.n_called = 0
+        self.out = None
+        self.ratios = None
+
+    def ratio(self, i):
+        self.seal()
+        self.flush()
+        if self.ratios is None:
+            self.ratios = self.env.calc_ratios64().cpu().numpy()
+        return float(self.ratios[i])
+
+
 class Container(object):
     """Drop-in for ``tools.Container`` (tools.py:3607): one container, numpy in / numpy out, the
-    placement computed by the same HIP kernels (a BatchedContainer with batch_size 1)."""
+    placement computed by the same HIP kernels -- a BatchedContainer of its own (one launch and one sync per call),
+    or, with ``lockstep_containers(True)``, one row of the BatchedContainer it shares with the Containers built
+    beside it (one launch per decoding step for all of them, see above)."""
 
     def __init__(self, container_size, blocks_num, reward_type, heightmap_type='full',
                  initial_container_size=None, max_height=None, packing_strategy='LB_GREEDY',
                  device='cuda'):
-        self._b = BatchedContainer(1, container_size, blocks_num, reward_type, heightmap_type,
-                                   initial_container_size, max_height, packing_strategy, device)
+        global _open_pool
+        self._pool = self._b = None
+        if _lockstep:
+            key = (tuple(int(v) for v in container_size), int(blocks_num), reward_type, heightmap_type,
+                   None if initial_container_size is None else tuple(initial_container_size), max_height, packing_strategy,
+                   str(device))
+            if _open_pool is None or _open_pool.key != key or _open_pool.env is not None:
+                _open_pool = _Pool(key, (list(container_size), blocks_num, reward_type, heightmap_type, initial_container_size,
+                                         max_height, packing_strategy, device))
+            self._pool = _open_pool
+            self._i = self._pool.join()
+            strategy = packing_strategy
+            if reward_type in ('C+P+S-mul-soft', 'C+P+S-mul-hard'):          # tools.py:3617-3620
+                strategy = 'MUL'
+            elif reward_type in ('C+P+S-mcs-soft', 'C+P+S-mcs-hard'):
+                strategy = 'MACS'
+            self.packing_strategy = strategy
+            self.max_height = 2 * int(container_size[0]) if max_height is None else max_height
+            self.block_dim = len(container_size)
+        else:
+            self._b = BatchedContainer(1, container_size, blocks_num, reward_type, heightmap_type,
+                                       initial_container_size, max_height, packing_strategy, device)
+            self._i = 0
+            self.block_dim = self._b.block_dim
+            self.packing_strategy = self._b.packing_strategy
+            self.max_height = self._b.max_height
         self.reward_type = reward_type
-        self.block_dim = self._b.block_dim
         self.blocks_num = int(blocks_num)
         self.container_size = container_size
         self.initial_container_size = initial_container_size
-        self.packing_strategy = self._b.packing_strategy
         self.heightmap_type = heightmap_type
-        self.max_height = self._b.max_height
         self.blocks = []
         self.rotate_state = [False] * self.blocks_num
         self.bounding_box = np.zeros(self.block_dim)
+
+    @property
+    def _env(self):
+        """the BatchedContainer holding this container (a pool's pending round is completed first)"""
+        if self._pool is not None:
+            self._pool.seal()
+            self._pool.flush()
+            return self._pool.env
+        return self._b
 
     def _shape(self, feat):
         a = feat.detach().cpu().numpy().astype(np.int64)
@@ -252,6 +381,8 @@ class Container(object):
             raise IndexError("list assignment index out of range")   # tools.py:3677
         self.rotate_state[n] = is_rotate
         self.blocks.append(np.asarray(block))
+        if self._pool is not None:
+            return self._pool.request(self._i, np.asarray(block, dtype=np.float32).reshape(-1))
         blk = torch.as_tensor(np.asarray(block, dtype=np.float32).reshape(1, -1))
         feat = self._b.add_new_blocks(blk)
         self._b.check()
@@ -260,44 +391,51 @@ class Container(object):
     def get_heightmap(self, is_full=None):
         if is_full is not None:
             return self.heightmap
+        if self._pool is not None:
+            return self._pool.request(self._i, None)
         return self._shape(self._b.get_heightmaps())
 
     def calc_CPS(self):
-        c, p, s = self._b.calc_CPS()[0].tolist()
+        c, p, s = self._env.calc_CPS()[self._i].tolist()
         return c, p, s
 
     def calc_ratio(self):
+        if self._pool is not None:
+            return self._pool.ratio(self._i)
         return float(self._b.calc_ratios64()[0].item())
 
     def clear_container(self):
-        self._b.reset()
+        if self._pool is not None and self._pool.members > 1:
+            raise NotImplementedError("clear_container on one member of a lock-step pool: build new Containers per "
+                                      "episode (as model.py:294 does), or switch pooling off for this use")
+        self._env.reset()
         self.blocks = []
         self.rotate_state = [False] * self.blocks_num
         self.bounding_box = np.zeros(self.block_dim)
 
     @property
     def heightmap(self):
-        return self._b.heightmap[0].cpu().numpy().astype(np.int64)
+        return self._env.heightmap[self._i].cpu().numpy().astype(np.int64)
 
     @property
     def positions(self):
-        return self._b.positions[0].cpu().numpy().astype(np.int64)
+        return self._env.positions[self._i].cpu().numpy().astype(np.int64)
 
     @property
     def stable(self):
-        return [bool(v) for v in self._b.stable[0].tolist()]
+        return [bool(v) for v in self._env.stable[self._i].tolist()]
 
     @property
     def valid_size(self):
-        return int(self._b.counters[0, 0].item())
+        return int(self._env.counters[self._i, 0].item())
 
     @property
     def empty_size(self):
-        return int(self._b.counters[0, 1].item())
+        return int(self._env.counters[self._i, 1].item())
 
     @property
     def current_blocks_num(self):
-        return int(self._b.counters[0, 3].item())
+        return int(self._env.counters[self._i, 3].item())
 
     @property
     def container(self):

@@ -181,6 +181,12 @@ class Env:
             return f.reshape((2, d.W, d.L)) if d.feature == 2 else f.reshape((d.W, d.L))
         return f
 
+    def get_heightmap(self):
+        """Container.get_heightmap (tools.py:3824-3856): the feature of the current state"""
+        feat = np.zeros(max(self.flen, 1), np.int32)
+        lib().orc_env_feature(self._h, _p(feat))
+        return self._shape_feature(feat[:self.flen])
+
     def clear(self):
         lib().orc_env_clear(self._h)
 
