@@ -58,6 +58,11 @@ for seed in range(int(sys.argv[1])):
         if seed % 20 == 0:                                   # one in four of the family: 30 .. 70 small blocks into a tall container --
             r2 = np.random.RandomState(7000 + seed)          # the voxel-identity masks of tap_macs3_place change regime at 32 and 64
             n = int(r2.randint(30, 71)); cs[2] = int(r2.choice([300, 600, 1000])); hi = 3   # placed blocks (narrow -> by_bits -> fallback)
+        if seed % 20 == 10:                                  # and one in four above 64 cells / a side above 8 (macs3_big.hip:
+            r2 = np.random.RandomState(8000 + seed)          # one thread per container, rows as 64-bit masks)
+            W, L = int(r2.randint(2, 24)), int(r2.randint(9, 24))
+            if r2.rand() < 0.5: W, L = L, W
+            cs = [W, L, int(r2.choice([30, 60, 100]))]; n = int(r2.randint(8, 40)); hi = int(min(W, L, r2.randint(3, 9))) + 1
     elif kind == 1:  # MACS 2D
         W = int(rs.randint(2, 14)); cs = [W, int(rs.choice([60, 100, 200]))]; n = int(rs.randint(6, 24)); hi = min(W, 6) + 1
         reward = str(rs.choice(["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft", "C+P-mcs-hard"])); strat = "MACS"

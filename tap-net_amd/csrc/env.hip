@@ -168,11 +168,10 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
         if (d->W > 248 || (d->D == 3 && d->L > 248)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "legacy LB: side > 248");
     } else if (tap_is_big_macs(d)) {                               // one thread per container (macs_big.hip)
         if (d->W > 4096) return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 2D: W = %d columns > 4096", d->W);
-    } else {
-        if (tap_group_size(d) == 0)
-            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: W*L = %d cells > 64 lanes per container", d->W * d->L);
-        if (d->D == 3 && (d->W > 8 || d->L > 8))
-            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: sides above 8 are not supported");
+    } else if (tap_is_big_macs3(d)) {                              // one thread per container (macs3_big.hip)
+        if (d->W > 64 || d->L > 64) return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: side > 64 (rows are 64-bit masks)");
+    } else if (tap_group_size(d) == 0) {
+        return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 64 lanes per container", d->W * d->L);
     }
     if (d->H > 4000 || d->n_max > 4096)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "H or blocks_num too large for the 32-bit sort key");
@@ -338,7 +337,7 @@ extern "C" int tap_env_feature(tap_ctx *ctx, const tap_env_desc *d, const void *
     if (!state || !feature_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
     EnvView v;
     tap_env_layout(d, const_cast<void *>(state), &v);
-    if (tap_is_big(d) || tap_is_big_macs(d) || d->strategy == TAP_LB)
+    if (tap_is_big(d) || tap_is_big_macs(d) || tap_is_big_macs3(d) || d->strategy == TAP_LB)
         return tap_big_feature(ctx, d, v, feature_out, tap_env_feature_len(d), (hipStream_t)stream);
     TAP_DISPATCH_DG(launch_feature, d, ctx, d, v, feature_out, (hipStream_t)stream);
 }

@@ -332,7 +332,7 @@ static int episode_validate(tap_ctx *ctx, const tap_env_desc *d, const char *wha
     if (rc) return rc;
     if (d->strategy == TAP_LB)
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "%s: the legacy 'LB' strategy has no whole-episode form in use (tools.calc_positions_greedy is commented out at pack.py:741)", what);
-    if (tap_is_big(d) || tap_is_big_macs(d))
+    if (tap_is_big(d) || tap_is_big_macs(d) || tap_is_big_macs3(d))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "%s: containers above 64 cells are stepped with tap_env_step_gather", what);
     return TAP_OK;
 }

@@ -150,8 +150,8 @@ template <int G> static int launch_macs3(tap_ctx *ctx, const StepArgs &a, hipStr
 int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d)
 {
     if (d.D == 3) {
-        if (d.W > 8 || d.L > 8 || d.H > MACS3_MAX_H)
-            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D supports W, L <= 8 and H <= %d", MACS3_MAX_H);
+        if (d.W > 64 || d.L > 64 || d.H > MACS3_MAX_H)
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS 3D supports W, L <= 64 and H <= %d", MACS3_MAX_H);
         return TAP_OK;
     }
     if (d.W > 4096 || d.H > MACS_MAX_H)
@@ -164,6 +164,7 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
     int rc = tap_macs_validate(ctx, a.d);
     if (rc) return rc;
     if (a.d.D == 3) {
+        if (tap_is_big_macs3(&a.d)) return tap_macs3_big_step(ctx, a, st);  // one thread per container (macs3_big.hip)
         switch (tap_group_size(&a.d)) {
         case 8: return launch_macs3<8>(ctx, a, st);
         case 16: return launch_macs3<16>(ctx, a, st);

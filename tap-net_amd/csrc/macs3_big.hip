@@ -1,0 +1,90 @@
+// macs3_big.hip -- MACS / MUL 3D (tools.calc_one_position_mcs_3d, tools.py:2751-3165) for containers beyond the
+// lane-per-cell kernel of tap_macs3.h: more than 64 cells or a side above 8 (e.g. --container_width 10 -> 10 x 10 x H,
+// model.py:279).  One thread per container on the same reduced state (height-map, placement history, the free-list
+// bit-grid in `occ`), the algorithm in tap_macs3_big.h; candidate lists live in the blob's scratch section.
+// A correctness path for unusual shapes like big.hip / macs_big.hip.  gfx950 only.
+#include "tap_common.h"
+#include "tap_place.h"
+#include "tap_macs3_big.h"
+
+static_assert(M3B_F_HARD == TAP_F_HARD && M3B_F_USE_P == TAP_F_USE_P && M3B_F_USE_S == TAP_F_USE_S &&
+              M3B_F_ZERO == TAP_F_MCS_ZERO && M3B_F_TIE == TAP_F_MCS_TIE, "flag bits are passed through");
+
+// EMS entries one step can hold (error bit 16 beyond): the level lists contribute up to two per changed (level, row,
+// run), each placed block at most four beside it and its footprint's cells on top
+__host__ __device__ inline int macs3_big_cap(int n_max) { return 128 + 8 * n_max; }
+
+// scratch ints per container: ems[cap] (2 ints each) | lev[cells] | slots[cells] | lvh[n_max + 2] | lvr[n_max + 2]
+size_t tap_macs3_big_scratch_ints(const tap_env_desc *d)
+{
+    return (size_t)2 * macs3_big_cap(d->n_max) + (size_t)2 * d->W * d->L + (size_t)2 * (d->n_max + 2);
+}
+
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32_t *scratch, size_t scratch_ints)
+{
+    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const int B = a.d.B, W = a.d.W, L = a.d.L, H = a.d.H, cells = W * L;
+    if (env >= B) return;
+    int bx, by, bz;
+    if (a.static_) {                                                             // model.py:404-412
+        bool badp;
+        const long p = tap_col((long)a.ptr[env], a.nR, badp);
+        bx = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+        by = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+        bz = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
+    } else if (a.blocks_dtype == TAP_DT_F32) {
+        const float *b = (const float *)a.blocks + (size_t)env * 3;
+        bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];
+    } else {
+        const int32_t *b = (const int32_t *)a.blocks + (size_t)env * 3;
+        bx = b[0]; by = b[1]; bz = b[2];
+    }
+    const bool act = !a.active || a.active[env] != 0;
+    const int4 cv = reinterpret_cast<const int4 *>(a.v.cnt)[env];
+    int cnt[4] = {cv.x, cv.y, cv.z, cv.w};
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt[3] >= a.d.n_max) { err |= 2; do_step = false; }               // tools.py:3677 IndexError
+    // sides larger than the container are rejected as invalid input, as in tap_macs3.h (the reference keeps such a
+    // block in its history at (0,0,0) and its later slices run out of range, tools.py:2858, 2914); footprints above
+    // 8 x 8 are beyond the support mask of the stability test
+    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > L || bx > 8 || by > 8)) { err |= 4; do_step = false; }
+    if (do_step) {
+        const int step = cnt[3], cap = macs3_big_cap(a.d.n_max);
+        int32_t *sc = scratch + (size_t)env * scratch_ints;
+        M3BState s;
+        s.W = W; s.L = L; s.H = H; s.HW = (H + 63) / 64; s.flags = a.d.flags; s.cap = cap; s.step = step;
+        s.hm = a.v.hm + (size_t)env * cells;
+        s.occ = a.v.occ + (size_t)env * cells * s.HW;
+        s.pos = a.v.pos + env; s.blk = a.v.blk + env; s.hs = (size_t)B;
+        s.ems = reinterpret_cast<M3BEms *>(sc);
+        s.lev = sc + 2 * cap;
+        s.slots = s.lev + cells;
+        s.lvh = s.slots + cells;
+        s.lvr = s.lvh + a.d.n_max + 2;
+        const uint32_t *lut = a.lut;
+        const M3BResult r = m3b_place(s, cnt, err, bx, by, bz,
+                                      [lut](int fx, int fy, m3b_u64 eq) -> int { return tap_stable3d_any(lut, fx, fy, eq); });
+        cnt[3] += 1;                                                             // tools.py:3713
+        reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+        a.v.pos[(size_t)(step * 3) * B + env] = r.x;
+        a.v.pos[(size_t)(step * 3 + 1) * B + env] = r.y;
+        a.v.pos[(size_t)(step * 3 + 2) * B + env] = r.z;
+        a.v.stable[(size_t)step * B + env] = (uint8_t)r.stab;
+        a.v.blk[(size_t)(step * 3) * B + env] = bx | (r.placed << 16);          // history of later steps
+        a.v.blk[(size_t)(step * 3 + 1) * B + env] = by;                          // (tools.py:2843-2846), failures too
+        a.v.blk[(size_t)(step * 3 + 2) * B + env] = bz;
+    }
+    if (err) a.v.err[env] |= err;
+}
+
+int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
+{
+    const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
+    if (grid == 0) return TAP_OK;
+    if (!a.v.scratch || !a.v.occ) return tap_fail(ctx, TAP_E_INVALID, "MACS 3D above 64 cells: the state blob has no scratch section");
+    hipLaunchKernelGGL(k_macs3d_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.scratch, tap_macs3_big_scratch_ints(&a.d));
+    TAP_LAUNCH_CHECK(ctx, "k_macs3d_big_step");
+    if (a.feature_out) return tap_big_feature(ctx, &a.d, a.v, a.feature_out, a.flen, st);   // tools.py:3716-3744
+    return TAP_OK;
+}

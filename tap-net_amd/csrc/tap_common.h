@@ -102,7 +102,7 @@ struct EnvView {
     uint8_t *stable;
     int32_t *blk;
     unsigned long long *occ;
-    int32_t *scratch; // LB_GREEDY above 64 cells (big.hip): cells ints per container; MACS 2D above 64 columns (macs_big.hip)
+    int32_t *scratch; // LB_GREEDY above 64 cells (big.hip): cells ints per container; MACS 2D above 64 columns (macs_big.hip); MACS 3D above 64 cells (macs3_big.hip)
     int16_t *vox;     // legacy LB (lb.hip): [B][cells][H] block ids, -1 under covered holes   (tools.py:3630)
     uint8_t *lfs;     //   [B][H*L][W+2] level_free_space lists                                (tools.py:3649-3653)
     uint8_t *lfn;     //   [B][H*L] (list length - 1) mod 256: the zeroed blob is the initial [0] everywhere
@@ -120,6 +120,13 @@ inline bool tap_is_big(const tap_env_desc *d)
 // container with its candidate lists in a scratch section of the blob
 inline bool tap_is_big_macs(const tap_env_desc *d) { return d->strategy == TAP_MACS && d->D == 2 && d->W > 64; }
 size_t tap_macs_big_scratch_ints(const tap_env_desc *d);   // macs_big.hip
+// MACS / MUL 3D containers beyond the lane-per-cell kernel (more than 64 cells or a side above 8): macs3_big.hip, one
+// thread per container on the same state (height-map, history, free-list bit-grid) + candidate lists in the scratch section
+inline bool tap_is_big_macs3(const tap_env_desc *d)
+{
+    return d->strategy == TAP_MACS && d->D == 3 && (d->W * d->L > 64 || d->W > 8 || d->L > 8);
+}
+size_t tap_macs3_big_scratch_ints(const tap_env_desc *d);  // macs3_big.hip
 
 inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
 {
@@ -132,8 +139,9 @@ inline size_t tap_env_layout(const tap_env_desc *d, void *base, EnvView *v)
     size_t o_blk = (d->strategy == TAP_MACS || d->strategy == TAP_LB) ? take(nD * B * 4) : 0;
     size_t o_occ = (d->strategy == TAP_MACS && d->D == 3) ? take(B * cells * 8 * (size_t)((d->H + 63) / 64)) : 0;
     const bool lb = d->strategy == TAP_LB;
-    const bool scr = tap_is_big(d) || tap_is_big_macs(d);
-    size_t o_scr = tap_is_big(d) ? take(B * cells * 4) : tap_is_big_macs(d) ? take(B * tap_macs_big_scratch_ints(d) * 4) : 0;
+    const bool scr = tap_is_big(d) || tap_is_big_macs(d) || tap_is_big_macs3(d);
+    size_t o_scr = tap_is_big(d) ? take(B * cells * 4) : tap_is_big_macs(d) ? take(B * tap_macs_big_scratch_ints(d) * 4)
+                 : tap_is_big_macs3(d) ? take(B * tap_macs3_big_scratch_ints(d) * 4) : 0;
     size_t o_vox = lb ? take(B * cells * (size_t)d->H * 2) : 0;
     size_t o_lfs = lb ? take(B * (size_t)d->H * d->L * (size_t)(d->W + 2)) : 0;
     size_t o_lfn = lb ? take(B * (size_t)d->H * d->L) : 0;
@@ -203,6 +211,7 @@ inline int tap_group_size(const tap_env_desc *d)
 // the same by-products from a launch of their own, for the steps that run as two launches (transition.hip)
 int tap_step_aux_launch(tap_ctx *ctx, const StepArgs &s, hipStream_t st);
 int tap_macs_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st);                                             // macs_big.hip
+int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st);                                            // macs3_big.hip
 int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st);                                      // big.hip
 int tap_big_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, int flen, hipStream_t st);   // big.hip
 

@@ -112,8 +112,8 @@ template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransAr
 
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
 
-// Shapes and strategies whose placement is one THREAD per container (legacy 'LB', LB_GREEDY above 64 cells or a 3D
-// side above 8) or the wide MACS 2D form (17 .. 64 columns): no single kernel carries both halves of the step.  (For
+// Shapes and strategies whose placement is one THREAD per container (legacy 'LB', LB_GREEDY and MACS 3D above 64
+// cells or with a 3D side above 8) or the wide MACS 2D form (17 .. 64 columns): no single kernel carries both halves of the step.  (For
 // wide MACS one was built and measured in round 3 -- tap_macs_wide_wave as the placement waves of a k_transition_macs
 // look-alike: 121 against 97 us per step at W = 20, n = 12, B = 8192, equal at W = 40: the placement is ~100 us of
 // register-heavy work, the stream waves hide nothing and their wave slots cost a quarter of the resident envs.)
@@ -121,7 +121,7 @@ static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransA
 // reset / calc_ratio where the flags ask for them, so a caller drives every shape through one entry point.
 static bool transition_single_kernel(const tap_ctx *ctx, const tap_env_desc *d, int nR)
 {
-    if (d->strategy == TAP_LB || tap_is_big(d) || (d->strategy == TAP_MACS && d->D == 2 && d->W > 16)) return false;
+    if (d->strategy == TAP_LB || tap_is_big(d) || tap_is_big_macs3(d) || (d->strategy == TAP_MACS && d->D == 2 && d->W > 16)) return false;
     if (d->strategy == TAP_MACS) {
         // the MACS placement keeps its lists in LDS: a container too tall (or an episode too long) for one workgroup's
         // LDS (160 KiB on gfx950) next to the stream tiles takes the two launches as well (the stand-alone step runs

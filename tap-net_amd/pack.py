@@ -779,8 +779,8 @@ def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, con
                                 "scores)" % (reward_type, 'calc_positions_mcs' if mcs else 'calc_positions_lb_greedy'))
     strategy = 'MACS' if mcs else 'LB_GREEDY'
     desc = _lib.make_desc(B, container_size, n, reward_type, 'full', strategy)
-    if (desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))) and (not mcs or desc.D == 2):
-        # beyond the whole-episode kernels' container size (LB_GREEDY above 64 cells, MACS 2D above 64 columns)
+    if desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8)):
+        # beyond the whole-episode kernels' container size (above 64 cells -- MACS 2D: 64 columns -- or a 3D side above 8)
         return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target, check)
     ratio = torch.empty(B, dtype=torch.float64, device=st.device)
     scores = torch.empty(B, 5, dtype=torch.int64, device=st.device)

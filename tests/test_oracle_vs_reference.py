@@ -85,6 +85,10 @@ def test_macs3d(ref, reward):
     _diff(ref[0], [5, 5, 50], 10, reward, "diff", "MACS", 12, 41)
     _diff(ref[0], [6, 6, 60], 16, reward, "full", "MACS", 4, 42, 1, 6)
     _diff(ref[0], [4, 7, 40], 12, reward, "diff", "MACS", 4, 43)
+    # above 64 cells / sides above 8 (the kernels' one-thread-per-container form, macs3_big.hip), footprints up to 8 x 8
+    _diff(ref[0], [10, 10, 40], 24, reward, "diff", "MACS", 2, 44, 1, 6)
+    _diff(ref[0], [12, 9, 30], 20, reward, "full", "MACS", 1, 45, 1, 9, hz=5)
+    _diff(ref[0], [9, 16, 30], 20, reward, "zero", "MACS", 1, 46, 2, 8, hz=6)
 
 
 @pytest.mark.parametrize("shape", [(32, 6, 2), (16, 30, 2), (8, 42, 6), (8, 22, 6)])   # 18 .. 126 rows
