@@ -36,7 +36,7 @@ typedef struct tap_ctx tap_ctx;
 enum {
     TAP_OK = 0,
     TAP_E_INVALID = -1,     /* bad argument */
-    TAP_E_UNSUPPORTED = -2, /* valid in the reference, not implemented here (e.g. > 64 cells) */
+    TAP_E_UNSUPPORTED = -2, /* valid in the reference, not implemented here (e.g. > 4096 cells) */
     TAP_E_HIP = -3,         /* HIP runtime error */
     TAP_E_OVERFLOW = -4,    /* a placement reached above H (reference: IndexError tools.py:2109 /
                                silent clipping tools.py:2169) */
@@ -112,9 +112,10 @@ int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream
 
 /* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy
  * 2027-2351, is_stable_2d 839-868, is_stable 710-765; with strategy TAP_MACS ->
- * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 64, H <= 4096;
- * 3D: W, L <= 8, H <= 4096 and block sides <= container sides, else error bit 4); model.py:451-465 is
- * the loop it replaces).
+ * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 4096, H <= 4096 -- lane-per-column
+ * kernels up to 64 columns, one thread per container above; 3D: W, L <= 64, H <= 4096 -- lane-per-cell kernel up to
+ * 64 cells with sides <= 8, one thread per container above (block footprints <= 8 x 8 there); block sides <=
+ * container sides, else error bit 4); model.py:451-465 is the loop it replaces).
  *   blocks      (B, D) TAP_DT_F32 | TAP_DT_I32, one block per env; f32 is truncated like
  *               block.astype(int) (tools.py:3689)
  *   active      (B,) uint8 or NULL: envs with 0 are not stepped and only report their feature
@@ -394,7 +395,7 @@ enum {
  * precedence update and a kernel boundary disappears.  n = blocks in the precedence window
  * (nR = n*R columns); d->n_max may be larger (rolling windows over one long-lived container).
  * One kernel for LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D up to 8 x 8), as long as a workgroup's candidate lists fit the device's LDS (160 KiB per workgroup on gfx950); every other
- * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY above 64 cells, MACS 2D up to 64 columns, a MACS
+ * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY and MACS 3D above 64 cells, MACS 2D above 16 columns, a MACS
  * container whose candidate lists do not fit a fused workgroup's LDS) runs the same step as its two launches behind
  * this entry.  feature_out nullable; ratio_out (B,) f32 required with
  * TAP_T_RATIO. */

@@ -27,9 +27,10 @@ from tap_net_amd import _lib     # noqa: E402
 KINDS = {0: "copy", 1: "copy_nt", 2: "fill", 3: "fill_nt", 4: "read"}
 
 
-def run(kind, nbytes, cold, dev, reps=30):
+def run(kind, nbytes, cold, dev, reps=30, slots=None):
     n = nbytes // 4
-    slots = max(2, int(1.3e9 // nbytes)) if cold else 1
+    if slots is None:
+        slots = max(2, int(1.3e9 // nbytes)) if cold else 1
     slots = min(slots, 64)
     src = [torch.rand(n, device=dev) for _ in range(slots)] if kind in (0, 1, 4) else [None] * slots
     dst = [torch.empty(n, device=dev) for _ in range(slots)] if kind != 4 else [None] * slots
@@ -71,9 +72,23 @@ def run(kind, nbytes, cold, dev, reps=30):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--pingpong-sizes", default="",
+                    help="comma-separated bytes: fill / nontemporal fill alternating between TWO buffers of this size "
+                         "(the bench sweep's `dynamic` ping-pong at large batch: 2.5 GB per buffer at B = 1 M, c2 shape)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rows = []
+    if args.pingpong_sizes:
+        for nbytes in (int(x) for x in args.pingpong_sizes.split(",")):
+            for kind in (2, 3):
+                r = run(kind, nbytes, True, dev, reps=10, slots=2)
+                r["pingpong"] = True
+                rows.append(r)
+                print(json.dumps(r), flush=True)
+        if args.out:
+            with open(args.out, "w") as f:
+                json.dump(dict(device=torch.cuda.get_device_name(0), when=time.strftime("%Y-%m-%d %H:%M:%S"), rows=rows), f, indent=1)
+        return
     for nbytes in (19_660_800, 160_000_000, 1_200_000_000):
         for kind in (0, 1, 2, 3, 4):
             for cold in ((False, True) if nbytes < 1e9 else (False,)):

@@ -716,8 +716,8 @@ RENDER_FILES = ('ratio', 'valid_size', 'box_size', 'empty_size', 'stable_num', '
 
 
 def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target, check=True):
-    """The whole-episode figures for shapes the one-launch kernels do not take (LB_GREEDY above 64 cells, MACS 2D
-    above 64 columns): the same
+    """The whole-episode figures for shapes the one-launch kernels do not take (LB_GREEDY and MACS 3D above 64 cells or
+    with a 3D side above 8, MACS 2D above 64 columns): the same
     episode as n placement launches on a state blob, ``active`` selecting one container's blocks.  ``check`` as in
     episode_scores: raise like the reference (one host sync), or report per container -- NaN ratio where the error
     word is set, like the one-launch path."""

@@ -375,7 +375,10 @@ def _run_rolling_eager(rw, policy, container_width, container_height, reward_typ
     assert rw.is_last_graph()                                    # `win` is the last graph: a whole episode on it
     if win['colsum'] is not None:
         tpack._shadow_put(win['dynamic'], win['colsum'])
-    trans = EnvTransition(win['static'], win['dynamic'], env, bits=win['bits'] if win['bits'] is not None else False)
+    # windows of 22 .. 42 nodes (66 .. 126 rows): the window kernels emit the one-word shadow only, so the last
+    # window's episode builds the two-word shadow from the tensor itself (bits=None) instead of copying fp32 slabs
+    last_bits = win['bits'] if win['bits'] is not None else (None if tpack.bits_supported(3 * child, child * rw.R) else False)
+    trans = EnvTransition(win['static'], win['dynamic'], env, bits=last_bits)
     for t in range(child):
         ptr = policy(step=step, static=trans.static, dynamic=trans.dynamic, current_mask=trans.current_mask,
                      mask=trans.mask, decoder_static=decoder_static, decoder_dynamic=decoder_dynamic).to(torch.int64)
