@@ -12,7 +12,7 @@ TUS="masks transition transition_macs rolling"
 if [ "$1" = build ]; then
   mkdir -p build_prof
   for v in $VARIANTS; do
-    name=${v%%:*}; flags=${v#*:}
+    name=${v%%:*}; flags=${v#*:}; flags=${flags//,/ }     # commas stand for spaces inside one variant's flags
     mkdir -p build_prof/ab_$name
     for tu in $TUS; do
       ( cd tap-net_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed \

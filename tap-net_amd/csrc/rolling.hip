@@ -709,6 +709,9 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
         else if (v == 0) pyset_order(S.lst, child, S.ord, S.tbl, S.tbl + PYSET_CAP);
     }
     tap_wave_lds_sync();
+#ifndef TAP_ROLL_LATEWAIT
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) while only loads are outstanding (see rolling_window_wave)
+#endif
     if (v == 0) {
         stp[0] = e_lo; stp[1] = e_hi; stp[2] = w_lo; stp[3] = w_hi;
         if (a.err_out && (short_window || !a.err_sticky)) a.err_out[inst] = short_window;
@@ -885,6 +888,14 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
         S.ord[__popcll(window & below)] = (unsigned char)v;
     }
     tap_wave_lds_sync();
+    // The node records requested above are consumed by the emission, AFTER the first stores below: on gfx9 one counter
+    // (vmcnt) covers loads and stores, so a wait placed at the records' first use would also wait for every store issued
+    // before it to be ACKNOWLEDGED (the round-3 ISA had five such vmcnt(0) between the state store and the fp32
+    // expansion).  Waiting here, while only loads are outstanding -- they have had the whole set order to arrive --
+    // leaves nothing for the stores to be waited on.
+#ifndef TAP_ROLL_LATEWAIT                                             // (A/B builds: the round-3 placement of the waits)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
+#endif
     if (v == 0) {
         a.state[(size_t)inst * 2] = entered;
         a.state[(size_t)inst * 2 + 1] = window;

@@ -364,8 +364,161 @@ __device__ __forceinline__ void stream_build_bits(const MaskArgs &a, int senv0, 
 
 // BUILD: the words come from the wave's LDS tile (first step, mask_builds_bits) instead of a.bits_in; a
 // compile-time switch so that neither form reads through a generic pointer.
+//
+// Round 4, from the ISA of the round-3 form: (1) its input loads sat behind `cond ? ptr[i] : 0` selects, which the
+// compiler turns into exec-masked regions it will not move loads across -- the shadow words were only requested after
+// `ptr` / row 0 / the old mask had ARRIVED (an s_waitcnt vmcnt(0) between the two groups: two round trips, not one);
+// (2) the expansion loops have run-time trip counts, so at the next use of a loaded register the wait-count pass no
+// longer knows how many stores are outstanding and waits for vmcnt(0) -- the second slab's expansion started only after
+// every store of the first had been ACKNOWLEDGED.  Now every input of both slabs is loaded unconditionally (clamped
+// index, absent inputs read a valid dummy address, values selected afterwards), the wave waits ONCE for all of them,
+// and nothing after that wait reads a register a load is still writing: the stores of both slabs go out back to back.
+__device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v < 6 n (R <= 6 rotations), any v >= 0 otherwise
+{
+#pragma unroll
+    for (int r = 0; r < 5; ++r) v = v >= n ? v - n : v;
+    while (v >= n) v -= n;
+    return v;
+}
+
 template <int NS, int NC, bool BUILD = false>
-__device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
+__device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
+                                                 float *lds = nullptr)
+{
+    typedef unsigned long long u64;
+    if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
+    const int nR = a.nR, C4 = nR >> 2, rows = a.rows, n = a.n;
+    const int rsub = (int)(((unsigned)lane * (unsigned)a.c4_magic) >> 16), c4 = lane - rsub * C4, RP = a.rp;
+    const bool lane_on = rsub < RP;
+    u64 *tile = reinterpret_cast<u64 *>(lds);
+    // a readable, 16-byte aligned address for the inputs a caller may leave out (ptr / static: the initial mask,
+    // model.py:297-307; mask_in: a stepper's first step starts from ones)
+    const void *any = BUILD ? static_cast<const void *>(a.dyn_in) : static_cast<const void *>(a.bits_in);
+    const bool has_ptr = a.ptr != nullptr, has_static = a.static_ != nullptr, has_mask = a.mask_in != nullptr;
+    const int64_t *ptrp = has_ptr ? a.ptr : static_cast<const int64_t *>(any);
+    const float *stp = has_static ? a.static_ : static_cast<const float *>(any);
+    const float *mip = has_mask ? a.mask_in : static_cast<const float *>(any);
+    long praw[NS];
+    float row0[NS][NC], keep[NS][NC];
+    u64 bj[NS][NC];
+    ulonglong2 w[NS][2];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int env = on[k] ? senv0 + k : senv0;       // an idle slab re-reads the first one's inputs
+        praw[k] = ptrp[has_ptr ? env : 0];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = min(lane + 64 * c, nR - 1);
+            row0[k][c] = stp[has_static ? (size_t)env * a.static_rows * nR + j : 0];
+            keep[k][c] = mip[has_mask ? (size_t)env * nR + j : 0];
+        }
+    }
+#ifdef TAP_STREAM_G2          // A/B builds: the shadow words requested only after the small inputs have arrived (round 3's order)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+    if (!BUILD) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int env = on[k] ? senv0 + k : senv0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bj[k][c] = a.bits_in[(size_t)env * nR + min(lane + 64 * c, nR - 1)];
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + c4 * 4);
+            w[k][0] = src[0];
+            w[k][1] = src[1];
+        }
+    }
+    if (BUILD) {
+        stream_build_bits<NS>(a, senv0, lane, on, tile);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) bj[k][c] = tile[(size_t)k * nR + min(lane + 64 * c, nR - 1)];
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(tile + (size_t)k * nR + c4 * 4);
+            w[k][0] = src[0];
+            w[k][1] = src[1];
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every input of both slabs is here
+#ifdef TAP_PROF
+    TL_STAMP(1);
+#endif
+    const u64 nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    int jm[NC];                                                               // this lane's columns mod n (pack.py:314-316 for a column)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) jm[c] = tap_mod_small(min(lane + 64 * c, nR - 1), n);
+    u64 clr[NS];
+    int pm[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const bool valid = on[k] && has_ptr && praw[k] >= 0 && praw[k] < nR;  // no ptr: the initial mask (model.py:297-307)
+        const int p = valid ? (int)praw[k] : 0;
+        float r0 = -1.f;                                                      // pack.py:339 via shuffle; stays -1
+#pragma unroll                                                                        // for an index outside [0, nR)
+        for (int c = 0; c < NC; ++c) {
+            const float t = __shfl(row0[k][c], p & 63);
+            if (valid && has_static && (p >> 6) == c) r0 = t;
+        }
+        const int real = (r0 > -1.f && r0 < (float)rows) ? (int)r0 : -1;     // .long() truncates; a row beyond the tensor clears nothing
+        u64 m = 0;                                                            // pack.py:370-374
+        for (int i = 0; i < a.update_rows; ++i) {
+            const int r = real + n * i;
+            if (real >= 0 && r < rows) m |= 1ull << r;
+        }
+        clr[k] = m;
+        pm[k] = valid ? tap_mod_small(p, n) : -1;                             // pack.py:314-316; -1 matches no column
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        if (!on[k]) continue;
+#ifdef TAP_STREAM_PACE        // A/B builds: a slab's stores acknowledged before the next slab's go out (what round 3 did by accident)
+        if (k > 0) __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
+        const int env = senv0 + k;
+        if (lane_on) {
+            const u64 n0 = w[k][0].x & ~clr[k], n1 = w[k][0].y & ~clr[k], n2 = w[k][1].x & ~clr[k], n3 = w[k][1].y & ~clr[k];
+            if (a.dyn_out) {
+                float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
+                if (rows <= 32) {
+                    // n <= 10 (every BASELINE window): the column words fit 32 bits -- a bit-field extract and a
+                    // convert per element, no half selection
+                    const unsigned m0 = (unsigned)n0, m1 = (unsigned)n1, m2 = (unsigned)n2, m3 = (unsigned)n3;
+                    for (int r = rsub; r < rows; r += RP) {
+                        const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
+                                                     (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
+                        store_stream(&dst[(size_t)r * C4], v, a.wt);
+                    }
+                } else {
+                    for (int r = rsub; r < rows; r += RP) {
+                        const float4 v = make_float4(bit_as_float(n0, r), bit_as_float(n1, r), bit_as_float(n2, r),
+                                                     bit_as_float(n3, r));
+                        store_stream(&dst[(size_t)r * C4], v, a.wt);
+                    }
+                }
+            }
+            if (rsub == 0 && a.bits_out) {
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + (size_t)env * nR + c4 * 4);
+                dst[0] = make_ulonglong2(n0, n1);
+                dst[1] = make_ulonglong2(n2, n3);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int j = lane + 64 * c;
+            if (j >= nR) continue;
+            const u64 nb = bj[k][c] & ~clr[k];
+            const int move = __popcll(nb & nmask), small = n >= 64 ? 0 : __popcll((nb >> n) & nmask);
+            const int large = n >= 32 ? 0 : __popcll((nb >> (2 * n)) & nmask); // rows <= 64
+            const float kp = (jm[c] == pm[k]) ? 0.f : (has_mask ? keep[k][c] : 1.f);   // pack.py:320-321
+            if (a.mask_out) a.mask_out[(size_t)env * nR + j] = kp;
+            if (a.cur_out) a.cur_out[(size_t)env * nR + j] = (small * large + move) != 0 ? 0.f : kp; // :327-329
+        }
+    }
+}
+
+// -DTAP_STREAM_R3: the round-3 form of the step (scripts/ab_transition.sh A/B builds only)
+#ifdef TAP_STREAM_R3
+template <int NS, int NC, bool BUILD = false>
+__device__ __forceinline__ void stream_wave_bits_r3(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
                                                  float *lds = nullptr)
 {
     typedef unsigned long long u64;
@@ -477,6 +630,17 @@ __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, i
             if (a.cur_out) a.cur_out[(size_t)env * nR + j] = (small * large + move) != 0 ? 0.f : kp; // :327-329
         }
     }
+}
+
+#endif
+template <int NS, int NC, bool BUILD = false>
+__device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS], float *lds = nullptr)
+{
+#ifdef TAP_STREAM_R3
+    stream_wave_bits_r3<NS, NC, BUILD>(a, senv0, lane, on, lds);
+#else
+    stream_wave_bits_r4<NS, NC, BUILD>(a, senv0, lane, on, lds);
+#endif
 }
 
 // ---- the bit shadow with TWO words per column: 65 <= rows <= 128 (windows of 22 .. 42 nodes) -------------
