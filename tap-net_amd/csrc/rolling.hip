@@ -913,12 +913,25 @@ __host__ __device__ constexpr bool roll_wide_ok(int N, int child) { return N > 6
 
 // 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
 // were resident, so one workgroup in eight ran as a second round
+// The leading scalar arguments of the window kernels repeat what a window wave needs to ADDRESS its first loads (relation
+// masks, window state, the previous pick): they are preloaded into SGPRs by the dispatcher (-mllvm
+// -amdgpu-kernarg-preload-count, set for this file by the Makefile), so those loads do not wait for a read of the
+// argument block through the scalar cache (as in transition.hip).
+#define ROLL_HOT_PARAMS unsigned long long *h_rel, unsigned long long *h_state, const int64_t *h_remove, int h_B, int h_N
+#define ROLL_HOT_ARGS(r) (r).rel, (r).state, (r).remove_ptr, (r).B, (r).N
+__device__ __forceinline__ RollArgs roll_hot(const RollArgs &k, ROLL_HOT_PARAMS)
+{
+    RollArgs r = k;
+    r.rel = h_rel; r.state = h_state; r.remove_ptr = h_remove; r.B = h_B; r.N = h_N;
+    return r;
+}
+
 template <int D, int CH>
-__global__ void __launch_bounds__(TAP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rolling_window(RollArgs a)
+__global__ void __launch_bounds__(TAP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rolling_window(ROLL_HOT_PARAMS, RollArgs a)
 {
     __shared__ RollLds S[TAP_BLOCK / 64];
     const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
-    rolling_window_wave<D, CH>(a, blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
+    rolling_window_wave<D, CH>(roll_hot(a, h_rel, h_state, h_remove, h_B, h_N), blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
 }
 
 // ---- fused rolling step: add_new_block for the column picked in the CURRENT window (gathered from
@@ -934,24 +947,24 @@ constexpr int ROLL_EPB = 2;   // instances per workgroup of the fused step (2: 3
                               // better than 6-wave ones: 9 x 3 = 27 against 4 x 6 = 24)
 
 template <int D, int G, bool SOFT, int CH>
-__device__ __forceinline__ void rolling_step_body(const RollStepArgs &a);
+__device__ __forceinline__ void rolling_step_body(const RollStepArgs &a, ROLL_HOT_PARAMS);
 
 template <int D, int G, int CH>
 __global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_rolling_step_soft(RollStepArgs a)
+k_rolling_step_soft(ROLL_HOT_PARAMS, RollStepArgs a)
 {
-    rolling_step_body<D, G, true, CH>(a);
+    rolling_step_body<D, G, true, CH>(a, h_rel, h_state, h_remove, h_B, h_N);
 }
 
 template <int D, int G, int CH>
 __global__ void __launch_bounds__((64 * (ROLL_EPB + ROLL_EPB * G / 64 + (ROLL_EPB * G % 64 ? 1 : 0)))) __attribute__((amdgpu_waves_per_eu(7, 8)))
-k_rolling_step(RollStepArgs a)
+k_rolling_step(ROLL_HOT_PARAMS, RollStepArgs a)
 {
-    rolling_step_body<D, G, false, CH>(a);
+    rolling_step_body<D, G, false, CH>(a, h_rel, h_state, h_remove, h_B, h_N);
 }
 
 template <int D, int G, bool SOFT, int CH>
-__device__ __forceinline__ void rolling_step_body(const RollStepArgs &a)
+__device__ __forceinline__ void rolling_step_body(const RollStepArgs &a, ROLL_HOT_PARAMS)
 {
     constexpr int EPB = ROLL_EPB;                           // instances per workgroup
     constexpr int ENV_WAVES = (EPB * G + 63) / 64;
@@ -968,7 +981,7 @@ __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a)
         tap_lb_place_wave<D, G, !SOFT>(a.s, 0, nullptr, env, cell, lane, s_old + (tid - cell), s_new + (tid - cell));
         return;
     }
-    rolling_window_wave<D, CH>(a.r, base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
+    rolling_window_wave<D, CH>(roll_hot(a.r, h_rel, h_state, h_remove, h_B, h_N), base + (wave - ENV_WAVES), lane, S[wave - ENV_WAVES]);
 }
 
 // ---- more than 64 blocks per instance ------------------------------------------------------------------------
@@ -1236,8 +1249,8 @@ static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, con
     const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
     if (grid == 0) return TAP_OK;
     if (roll_wide_ok(N, child)) {                                     // 65 .. 128 blocks: one wavefront per instance
-        if (D == 2) hipLaunchKernelGGL((k_rolling_window<2, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_rolling_window<3, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        if (D == 2) hipLaunchKernelGGL((k_rolling_window<2, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
+        else hipLaunchKernelGGL((k_rolling_window<3, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
         TAP_LAUNCH_CHECK(ctx, "k_rolling_window(wide)");
         return TAP_OK;
     }
@@ -1250,11 +1263,11 @@ static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, con
     }
     const bool fast = roll_fast_ok(D, child);
     if (D == 2) {
-        if (fast) hipLaunchKernelGGL((k_rolling_window<2, 10>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_rolling_window<2, 0>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        if (fast) hipLaunchKernelGGL((k_rolling_window<2, 10>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
+        else hipLaunchKernelGGL((k_rolling_window<2, 0>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
     } else {
-        if (fast) hipLaunchKernelGGL((k_rolling_window<3, 10>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((k_rolling_window<3, 0>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        if (fast) hipLaunchKernelGGL((k_rolling_window<3, 10>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
+        else hipLaunchKernelGGL((k_rolling_window<3, 0>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
     }
     TAP_LAUNCH_CHECK(ctx, "k_rolling_window");
     return TAP_OK;
@@ -1269,13 +1282,13 @@ template <int D, int G> static int launch_rolling_step(tap_ctx *ctx, const RollS
     if (a.r.N > 64) {
         // (soft rewards too: the soft-only kernel's 64-register cap costs the two-word window code 20 spilled registers
         //  and 24.6 against 21.1 us per step at N = 100, B = 8192; this one is held to 72)
-        hipLaunchKernelGGL((k_rolling_step<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, a);
+        hipLaunchKernelGGL((k_rolling_step<D, G, ROLL_CH_WIDE>), dim3(grid), dim3(THREADS), 0, st, ROLL_HOT_ARGS(a.r), a);
     } else if (roll_fast_ok(D, a.r.child)) {
-        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, a);
+        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, ROLL_HOT_ARGS(a.r), a);
+        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 10>), dim3(grid), dim3(THREADS), 0, st, ROLL_HOT_ARGS(a.r), a);
     } else {
-        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 0>), dim3(grid), dim3(THREADS), 0, st, a);
-        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 0>), dim3(grid), dim3(THREADS), 0, st, a);
+        if (hard) hipLaunchKernelGGL((k_rolling_step<D, G, 0>), dim3(grid), dim3(THREADS), 0, st, ROLL_HOT_ARGS(a.r), a);
+        else hipLaunchKernelGGL((k_rolling_step_soft<D, G, 0>), dim3(grid), dim3(THREADS), 0, st, ROLL_HOT_ARGS(a.r), a);
     }
     TAP_LAUNCH_CHECK(ctx, "k_rolling_step");
     return TAP_OK;

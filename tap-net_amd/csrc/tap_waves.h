@@ -19,31 +19,35 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
     const bool fresh = flags & TAP_T_FRESH;
     const int B = s.d.B;
     const bool ev = env < B, incell = cell < cells;
-    int hm = 0, cv = 0, dims[3] = {1, 1, 1};
-    if (ev) {
-        if (!fresh) {
-            if (incell) hm = s.v.hm[(size_t)env * cells + cell];
-            if (cell < 4) cv = s.v.cnt[(size_t)env * 4 + cell];
+    // Every load is unconditional on a clamped address (an exec-masked `cond ? p[i] : 0` keeps the compiler from
+    // moving loads across it) and `ptr` -- the head of the step's only dependent chain, ptr -> static[ptr] -- goes
+    // out first; in the fused kernels its address comes from preloaded kernel arguments (transition.hip).
+    const int envc = ev ? env : 0;
+    long praw = 0;
+    if (s.static_) praw = (long)s.ptr[envc];
+    const int hm_l = s.v.hm[(size_t)envc * cells + min(cell, cells - 1)];
+    const int cv_l = s.v.cnt[(size_t)envc * 4 + (cell & 3)];
+    unsigned char act_l = 1;
+    if (s.active) act_l = s.active[envc];
+    const int hm0 = (ev && !fresh && incell) ? hm_l : 0;
+    const int cv = (ev && !fresh && cell < 4) ? cv_l : 0;
+    int hm = hm0, dims[3] = {1, 1, 1};
+    float fv[3] = {0.f, 0.f, 0.f};   // the gathered sides as floats: decoder_static, written with the step's other results
+    if (s.static_) { // gather of model.py:404-412
+        bool badp;
+        const long p = tap_col(praw, s.nR, badp);
+        for (int k = 0; k < D; ++k) { // unconditional load of a valid column, then the select
+            const float v = s.static_[((size_t)envc * s.static_rows + 1 + k) * s.nR + p];
+            dims[k] = !ev ? 1 : badp ? 0 : (int)v;
+            fv[k] = badp ? 0.f : v;
         }
-        if (s.static_) { // gather of model.py:404-412
-            bool badp;
-            const long praw = (long)s.ptr[env];
-            const long p = tap_col(praw, s.nR, badp);
-            float fv[3];
-            for (int k = 0; k < D; ++k) { // unconditional load of a valid column, then the select
-                const float v = s.static_[((size_t)env * s.static_rows + 1 + k) * s.nR + p];
-                dims[k] = badp ? 0 : (int)v;
-                fv[k] = badp ? 0.f : v;
-            }
-            if (cell == 0) tap_step_aux(s, env, D, fv, praw);
-        } else if (s.blocks_dtype == TAP_DT_F32) { // block.astype(int), tools.py:3689
-            for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)s.blocks)[(size_t)env * D + k];
-        } else {
-            for (int k = 0; k < D; ++k) dims[k] = ((const int32_t *)s.blocks)[(size_t)env * D + k];
-        }
+    } else if (s.blocks_dtype == TAP_DT_F32) { // block.astype(int), tools.py:3689
+        for (int k = 0; k < D; ++k) { const float v = ((const float *)s.blocks)[(size_t)envc * D + k]; dims[k] = ev ? (int)v : 1; }
+    } else {
+        for (int k = 0; k < D; ++k) { const int v = ((const int32_t *)s.blocks)[(size_t)envc * D + k]; dims[k] = ev ? v : 1; }
     }
     // `active` = 0: the 'mul' input types' idle container -- untouched, only reports its feature
-    const bool act = ev && (!s.active || s.active[env] != 0);
+    const bool act = ev && act_l != 0;
     const int gl0 = lane - cell;
     Counters cnt = {__shfl(cv, gl0), __shfl(cv, gl0 + 1), __shfl(cv, gl0 + 2), __shfl(cv, gl0 + 3)};
     const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
@@ -70,6 +74,7 @@ __device__ __forceinline__ void tap_lb_place_wave(const StepArgs &s, int flags, 
             tap_write_feature<D, G>(s.d.feature, W, L, g_new, cell, hm,
                                     s.feature_out + (size_t)env * s.flen);
         if (cell == 0) {
+            if (s.static_) tap_step_aux(s, env, D, fv, praw);   // after the placement: no load of this wave waits behind these stores
             if (do_step || fresh)
                 reinterpret_cast<int4 *>(s.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
             if (do_step) {

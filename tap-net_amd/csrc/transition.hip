@@ -63,7 +63,9 @@ k_transition(const int64_t *h_ptr, const float *h_static, const float *h_mask_in
     __builtin_amdgcn_s_setprio(2);
     const int cell = tid % G;
     TL_STAMP(0);
-    tap_lb_place_wave<D, G>(a.s, a.flags, a.ratio_out, env_base + tid / G, cell, lane,
+    StepArgs sa = a.s;       // the gather's source is the update's: ptr, static and their sizes are already in SGPRs
+    sa.ptr = h_ptr; sa.static_ = h_static; sa.nR = h_nR; sa.static_rows = h_static_rows; sa.d.B = h_B;
+    tap_lb_place_wave<D, G>(sa, a.flags, a.ratio_out, env_base + tid / G, cell, lane,
                             s_old + (tid - cell), s_new + (tid - cell));
     TL_WAIT_VM();
     TL_STAMP(3);
