@@ -524,8 +524,9 @@ int tap_roller_steps_done(const tap_roller *r);
 
 /* Bandwidth calibration in the hot kernels' own access shape (16 bytes per lane, a wavefront covers 1 KiB): SURVEY
  * 8(d) asks for the HBM peak to be confirmed on the box.  kind 0: dst = src (plain stores), 1: the same with
- * nontemporal stores, 2: fill dst (plain), 3: fill dst (nontemporal), 4: read src only.  bytes % 16 == 0, 16-byte
- * aligned buffers.  scripts/calibrate_bw.py times these; nothing on the hot path calls them. */
+ * nontemporal stores, 2: fill dst (plain), 3: fill dst (nontemporal), 4: read src only, 5: fill with write-through
+ * (sc0 sc1) stores, 6 / 7: the same in the bit-shadow expansion's store shape at c2 and as 4 800 linear bytes per wave
+ * (bytes % 19200 == 0).  bytes % 16 == 0, 16-byte aligned buffers.  scripts/calibrate_bw.py times these; nothing on the hot path calls them. */
 int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, size_t bytes, void *stream);
 
 #ifdef __cplusplus

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../tap-net_amd/csrc"
 mkdir -p ../../build_prof
 for v in PROF PROF_SWITCH; do
   ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed -fno-fast-math \
-      -ffp-contract=off -I../../include -I. -DTAP_$v -c transition.hip -o ../../build_prof/transition_$v.o && \
+      -ffp-contract=off -mllvm -amdgpu-kernarg-preload-count=12 -I../../include -I. -DTAP_$v -c transition.hip -o ../../build_prof/transition_$v.o && \
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared $(ls build/*.o | grep -v /transition.o) ../../build_prof/transition_$v.o \
       -o ../../build_prof/libtapenv_$v.so ) &
 done

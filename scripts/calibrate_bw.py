@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import tap_net_amd as T          # noqa: E402
 from tap_net_amd import _lib     # noqa: E402
 
-KINDS = {0: "copy", 1: "copy_nt", 2: "fill", 3: "fill_nt", 4: "read"}
+KINDS = {0: "copy", 1: "copy_nt", 2: "fill", 3: "fill_nt", 4: "read", 5: "fill_wt", 6: "fill_wt_slab_shape", 7: "fill_wt_wave_linear"}
 
 
 def run(kind, nbytes, cold, dev, reps=30, slots=None):
@@ -75,9 +75,22 @@ def main():
     ap.add_argument("--pingpong-sizes", default="",
                     help="comma-separated bytes: fill / nontemporal fill alternating between TWO buffers of this size "
                          "(the bench sweep's `dynamic` ping-pong at large batch: 2.5 GB per buffer at B = 1 M, c2 shape)")
+    ap.add_argument("--store-shapes", action="store_true",
+                    help="19.66 MB (the c2 step's tensor): linear fill with plain / nontemporal / write-through stores against "
+                         "the bit-shadow expansion's own store shape (kinds 6, 7 of tap_bw_probe)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     rows = []
+    if args.store_shapes:
+        for kind in (2, 3, 5, 6, 7):
+            for cold in (False, True):
+                r = run(kind, 19_660_800, cold, dev)
+                rows.append(r)
+                print(json.dumps(r), flush=True)
+        if args.out:
+            with open(args.out, "w") as f:
+                json.dump(dict(device=torch.cuda.get_device_name(0), when=time.strftime("%Y-%m-%d %H:%M:%S"), rows=rows), f, indent=1)
+        return
     if args.pingpong_sizes:
         for nbytes in (int(x) for x in args.pingpong_sizes.split(",")):
             for kind in (2, 3):

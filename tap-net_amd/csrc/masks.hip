@@ -64,18 +64,19 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_dyn_bits(int B, int nR, int rows,
 // MODE: 0 = fp32 copy with the column-sum shadow (or the generic path), 1 = bit shadow, 2 = first step;
 // 3 / 4 = the same two on the two-word shadow (65 .. 128 rows)
 template <int NC, int MODE>
-__global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(MaskArgs a)
+__global__ void __launch_bounds__(TAP_BLOCK) k_mask_step(TAP_MASK_HOT_PARAMS, MaskArgs ka)
 {
     extern __shared__ float mask_lds[];
     const int wave = threadIdx.x / WAVE;
     const int env = blockIdx.x * ENVS_PER_BLOCK + wave;
     const int lane = threadIdx.x % WAVE;
-    if (env >= a.B) return;
+    if (env >= h_B) return;
+    const MaskArgs a = tap_mask_hot(ka, MODE == 1 || MODE == 3, TAP_MASK_HOT_NAMES);
     if (NC > 0) {
         const bool on[1] = {true};
         if (MODE == 3) stream_wave_bits2<(NC > 0 ? NC : 1), false>(a, env, lane, nullptr);
         else if (MODE == 4) stream_wave_bits2<(NC > 0 ? NC : 1), true>(a, env, lane, mask_lds + (size_t)wave * 4 * a.nR);
-        else if (MODE == 1) stream_wave_bits<1, (NC > 0 ? NC : 1), false>(a, env, lane, on);
+        else if (MODE == 1) stream_wave_bits<1, (NC > 0 ? NC : 1), false>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         else if (MODE == 2) stream_wave_bits<1, (NC > 0 ? NC : 1), true>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         else stream_wave_fast<1, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(a, env, lane, on, mask_lds + (size_t)wave * 3 * a.nR);
         return;
@@ -108,7 +109,7 @@ static int launch_mask_step(tap_ctx *ctx, const MaskArgs &a, hipStream_t st)
     const bool wide = (a.bits_in || mask_builds_bits(a)) && a.rows > 64;     // two words per column
     const size_t lds = (size_t)ENVS_PER_BLOCK * (wide ? 4 : 3) * a.nR * sizeof(float);
     const int mode = (a.bits_in ? 1 : mask_builds_bits(a) ? 2 : 0) + (wide ? 2 : 0);
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_mask_step<NC_, M_>), dim3(grid), dim3(TAP_BLOCK), LDS_, st, a)
+#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_mask_step<NC_, M_>), dim3(grid), dim3(TAP_BLOCK), LDS_, st, TAP_MASK_HOT_ARGS(a), a)
 #define TAP_LAUNCH_M(NC_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, lds); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, lds); else if (mode == 3) TAP_LAUNCH_T(NC_, 3, lds); else if (mode == 4) TAP_LAUNCH_T(NC_, 4, lds); else TAP_LAUNCH_T(NC_, 0, lds); } while (0)
     switch (mask_fast_path_cols(a)) {
     case 1: TAP_LAUNCH_M(1); break;

@@ -43,11 +43,51 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe(v4f *__restrict__ dst, c
     }
 }
 
+// kinds 5 .. 7 (round 4): the fused step's own stores, to tell what its access SHAPE costs at the BASELINE batch.
+//   5  the linear fill of kind 2 with write-through (sc0 sc1) stores
+//   6  the bit-shadow expansion's shape at c2 (nR = 20, 30 rows: slabs of 2 400 B, not a multiple of a 128-byte line):
+//      a 4-wave workgroup owns 8 consecutive slabs, a wave two of them; lane (rsub, c4) = (lane / 5, lane % 5) of 60
+//      writes the float4 of rows rsub, rsub + 12, rsub + 24 -- store instructions of 960 / 960 / 480 contiguous bytes
+//   7  the same 4 800 bytes per wave written linearly: float4 i * 64 + lane, five instructions of 1 024 ... 704 bytes
+template <int KIND>
+__global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_slab(v4f *__restrict__ dst, size_t n_wg)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float f = (float)(lane & 1);
+    const v4f v = {f, 0.f, f, 1.f};
+    v4f *base = dst + ((size_t)blockIdx.x * 8 + wave * 2) * 150;        // 150 float4 per slab
+    if (KIND == 6) {
+        const int rsub = lane / 5, c4 = lane - rsub * 5;
+        if (rsub < 12)
+            for (int k = 0; k < 2; ++k)
+                for (int r = rsub; r < 30; r += 12)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + k * 150 + r * 5 + c4), "v"(v) : "memory");
+    } else {
+        for (int q = lane; q < 300; q += 64)
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + q), "v"(v) : "memory");
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_wt(v4f *__restrict__ dst, size_t n4)
+{
+    const size_t base = ((size_t)blockIdx.x * PROBE_UNROLL) * TAP_BLOCK + threadIdx.x;
+    const float f = (float)(threadIdx.x & 1);
+    const v4f v = {f, 0.f, f, 1.f};
+#pragma unroll
+    for (int u = 0; u < PROBE_UNROLL; ++u) {
+        const size_t i = base + (size_t)u * TAP_BLOCK;
+        if (i < n4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst + i), "v"(v) : "memory");
+    }
+}
+
 extern "C" int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, size_t bytes, void *stream)
 {
     if (!ctx) return TAP_E_INVALID;
-    if (kind < 0 || kind > 4 || bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16)
-        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kind 0..4, 16-byte aligned buffers and sizes");
+    if (kind < 0 || kind > 7 || bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16)
+        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kind 0..7, 16-byte aligned buffers and sizes");
+    if (kind >= 6 && bytes % 19200)
+        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kinds 6 / 7 write whole workgroups of 8 slabs x 2400 bytes");
     if ((kind != 4 && !dst) || ((kind == 0 || kind == 1 || kind == 4) && !src))
         return tap_fail(ctx, TAP_E_INVALID, "bw_probe: null buffer");
     const size_t n4 = bytes / 16;
@@ -58,6 +98,14 @@ extern "C" int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, 
     v4f *d = static_cast<v4f *>(dst);
     const v4f *s = static_cast<const v4f *>(src);
     float *sink = reinterpret_cast<float *>(ctx->chk);
+    if (kind >= 5) {
+        if (!dst) return tap_fail(ctx, TAP_E_INVALID, "bw_probe: null buffer");
+        if (kind == 5) hipLaunchKernelGGL(k_bw_probe_wt<5>, grid, dim3(TAP_BLOCK), 0, st, d, n4);
+        else if (kind == 6) hipLaunchKernelGGL(k_bw_probe_slab<6>, dim3((unsigned)(bytes / 19200)), dim3(TAP_BLOCK), 0, st, d, bytes / 19200);
+        else hipLaunchKernelGGL(k_bw_probe_slab<7>, dim3((unsigned)(bytes / 19200)), dim3(TAP_BLOCK), 0, st, d, bytes / 19200);
+        TAP_LAUNCH_CHECK(ctx, "k_bw_probe");
+        return TAP_OK;
+    }
     switch (kind) {
     case 0: hipLaunchKernelGGL(k_bw_probe<0>, grid, dim3(TAP_BLOCK), 0, st, d, s, n4, sink); break;
     case 1: hipLaunchKernelGGL(k_bw_probe<1>, grid, dim3(TAP_BLOCK), 0, st, d, s, n4, sink); break;

@@ -46,6 +46,29 @@ inline MaskArgs mask_finish(MaskArgs a)
 
 __host__ __device__ __forceinline__ bool mask_builds_bits(const MaskArgs &a) { return !a.bits_in && a.bits_out && a.dyn_in; }
 
+// Kernels that run a stream wave take, AHEAD of their argument block, the fields a wave needs to ADDRESS its input loads
+// (h_src = the shadow words when the step reads them, the fp32 tensor otherwise): leading scalar kernel arguments are
+// preloaded into SGPRs by the dispatcher (-mllvm -amdgpu-kernarg-preload-count, gfx940+; set per file in the Makefile),
+// so the loads go out without the dependent scalar-cache round trips a read of the block costs at the start of every
+// wave (measured on the fused step, round 4: c2 1 214 -> 1 282 M env-steps/s, c3 490 -> 523 M).
+#define TAP_MASK_HOT_PARAMS const int64_t *h_ptr, const float *h_static, const float *h_mask_in, const void *h_src, int h_B, \
+                            int h_nR, int h_static_rows, int h_c4_magic
+#define TAP_MASK_HOT_NAMES h_ptr, h_static, h_mask_in, h_src, h_B, h_nR, h_static_rows, h_c4_magic
+#define TAP_MASK_HOT_ARGS(m) (m).ptr, (m).static_, (m).mask_in,                                                              \
+        ((m).bits_in ? static_cast<const void *>((m).bits_in) : static_cast<const void *>((m).dyn_in)), (m).B, (m).nR,       \
+        (m).static_rows, (m).c4_magic
+// src_is_bits: compile-time in the callers (MODE == 1 / 3)
+__device__ __forceinline__ MaskArgs tap_mask_hot(const MaskArgs &k, bool src_is_bits, TAP_MASK_HOT_PARAMS)
+{
+    MaskArgs m = k;
+    m.ptr = h_ptr; m.static_ = h_static; m.mask_in = h_mask_in;
+    m.B = h_B; m.nR = h_nR; m.static_rows = h_static_rows; m.c4_magic = h_c4_magic;
+    if (src_is_bits) m.bits_in = static_cast<const unsigned long long *>(h_src);
+    else m.dyn_in = static_cast<const float *>(h_src);
+    return m;
+}
+
+
 // -DTAP_PROF (scripts/decompose_step.py): a timeline of the fused step.  Every wave of the first TAP_PROF_WGS workgroups
 // records the constant-rate 100 MHz clock (s_memrealtime: comparable across CUs) at four points -- stream waves: entry,
 // first store (all inputs have arrived), last store issued, stores acknowledged; placement waves: entry, state + block
@@ -381,6 +404,13 @@ __device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v 
     return v;
 }
 
+// (Round 4, measured and dropped: the fp32 tensor expanded LINEARLY over a wave's slabs -- float4 number i * 64 + lane of
+//  the wave's contiguous region, the cleared column words fetched from a wave-private LDS tile -- so that every store
+//  instruction covers 1 KiB of whole 128-byte lines instead of the 960 / 960 / 480-byte pieces of the (rsub, c4) mapping.
+//  The bare store shapes say it should pay (tap_bw_probe kinds 6 / 7 at 19.66 MB: 4.51 against 4.35 us on a
+//  cache-resident buffer, 6.14 against 4.02 us on fresh ones, profiles/r04_bw_store_shapes.json); the kernel did not
+//  agree: c2 1 295 -> 1 268 M env-steps/s, c3 520 -> 478 M, cold passes 1 009 -> 992 M, and 10-15 % slower from
+//  B = 128 k up -- the LDS read and the index arithmetic in front of every store cost more than the half lines.)
 template <int NS, int NC, bool BUILD = false>
 __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
                                                  float *lds = nullptr)

@@ -27,14 +27,10 @@
 #include "tap_transition.h"
 #include "tap_waves.h"
 
-// The first eight arguments repeat what a stream wave needs to ADDRESS its input loads (h_src = the shadow words, or
-// the fp32 tensor in the copy / first-step forms): leading scalar kernel arguments are preloaded into SGPRs by the
-// dispatcher (-mllvm -amdgpu-kernarg-preload-count, gfx940+; the Makefile sets it for this file), so the loads go out
-// without the two dependent scalar-cache round trips a read of `a.m` costs at the start of every wave.
+// (TAP_MASK_HOT_PARAMS, tap_masks.h: the load addresses of the stream waves -- and of the placement waves' gather, which
+//  reads the same `ptr` and `static` -- arrive in SGPRs with the wave)
 template <int D, int G, int NC, int SW, int MODE>
-__global__ void __launch_bounds__((TransGeom<G, SW>::THREADS))
-k_transition(const int64_t *h_ptr, const float *h_static, const float *h_mask_in, const void *h_src, int h_B, int h_nR,
-             int h_static_rows, int h_c4_magic, TransArgs a)
+__global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TAP_MASK_HOT_PARAMS, TransArgs a)
 {
     using Geo = TransGeom<G, SW>;
     constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
@@ -49,11 +45,7 @@ k_transition(const int64_t *h_ptr, const float *h_static, const float *h_mask_in
     if (wave >= ENV_WAVES ? (a.flags & TAP_T_PROF_NOSTREAM) : (a.flags & TAP_T_PROF_NOPLACE)) return;
 #endif
     if (wave >= ENV_WAVES) {
-        MaskArgs m = a.m;
-        m.ptr = h_ptr; m.static_ = h_static; m.mask_in = h_mask_in;
-        m.B = h_B; m.nR = h_nR; m.static_rows = h_static_rows; m.c4_magic = h_c4_magic;
-        if (MODE == 1) m.bits_in = static_cast<const unsigned long long *>(h_src);
-        else m.dyn_in = static_cast<const float *>(h_src);
+        const MaskArgs m = tap_mask_hot(a.m, MODE == 1, TAP_MASK_HOT_NAMES);
         trans_stream_wave<SPW, NC, MODE>(m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * h_nR);
         return;
@@ -101,9 +93,7 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, a.m.ptr, \
-        a.m.static_, a.m.mask_in, (M_) == 1 ? static_cast<const void *>(a.m.bits_in) : static_cast<const void *>(a.m.dyn_in), a.m.B,        \
-        a.m.nR, a.m.static_rows, a.m.c4_magic, a)
+#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, TAP_MASK_HOT_ARGS(a.m), a)
 #define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
