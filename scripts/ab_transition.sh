@@ -1,13 +1,15 @@
 #!/bin/bash
-# A/B builds of the streaming kernels (masks.hip, transition.hip, transition_macs.hip, rolling.hip): store flavour of
-# the fp32 expansion (TAP_STORE_MODE, tap_masks.h) and stream waves per
-# workgroup (TAP_TRANS_SW).  Build here (no GPU needed), run on the GPU box:
+# A/B builds of the streaming kernels (masks.hip, transition.hip, transition_macs.hip, rolling.hip): the round-3 form of
+# the stream wave (TAP_STREAM_R3), its load order (TAP_STREAM_G2) and store pacing (TAP_STREAM_PACE), the rolling waves'
+# late waits (TAP_ROLL_LATEWAIT), the store flavour of the fp32 expansion (TAP_STORE_MODE, tap_masks.h), stream waves
+# per workgroup (TAP_TRANS_SW), and the kernarg preload (a variant whose flags contain NOPRELOAD is built without the
+# Makefile's -amdgpu-kernarg-preload-count).  Build here (no GPU needed), run on the GPU box:
 #   scripts/ab_transition.sh build                -> build_prof/libtapenv_ab_<name>.so
 #   scripts/ab_transition.sh run "c2 c3 ..."      -> one bench line per variant and config (value, kernel_us)
 # AB_VARIANTS="name:flags ..." overrides the list.
 set -e
 cd "$(dirname "$0")/.."
-VARIANTS=${AB_VARIANTS:-"base: nt:-DTAP_STORE_MODE=0 sc1:-DTAP_STORE_MODE=1 plain:-DTAP_STORE_MODE=4"}
+VARIANTS=${AB_VARIANTS:-"base: nopreload:-DNOPRELOAD r3:-DTAP_STREAM_R3 r3nopreload:-DTAP_STREAM_R3,-DNOPRELOAD g2:-DTAP_STREAM_G2 pace:-DTAP_STREAM_PACE"}
 TUS="masks transition transition_macs rolling"
 if [ "$1" = build ]; then
   mkdir -p build_prof
@@ -15,8 +17,10 @@ if [ "$1" = build ]; then
     name=${v%%:*}; flags=${v#*:}; flags=${flags//,/ }     # commas stand for spaces inside one variant's flags
     mkdir -p build_prof/ab_$name
     for tu in $TUS; do
+      pl=""                                               # the Makefile's per-file kernarg preload counts
+      case "$flags" in *NOPRELOAD*) ;; *) case $tu in transition|masks) pl="-mllvm -amdgpu-kernarg-preload-count=12";; rolling) pl="-mllvm -amdgpu-kernarg-preload-count=8";; esac;; esac
       ( cd tap-net_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function -Wno-pass-failed \
-          -fno-fast-math -ffp-contract=off -I../../include -I. $flags -c $tu.hip -o ../../build_prof/ab_$name/$tu.o ) &
+          -fno-fast-math -ffp-contract=off $pl -I../../include -I. $flags -c $tu.hip -o ../../build_prof/ab_$name/$tu.o ) &
     done
   done
   wait
