@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "tapenv.h"
@@ -206,6 +207,8 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d);
 inline int tap_group_size(const tap_env_desc *d)
 {
     const int cells = d->W * d->L;
+    static const int forced = [] { const char *e = getenv("TAP_FORCE_G"); return e ? atoi(e) : 0; }();   // A/B runs only
+    if (forced >= cells && (forced == 8 || forced == 16 || forced == 32 || forced == 64)) return forced;
     return cells <= 8 ? 8 : cells <= 16 ? 16 : cells <= 32 ? 32 : cells <= 64 ? 64 : 0;
 }
 // the same by-products from a launch of their own, for the steps that run as two launches (transition.hip)

@@ -108,10 +108,31 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(
 }
 
 // ---- and for MACS / MUL 3D (tap_macs3.h): G = 8..64 lanes per env --------------------------------
-template <int G, int NC, int MODE>
-__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3(TransArgs a)
-{
+// -DTAP_M3_SPREAD (A/B builds): ONE container per placement wave at G = 32 -- the wave's second lane group idles on an
+// out-of-range env -- so that B = 4096 puts four placement waves on a SIMD instead of two, each running only its own
+// container's loop trips.
+#ifdef TAP_M3_SPREAD
+template <int G> struct M3Spread { static constexpr bool on = G == 32; };
+#else
+template <int G> struct M3Spread { static constexpr bool on = false; };
+#endif
+template <int G> struct M3Geo {
     using Geo = TransGeom<G, 4>;
+    static constexpr bool SPREAD = M3Spread<G>::on;
+    static constexpr int EPB = SPREAD ? 4 : Geo::EPB, SPW = SPREAD ? 2 : Geo::SPW, ENV_WAVES = SPREAD ? 4 : Geo::ENV_WAVES;
+    static constexpr int GROUPS = SPREAD ? 8 : Geo::EPB;                      // LDS regions (the idle halves get one too)
+    static constexpr int THREADS = SPREAD ? 384 : Geo::THREADS;              // 4 placement + 2 stream waves
+};
+
+#ifdef TAP_M3_CAP6
+#define M3_OCC __attribute__((amdgpu_waves_per_eu(6, 6)))
+#else
+#define M3_OCC
+#endif
+template <int G, int NC, int MODE>
+__global__ void __launch_bounds__((M3Geo<G>::THREADS)) M3_OCC k_transition_macs3(TransArgs a)
+{
+    using Geo = M3Geo<G>;
     constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
     extern __shared__ float trans_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -123,17 +144,19 @@ __global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs3
     }
     __builtin_amdgcn_s_setprio(2);
     int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
-    tap_macs3_wave<G>(a.s, a.flags, a.ratio_out, env_base + tid / G, tid % G, lane,
-                      macs_base + (tid / G) * macs3_group_words(G, a.s.d.n_max, a.s.d.H));
+    const int grp = tid / G;
+    const int env = Geo::SPREAD ? ((grp & 1) ? a.s.d.B : env_base + (grp >> 1)) : env_base + grp;
+    tap_macs3_wave<G>(a.s, a.flags, a.ratio_out, env, tid % G, lane,
+                      macs_base + grp * macs3_group_words(G, a.s.d.n_max, a.s.d.H));
 }
 
 template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-    constexpr int EPB = TransGeom<G, 4>::EPB, THREADS = TransGeom<G, 4>::THREADS;
+    constexpr int EPB = M3Geo<G>::EPB, THREADS = M3Geo<G>::THREADS;
     const int grid = (a.s.d.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
-                       (size_t)EPB * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
+                       (size_t)M3Geo<G>::GROUPS * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
     if (lds > tap_lds_limit(ctx)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs3<G, NC_, M_>, LDS_)); \
