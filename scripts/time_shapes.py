@@ -103,6 +103,16 @@ def main():
     rows += rolling_case("3D rolling N=100 child=10 (two-word graphs, one wavefront per instance)", 4096, 100, 10, 3, [7, 7, 500])
     rows += rolling_case("3D rolling N=128 child=10", 4096, 128, 10, 3, [7, 7, 600])
     rows += rolling_case("3D rolling N=130 child=10 (one thread per instance)", 4096, 130, 10, 3, [7, 7, 600])
+    # round 4: the one-thread-per-container paths (correctness paths for unusual --container_width values), next to the
+    # lane-per-cell kernels at the nearest shapes they cover
+    one = bits_vs_copy[:1]
+    rows += episode_case("3D n=10 8x8 LB_GREEDY (lane per cell, for scale)", 4096, 10, 3, [8, 8, 50], "C+P+S-lb-soft", "LB_GREEDY", one)
+    rows += episode_case("3D n=10 10x10 LB_GREEDY (big.hip: one thread per container)", 4096, 10, 3, [10, 10, 50], "C+P+S-lb-soft", "LB_GREEDY", one)
+    rows += episode_case("3D n=10 8x8 MACS (lane per cell, for scale)", 4096, 10, 3, [8, 8, 50], "C+P+S-mcs-soft", "MACS", one)
+    rows += episode_case("3D n=10 10x10 MACS (macs3_big.hip: one thread per container)", 4096, 10, 3, [10, 10, 50], "C+P+S-mcs-soft", "MACS", one)
+    rows += episode_case("2D n=10 W=64 MACS (64 lanes per container, for scale)", 4096, 10, 2, [64, 50], "C+P+S-mcs-soft", "MACS", one)
+    rows += episode_case("2D n=10 W=100 MACS (macs_big.hip: one thread per container)", 4096, 10, 2, [100, 50], "C+P+S-mcs-soft", "MACS", one)
+    rows += episode_case("2D n=10 W=100 LB_GREEDY (big.hip)", 4096, 10, 2, [100, 50], "C+P+S-lb-soft", "LB_GREEDY", one)
     for r in rows:
         print(json.dumps(r))
     if a.out:
