@@ -210,6 +210,192 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_step(StepArgs a, int32_t *scr
     if (a.feature_out) big_feature(a.d.feature, D, W, L, hm, a.feature_out + (size_t)env * a.flen);
 }
 
+// ---- soft rewards: one WAVEFRONT per container (round 4) ----------------------------------------------------------------
+// In soft mode every corner candidate is scored independently and the winner is the first maximum in (z, y, class, x)
+// order (tools.py:2161-2165, 2336-2340): lanes take the cells c = lane, lane + 64, ..., keep their best (ratio, key),
+// and one wave-wide reduction on (ratio desc, key asc) picks the placement -- the container's height-map sits in the
+// wave's LDS tile.  (One thread per container ran 4 096 containers as 64 wavefronts, each the union of 64 control
+// flows: 265 us per step at 10 x 10 x 50, 1.9 ms with hard rewards.)  The thread-per-container kernel above remains for
+// containers whose tiles do not fit a workgroup's LDS (hard rewards above 2 560 cells).
+// HARD: the tile also holds, per cell, the corner key and the position's (max height under the footprint, stable) pair
+// and height sum: 4 ints per cell instead of 1.
+template <bool HARD>
+__global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
+{
+    extern __shared__ int32_t big_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int env = blockIdx.x * (TAP_BLOCK / 64) + wave;
+    const int B = a.d.B, D = a.d.D, W = a.d.W, L = a.d.L, cells = W * L;
+    if (env >= B) return;                                                         // wave-uniform
+    int32_t *hm = big_lds + (size_t)wave * cells * (HARD ? 4 : 1);
+    int32_t *ghm = a.v.hm + (size_t)env * cells;
+    int gmax = 0;
+    for (int c = lane; c < cells; c += 64) { const int h = ghm[c]; hm[c] = h; gmax = max(gmax, h); }
+    int dims[3] = {1, 1, 1};
+    if (a.static_) {                                                             // model.py:404-412
+        bool badp;
+        const long p = tap_col((long)a.ptr[env], a.nR, badp);
+        for (int k = 0; k < D; ++k) dims[k] = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 1 + k) * a.nR + p];
+    } else if (a.blocks_dtype == TAP_DT_F32) {
+        for (int k = 0; k < D; ++k) dims[k] = (int)((const float *)a.blocks)[(size_t)env * D + k];
+    } else {
+        for (int k = 0; k < D; ++k) dims[k] = ((const int32_t *)a.blocks)[(size_t)env * D + k];
+    }
+    const bool act = !a.active || a.active[env] != 0;
+    const int4 cv = reinterpret_cast<const int4 *>(a.v.cnt)[env];
+    Counters cnt = {cv.x, cv.y, cv.z, cv.w};
+    const int bx = dims[0], by = D == 3 ? dims[1] : 1, bz = dims[D - 1];
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }
+    if (act && (bx < 1 || by < 1 || bz < 1)) { err |= 4; do_step = false; }
+    if (act && do_step && ((D == 3 && (bx > 8 || by > 8) && bx <= W && by <= L) || (D == 2 && bx > 64 && bx <= W))) {
+        err |= 4; do_step = false;                                               // footprint beyond the support masks
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, __shfl_xor(gmax, o));
+    tap_wave_lds_sync();
+    if (do_step) {                                                               // wave-uniform
+        const BigCtx c = {D, W, L, a.d.H, a.d.flags, a.lut, hm, nullptr};
+        const PlaceCfg cfg = {W, L, a.d.H, a.d.flags, a.lut};
+        const int vol = bx * by * bz, step = cnt.count;
+        double best = -1.0;
+        long bestkey = LONG_MAX;
+        int bxy = 0, bzv = 0, bstab = 0, bemp = 0;
+        double wr;
+        long wk;
+        if (!HARD) {
+        for (int cell = lane; cell < cells; cell += 64) {
+            const int x = cell / L, y = cell - x * L;
+            int cls;
+            if (!big_corner(c, x, y, cls)) continue;
+            if (x + bx > W || y + by > L) continue;                              // :2076 (2D: every later corner overflows too), :2255-2256
+            int mx, sum; u64 eq;
+            big_scan(c, x, y, bx, by, mx, eq, sum);
+            const int z = mx;
+            if (z >= a.d.H) err |= 1;                                            // :2109 would raise IndexError
+            const int stab = z == 0 ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d_any(a.lut, bx, by, eq));
+            const int emp = cnt.empty + bx * by * z - sum;
+            const double r = tap_score(cfg, cnt, vol, gmax, z, bz, emp, stab);
+            const long key = big_key(c, x, y, z, cls);
+            if (r > best || (r == best && key < bestkey)) { best = r; bestkey = key; bxy = x | (y << 12); bzv = z; bstab = stab; bemp = emp; }
+        }
+        // first maximum in key order over the wave
+        wr = best;
+        wk = bestkey;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double r2 = __hiloint2double(__shfl_xor(__double2hiint(wr), o), __shfl_xor(__double2loint(wr), o));
+            const long k2 = ((long)__shfl_xor((int)(wk >> 32), o) << 32) | (unsigned)__shfl_xor((int)wk, o);
+            if (r2 > wr || (r2 == wr && k2 < wk)) { wr = r2; wk = k2; }
+        }
+        } else {
+            // The reference walks the corners in key order and slides each one (x up, then y up from the corner) to the
+            // first position that is supported, free and stable, skipping positions an earlier walk of the same level
+            // visited (tools.py:2100-2121, 2284-2297, 2320-2327).  A position settles at level z iff the maximum under its
+            // footprint IS z and it is stable, so it can settle at one level only and "visited" only matters for
+            // positions that settled: per position (max, stable, sum) once, then per corner one wave-wide minimum over
+            // the order index x * L + y of the settling, untaken positions of its rectangle.
+            int32_t *keys = hm + cells, *pms = keys + cells, *psum = pms + cells;
+            for (int cell = lane; cell < cells; cell += 64) {
+                const int x = cell / L, y = cell - x * L;
+                int cls, k = INT_MAX, ms = -1, sm = 0;
+                if (x + bx <= W && y + by <= L) {
+                    int mx; u64 eq;
+                    big_scan(c, x, y, bx, by, mx, eq, sm);
+                    const int st = mx == 0 ? 1 : (D == 2 ? tap_stable2d(bx, eq) : tap_stable3d_any(a.lut, bx, by, eq));
+                    ms = (mx << 1) | st;
+                    if (big_corner(c, x, y, cls)) { const long kk = big_key(c, x, y, mx, cls); k = kk > INT_MAX ? INT_MAX : (int)kk; }
+                }
+                keys[cell] = k; pms[cell] = ms; psum[cell] = sm;
+            }
+            tap_wave_lds_sync();
+            wr = -1.0; wk = 0;
+            int last = -1;
+            for (;;) {
+                int kmin = INT_MAX;
+                for (int cell = lane; cell < cells; cell += 64) { const int k = keys[cell]; if (k > last && k < kmin) kmin = k; }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, __shfl_xor(kmin, o));
+                if (kmin == INT_MAX) break;
+                last = kmin;
+                const int X0 = kmin % W;
+                int t = kmin / W; t /= 3;
+                const int Y0 = t % L, z = t / L;
+                if (z >= a.d.H) { err |= 1; continue; }                          // :2109 IndexError at the corner's own position
+                int first = INT_MAX;
+                for (int cell = lane; cell < cells; cell += 64) {
+                    const int x = cell / L, y = cell - x * L;
+                    const int ms = pms[cell];
+                    if (x >= X0 && y >= Y0 && ms == ((z << 1) | 1) && cell < first) first = cell;   // ms < 0: out of bounds or taken
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+                if (first == INT_MAX) continue;
+                if (lane == 0) pms[first] = -2;                                  // settled: no later walk stops here
+                const int sx = first / L, sy = first - sx * L, semp = cnt.empty + bx * by * z - psum[first];
+                const double r = tap_score(cfg, cnt, vol, gmax, z, bz, semp, 1);
+                if (r > wr) { wr = r; bxy = sx | (sy << 12); bzv = z; bstab = 1; bemp = semp; }    // first maximum in walk order
+                tap_wave_lds_sync();
+            }
+            best = wr; bestkey = wk;                                             // every lane holds the winner
+        }
+        const bool placed = wr > 0.0;
+        const u64 wm = __ballot(placed && best == wr && bestkey == wk);          // keys are unique: one lane
+        const int src = wm ? __ffsll((long long)wm) - 1 : 0;
+        const int pxy = __shfl(bxy, src), pz = __shfl(bzv, src), pstab = __shfl(bstab, src), pemp = __shfl(bemp, src);
+        const int px = pxy & 4095, py = pxy >> 12;
+        unsigned eall = (unsigned)err;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) eall |= (unsigned)__shfl_xor((int)eall, o);
+        err = (int)eall;
+        tap_wave_lds_sync();
+        if (placed) {                                                            // tools.py:2167-2174
+            for (int f = lane; f < bx * by; f += 64) {
+                const int i = f / by, j = f - i * by;
+                const int cidx = (px + i) * L + py + j;
+                hm[cidx] = pz + bz;
+                ghm[cidx] = pz + bz;
+            }
+            cnt.valid += vol;
+            cnt.empty = pemp;
+            cnt.nstable += pstab;
+            if (pz + bz > a.d.H) err |= 1;                                       // :2169 numpy clips silently
+        }
+        cnt.count += 1;                                                          // tools.py:3713
+        if (lane == 0) {
+            reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+            int32_t *q = a.v.pos + (size_t)step * D * B + env;
+            q[0] = placed ? px : 0;
+            if (D == 3) { q[B] = placed ? py : 0; q[2 * (size_t)B] = placed ? pz : 0; } else q[B] = placed ? pz : 0;
+            a.v.stable[(size_t)step * B + env] = (uint8_t)(placed ? pstab : 0);
+        }
+        tap_wave_lds_sync();
+    }
+    if (lane == 0 && err) a.v.err[env] |= err;
+    if (a.feature_out) {                                                         // tools.py:3716-3744, lanes over the cells
+        float *out = a.feature_out + (size_t)env * a.flen;
+        if (a.d.feature == TAP_FEAT_DIFF) {
+            if (D == 2) { for (int c = lane; c + 1 < W; c += 64) out[c] = (float)(hm[c + 1] - hm[c]); }
+            else
+                for (int c = lane; c < cells; c += 64) {
+                    const int x = c / L, y = c - x * L;
+                    out[c] = (float)(x > 0 ? hm[c] - hm[c - L] : 0);
+                    out[cells + c] = (float)(y > 0 ? hm[c] - hm[c - 1] : 0);
+                }
+        } else {
+            int mn = 0;
+            if (a.d.feature == TAP_FEAT_ZERO) {
+                mn = INT_MAX;
+                for (int c = lane; c < cells; c += 64) mn = min(mn, hm[c]);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+            }
+            for (int c = lane; c < cells; c += 64) out[c] = (float)(hm[c] - mn);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(TAP_BLOCK) k_big_feature(tap_env_desc d, EnvView v, float *out, int flen)
 {
     const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
@@ -222,6 +408,20 @@ int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
     const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
     if (grid == 0) return TAP_OK;
     (void)state;
+    const bool hard = (a.d.flags & TAP_F_HARD) != 0;
+    const size_t lds = (size_t)(TAP_BLOCK / 64) * a.d.W * a.d.L * sizeof(int32_t) * (hard ? 4 : 1);
+    if (lds <= tap_lds_limit(ctx)) {                                             // one wavefront per container
+        const dim3 g((a.d.B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64));
+        if (hard) {
+            TAP_HIP_CHECK(ctx, tap_allow_lds(k_big_wave_step<true>, lds));
+            hipLaunchKernelGGL(k_big_wave_step<true>, g, dim3(TAP_BLOCK), lds, st, a);
+        } else {
+            TAP_HIP_CHECK(ctx, tap_allow_lds(k_big_wave_step<false>, lds));
+            hipLaunchKernelGGL(k_big_wave_step<false>, g, dim3(TAP_BLOCK), lds, st, a);
+        }
+        TAP_LAUNCH_CHECK(ctx, "k_big_wave_step");
+        return TAP_OK;
+    }
     hipLaunchKernelGGL(k_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.scratch);
     TAP_LAUNCH_CHECK(ctx, "k_big_step");
     return TAP_OK;
