@@ -167,11 +167,11 @@ __device__ static void big_feature(int feature, int D, int W, int L, const int32
     for (int c = 0; c < cells; ++c) out[c] = (float)(hm[c] - mn);
 }
 
-__global__ void __launch_bounds__(TAP_BLOCK) k_big_step(StepArgs a, int32_t *scratch)
+__global__ void __launch_bounds__(TAP_BLOCK) k_big_step(StepArgs a, int32_t *scratch, int lpw)
 {
-    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const int env = tap_spread_env(lpw, a.d.B);                                  // containers spread over the waves (tap_common.h)
     const int B = a.d.B;
-    if (env >= B) return;
+    if (env < 0) return;
     const int D = a.d.D, W = a.d.W, L = a.d.L, cells = W * L;
     int dims[3] = {1, 1, 1};
     int err = 0;
@@ -422,7 +422,8 @@ int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
         TAP_LAUNCH_CHECK(ctx, "k_big_wave_step");
         return TAP_OK;
     }
-    hipLaunchKernelGGL(k_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.scratch);
+    const int lpw = tap_spread_lpw(a.d.B);
+    hipLaunchKernelGGL(k_big_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.scratch, lpw);
     TAP_LAUNCH_CHECK(ctx, "k_big_step");
     return TAP_OK;
 }

@@ -75,11 +75,11 @@ __device__ static void lb_try(const LbView &s, const PlaceCfg &c, const Counters
         }
 }
 
-__global__ void __launch_bounds__(TAP_BLOCK) k_lb_step(StepArgs a, int16_t *vox, uint8_t *lfs, uint8_t *lfn, int cap)
+__global__ void __launch_bounds__(TAP_BLOCK) k_lb_step(StepArgs a, int16_t *vox, uint8_t *lfs, uint8_t *lfn, int cap, int lpw)
 {
-    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const int env = tap_spread_env(lpw, a.d.B);                                  // containers spread over the waves (tap_common.h)
     const int B = a.d.B;
-    if (env >= B) return;
+    if (env < 0) return;
     const int D = a.d.D, W = a.d.W, L = a.d.L, H = a.d.H, cells = W * L;
     int dims[3] = {1, 1, 1};
     int err = 0;
@@ -255,10 +255,10 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_lb_step(StepArgs a, int16_t *vox,
 int tap_lb_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
 {
     if (a.d.W + 2 > 250) return tap_fail(ctx, TAP_E_UNSUPPORTED, "legacy LB: container width %d too large", a.d.W);
-    const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
-    if (grid == 0) return TAP_OK;
+    if (a.d.B == 0) return TAP_OK;
     (void)state;
-    hipLaunchKernelGGL(k_lb_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.vox, a.v.lfs, a.v.lfn, a.d.W + 2);
+    const int lpw = tap_spread_lpw(a.d.B);
+    hipLaunchKernelGGL(k_lb_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.vox, a.v.lfs, a.v.lfn, a.d.W + 2, lpw);
     TAP_LAUNCH_CHECK(ctx, "k_lb_step");
     return TAP_OK;
 }

@@ -20,11 +20,11 @@ size_t tap_macs3_big_scratch_ints(const tap_env_desc *d)
     return (size_t)2 * macs3_big_cap(d->n_max) + (size_t)2 * d->W * d->L + (size_t)2 * (d->n_max + 2);
 }
 
-__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32_t *scratch, size_t scratch_ints)
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32_t *scratch, size_t scratch_ints, int lpw)
 {
-    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const int env = tap_spread_env(lpw, a.d.B);                                  // containers spread over the waves (tap_common.h)
     const int B = a.d.B, W = a.d.W, L = a.d.L, H = a.d.H, cells = W * L;
-    if (env >= B) return;
+    if (env < 0) return;
     int bx, by, bz;
     if (a.static_) {                                                             // model.py:404-412
         bool badp;
@@ -80,10 +80,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32
 
 int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
-    const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
-    if (grid == 0) return TAP_OK;
+    if (a.d.B == 0) return TAP_OK;
     if (!a.v.scratch || !a.v.occ) return tap_fail(ctx, TAP_E_INVALID, "MACS 3D above 64 cells: the state blob has no scratch section");
-    hipLaunchKernelGGL(k_macs3d_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.scratch, tap_macs3_big_scratch_ints(&a.d));
+    const int lpw = tap_spread_lpw(a.d.B);                                     // containers per wavefront (tap_common.h)
+    hipLaunchKernelGGL(k_macs3d_big_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.scratch,
+                       tap_macs3_big_scratch_ints(&a.d), lpw);
     TAP_LAUNCH_CHECK(ctx, "k_macs3d_big_step");
     if (a.feature_out) return tap_big_feature(ctx, &a.d, a.v, a.feature_out, a.flen, st);   // tools.py:3716-3744
     return TAP_OK;

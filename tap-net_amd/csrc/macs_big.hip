@@ -69,11 +69,11 @@ __device__ static long mb_adj(const MbCtx &c, int xs, int bx, int top, int m)
     return base - (long)m * (W - 1);
 }
 
-__global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32_t *scratch, int cap)
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32_t *scratch, int cap, int lpw)
 {
-    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const int env = tap_spread_env(lpw, a.d.B);                                  // containers spread over the waves (tap_common.h)
     const int B = a.d.B, W = a.d.W, H = a.d.H;
-    if (env >= B) return;
+    if (env < 0) return;
     int32_t *hm = a.v.hm + (size_t)env * W;
     const int4 cv = reinterpret_cast<const int4 *>(a.v.cnt)[env];
     Counters cnt = {cv.x, cv.y, cv.z, cv.w};
@@ -263,10 +263,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32
 
 int tap_macs_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
-    const int grid = (a.d.B + TAP_BLOCK - 1) / TAP_BLOCK;
-    if (grid == 0) return TAP_OK;
+    if (a.d.B == 0) return TAP_OK;
     if (!a.v.scratch) return tap_fail(ctx, TAP_E_INVALID, "MACS above 64 columns: the state blob has no scratch section");
-    hipLaunchKernelGGL(k_macs2d_big_step, dim3(grid), dim3(TAP_BLOCK), 0, st, a, a.v.scratch, macs_big_cap(a.d.W, a.d.n_max));
+    const int lpw = tap_spread_lpw(a.d.B);
+    hipLaunchKernelGGL(k_macs2d_big_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.scratch,
+                       macs_big_cap(a.d.W, a.d.n_max), lpw);
     TAP_LAUNCH_CHECK(ctx, "k_macs2d_big_step");
     return TAP_OK;
 }

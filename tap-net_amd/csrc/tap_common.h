@@ -202,6 +202,25 @@ __device__ __forceinline__ void tap_step_aux(const StepArgs &s, int env, int D, 
     }
 }
 
+// One-THREAD-per-container kernels (macs_big.hip, macs3_big.hip, lb.hip, big.hip's fallback): a wavefront runs the union of
+// its lanes' control flows, and these placements are long, data-dependent serial loops -- 64 containers per wave cost
+// about 64 times one.  So the containers are SPREAD: only the first `lpw` lanes of every wave carry a container, with
+// lpw chosen so that the launch has about four waves per SIMD (B = 4 096 -> one container per wave).  env of this thread,
+// or -1 for an idle lane:
+__device__ __forceinline__ int tap_spread_env(int lpw, int B)
+{
+    const int lane = threadIdx.x & 63, wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int env = wave * lpw + lane;
+    return (lane < lpw && env < B) ? env : -1;
+}
+inline int tap_spread_lpw(int B)                 // lanes per wave that carry a container
+{
+    int lpw = 64;
+    while (lpw > 1 && (B + lpw - 1) / lpw < 4096) lpw >>= 1;        // 256 CUs x 4 SIMDs x 4 waves
+    return lpw;
+}
+inline int tap_spread_grid(int B, int lpw, int threads) { const int waves = (B + lpw - 1) / lpw, wpb = threads / 64; return (waves + wpb - 1) / wpb; }
+
 int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d);
 // lanes per env: smallest of 8/16/32/64 that holds W*L cells, 0 if unsupported
 inline int tap_group_size(const tap_env_desc *d)
