@@ -111,7 +111,7 @@ def main():
     rows += episode_case("3D n=10 10x10 LB_GREEDY hard rewards (big.hip)", 4096, 10, 3, [10, 10, 50], "C+P+S-lb-hard", "LB_GREEDY", one)
     rows += episode_case("3D n=20 16x16 LB_GREEDY (big.hip)", 4096, 20, 3, [16, 16, 60], "C+P+S-lb-soft", "LB_GREEDY", one)
     rows += episode_case("3D n=10 8x8 MACS (lane per cell, for scale)", 4096, 10, 3, [8, 8, 50], "C+P+S-mcs-soft", "MACS", one)
-    rows += episode_case("3D n=10 10x10 MACS (macs3_big.hip: one thread per container)", 4096, 10, 3, [10, 10, 50], "C+P+S-mcs-soft", "MACS", one)
+    rows += episode_case("3D n=10 10x10 MACS (macs3_big.hip: one wavefront per container)", 4096, 10, 3, [10, 10, 50], "C+P+S-mcs-soft", "MACS", one)
     rows += episode_case("2D n=10 W=64 MACS (64 lanes per container, for scale)", 4096, 10, 2, [64, 50], "C+P+S-mcs-soft", "MACS", one)
     rows += episode_case("2D n=10 W=100 MACS (macs_big.hip: one thread per container)", 4096, 10, 2, [100, 50], "C+P+S-mcs-soft", "MACS", one)
     rows += episode_case("2D n=10 W=100 LB_GREEDY (big.hip)", 4096, 10, 2, [100, 50], "C+P+S-lb-soft", "LB_GREEDY", one)

@@ -1,11 +1,13 @@
 // macs3_big.hip -- MACS / MUL 3D (tools.calc_one_position_mcs_3d, tools.py:2751-3165) for containers beyond the
 // lane-per-cell kernel of tap_macs3.h: more than 64 cells or a side above 8 (e.g. --container_width 10 -> 10 x 10 x H,
-// model.py:279).  One thread per container on the same reduced state (height-map, placement history, the free-list
-// bit-grid in `occ`), the algorithm in tap_macs3_big.h; candidate lists live in the blob's scratch section.
-// A correctness path for unusual shapes like big.hip / macs_big.hip.  gfx950 only.
+// model.py:279).  ONE WAVEFRONT per container (tap_macs3_wave.h: the serial algorithm of tap_macs3_big.h run wave-uniformly on
+// the container's LDS tile, its long loops shared by the lanes), on the same reduced state as the lane kernel (height-map,
+// placement history, the free-list bit-grid in `occ`); one THREAD per container with the lists in the blob's scratch
+// section when the tile does not fit the LDS.  gfx950 only.
 #include "tap_common.h"
 #include "tap_place.h"
 #include "tap_macs3_big.h"
+#include "tap_macs3_wave.h"
 
 static_assert(M3B_F_HARD == TAP_F_HARD && M3B_F_USE_P == TAP_F_USE_P && M3B_F_USE_S == TAP_F_USE_S &&
               M3B_F_ZERO == TAP_F_MCS_ZERO && M3B_F_TIE == TAP_F_MCS_TIE, "flag bits are passed through");
@@ -78,10 +80,89 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32
     if (err) a.v.err[env] |= err;
 }
 
+// ---- one WAVEFRONT per container (tap_macs3_wave.h): the container's working set in the wave's LDS tile ---------------
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
+{
+    extern __shared__ unsigned long long m3w_lds[];
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int B = a.d.B, W = a.d.W, L = a.d.L, H = a.d.H, cells = W * L, HW = (H + 63) / 64;
+    if (env >= B) return;                                                         // wave-uniform
+    const int cap = macs3_big_cap(a.d.n_max);
+    M3WTile s;
+    s.W = W; s.L = L; s.H = H; s.HW = HW; s.flags = a.d.flags; s.cap = cap; s.n_max = a.d.n_max;
+    m3b_u64 *base = m3w_lds + (size_t)wave_in_wg * m3w_tile_u64(cells, HW, a.d.n_max, cap);
+    s.occ = base;
+    s.rows = s.occ + (size_t)cells * HW;
+    s.ems = reinterpret_cast<M3BEms *>(s.rows + 64);
+    s.hm = reinterpret_cast<int32_t *>(s.ems + cap);
+    s.lev = s.hm + cells; s.slots = s.lev + cells; s.lvh = s.slots + cells; s.lvr = s.lvh + a.d.n_max + 2;
+    s.pos = a.v.pos + env; s.blk = a.v.blk + env; s.hs = (size_t)B;
+    int32_t *ghm = a.v.hm + (size_t)env * cells;
+    m3b_u64 *gocc = a.v.occ + (size_t)env * cells * HW;
+    for (int c = lane; c < cells; c += 64) s.hm[c] = ghm[c];
+    for (int k = lane; k < cells * HW; k += 64) s.occ[k] = gocc[k];
+    int bx, by, bz;
+    if (a.static_) {                                                             // model.py:404-412
+        bool badp;
+        const long p = tap_col((long)a.ptr[env], a.nR, badp);
+        bx = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+        by = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+        bz = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 3) * a.nR + p];
+    } else if (a.blocks_dtype == TAP_DT_F32) {
+        const float *b = (const float *)a.blocks + (size_t)env * 3;
+        bx = (int)b[0]; by = (int)b[1]; bz = (int)b[2];
+    } else {
+        const int32_t *b = (const int32_t *)a.blocks + (size_t)env * 3;
+        bx = b[0]; by = b[1]; bz = b[2];
+    }
+    const bool act = !a.active || a.active[env] != 0;
+    const int4 cv = reinterpret_cast<const int4 *>(a.v.cnt)[env];
+    int cnt[4] = {cv.x, cv.y, cv.z, cv.w};
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt[3] >= a.d.n_max) { err |= 2; do_step = false; }                   // tools.py:3677 IndexError
+    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > L || bx > 8 || by > 8)) { err |= 4; do_step = false; }   // as k_macs3d_big_step
+    tap_wave_lds_sync();
+    if (do_step) {                                                               // wave-uniform
+        const int step = cnt[3];
+        s.step = step;
+        const M3BResult r = m3w_place(s, cnt, err, bx, by, bz, a.lut, lane);
+        cnt[3] += 1;                                                             // tools.py:3713
+        tap_wave_lds_sync();
+        for (int c = lane; c < cells; c += 64) ghm[c] = s.hm[c];
+        for (int k = lane; k < cells * HW; k += 64) gocc[k] = s.occ[k];
+        if (lane == 0) {
+            reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt[0], cnt[1], cnt[2], cnt[3]);
+            a.v.pos[(size_t)(step * 3) * B + env] = r.x;
+            a.v.pos[(size_t)(step * 3 + 1) * B + env] = r.y;
+            a.v.pos[(size_t)(step * 3 + 2) * B + env] = r.z;
+            a.v.stable[(size_t)step * B + env] = (uint8_t)r.stab;
+            a.v.blk[(size_t)(step * 3) * B + env] = bx | (r.placed << 16);      // history of later steps
+            a.v.blk[(size_t)(step * 3 + 1) * B + env] = by;                      // (tools.py:2843-2846), failures too
+            a.v.blk[(size_t)(step * 3 + 2) * B + env] = bz;
+        }
+    }
+    if (lane == 0 && err) a.v.err[env] |= err;
+}
+
 int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     if (a.d.B == 0) return TAP_OK;
     if (!a.v.scratch || !a.v.occ) return tap_fail(ctx, TAP_E_INVALID, "MACS 3D above 64 cells: the state blob has no scratch section");
+    {   // one wavefront per container when its working set fits a wave's share of the LDS
+        const int cells = a.d.W * a.d.L, HW = (a.d.H + 63) / 64;
+        const size_t tile = m3w_tile_u64(cells, HW, a.d.n_max, macs3_big_cap(a.d.n_max)) * 8;
+        int waves = TAP_BLOCK / 64;
+        while (waves > 1 && (size_t)waves * tile > tap_lds_limit(ctx)) waves >>= 1;
+        if ((size_t)waves * tile <= tap_lds_limit(ctx)) {
+            TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_wave_step, (size_t)waves * tile));
+            hipLaunchKernelGGL(k_macs3d_wave_step, dim3((a.d.B + waves - 1) / waves), dim3(waves * 64), (size_t)waves * tile, st, a);
+            TAP_LAUNCH_CHECK(ctx, "k_macs3d_wave_step");
+            if (a.feature_out) return tap_big_feature(ctx, &a.d, a.v, a.feature_out, a.flen, st);   // tools.py:3716-3744
+            return TAP_OK;
+        }
+    }
     const int lpw = tap_spread_lpw(a.d.B);                                     // containers per wavefront (tap_common.h)
     hipLaunchKernelGGL(k_macs3d_big_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.scratch,
                        tap_macs3_big_scratch_ints(&a.d), lpw);
