@@ -1,5 +1,7 @@
 // macs.hip -- stand-alone MACS / MUL step (tools.Container.add_new_block with packing_strategy
 // 'MACS' / 'MUL'); the placement itself is tap_macs.h (2D) / tap_macs3.h (3D).  gfx950 only.
+#include <cstdlib>
+
 #include "tap_common.h"
 #include "tap_macs.h"
 #include "tap_macs_wide.h"
@@ -172,7 +174,13 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
         default: return launch_macs3<64>(ctx, a, st);
         }
     }
-    if (a.d.W > 64) return tap_macs_big_step(ctx, a, st);              // one thread per container (macs_big.hip)
+    if (a.d.W > 64) return tap_macs_big_step(ctx, a, st);              // one wavefront per container (macs_big.hip)
+    {   // above 32 columns the wave-per-container kernel of macs_big.hip beats the 64-lane form of tap_macs_wide.h (eager
+        // steps at B = 4096, n = 20: W = 40 130 against 356 us, W = 64 174 against 1 473 us; W = 32 112 against 119, W = 20
+        // 77 against 61); TAP_MACS2D_WAVE_FROM=W moves the hand-over for A/B runs
+        static const int from = [] { const char *e = getenv("TAP_MACS2D_WAVE_FROM"); return e ? atoi(e) : 33; }();
+        if (a.d.W >= from && tap_macs_wave_step(ctx, a, st) == TAP_OK) return TAP_OK;
+    }
     if (a.d.W > 32) return launch_macs_wide<64>(ctx, a, st);
     if (a.d.W > 16) return launch_macs_wide<32>(ctx, a, st);
     return a.d.W <= 8 ? launch_macs<8>(ctx, a, st) : launch_macs<16>(ctx, a, st);

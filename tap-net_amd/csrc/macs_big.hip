@@ -1,11 +1,12 @@
 // macs_big.hip -- MACS / MUL 2D (tools.calc_one_position_mcs_2d, tools.py:2456-2749) for containers wider than the
-// lane-per-column kernels cover (W > 64; the reference builds any --container_width, model.py:279, and its MACS has
-// no size limit).  Same height-map restatement as tap_macs.h / tap_macs_wide.h (read tap_macs.h's header first:
+// lane-per-column kernels handle well (W > 32; the reference builds any --container_width, model.py:279, and its MACS
+// has no size limit).  Same height-map restatement as tap_macs.h / tap_macs_wide.h (read tap_macs.h's header first:
 // the reference's per-level free-interval lists are the runs of columns with hm <= z, its voxel tests are height
-// comparisons, `visited` is one flag per (position, level)), written for ONE THREAD per container walking its own
-// columns in global memory -- a correctness path for unusual shapes like big.hip, not a fast one.  No mask is
-// involved, so neither the container nor a block has a width limit beyond the state blob's (W <= 4096).
-// gfx950 only.
+// comparisons, `visited` is one flag per (position, level)).  Two forms: k_macs2d_wave_step, ONE WAVEFRONT per container
+// with the long loops shared by the lanes (the form that runs), and k_macs2d_big_step, one THREAD per container walking
+// its own columns in global memory (the serial statement of the algorithm; the fallback when a container's tile does not
+// fit the LDS).  No mask is involved, so neither the container nor a block has a width limit beyond the state
+// blob's (W <= 4096).  gfx950 only.
 #include "tap_common.h"
 #include "tap_place.h"
 
@@ -261,10 +262,309 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32
     if (err) a.v.err[env] |= err;
 }
 
+// ---- one WAVEFRONT per container (round 4) ------------------------------------------------------------------------------
+// The same algorithm as k_macs2d_big_step, statement for statement, with its control skeleton run wave-uniformly on the
+// container's LDS tile and the long loops shared by the lanes: a level's column runs come out of 64-column ballots, "is
+// the block's top free" / "how far is it free" are wave reductions, the settling level and stability of every position are
+// computed one position per lane once per step (a position settles at Z iff the maximum under it IS Z, so `visited`
+// is one flag per position), a corner walk is a wave-wide min / max over the settling positions of its range, the slots
+// are scored one per lane and the usable-space score of a tied slot sums one column per lane.
+// Tile (ints): hm[W] | lev[W] | psum[W] | slots[W] | ems[2 cap]
+__host__ __device__ inline size_t macs_wave_tile_ints(int W, int cap) { return (size_t)4 * W + (size_t)2 * cap; }
+
+__device__ __forceinline__ int mw_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int mw_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ long mw_sum(long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += ((long)__shfl_xor((int)(v >> 32), o) << 32) | (unsigned)__shfl_xor((int)v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int cap)
+{
+    extern __shared__ int32_t mw_lds[];
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int B = a.d.B, W = a.d.W, H = a.d.H;
+    if (env >= B) return;                                                         // wave-uniform
+    int32_t *hm = mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(W, cap);
+    int32_t *lev = hm + W, *psum = lev + W, *slots = psum + W;
+    int2 *ems = reinterpret_cast<int2 *>(slots + W);
+    int32_t *ghm = a.v.hm + (size_t)env * W;
+    int gmax = 0;
+    for (int k = lane; k < W; k += 64) { const int h = ghm[k]; hm[k] = h; gmax = max(gmax, h); }
+    gmax = mw_max(gmax);
+    const int4 cv = reinterpret_cast<const int4 *>(a.v.cnt)[env];
+    Counters cnt = {cv.x, cv.y, cv.z, cv.w};
+    int bx, bz;
+    if (a.static_) {
+        bool badp;
+        const long p = tap_col((long)a.ptr[env], a.nR, badp);
+        bx = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 1) * a.nR + p];
+        bz = badp ? 0 : (int)a.static_[((size_t)env * a.static_rows + 2) * a.nR + p];
+    } else if (a.blocks_dtype == TAP_DT_F32) {
+        bx = (int)((const float *)a.blocks)[(size_t)env * 2];
+        bz = (int)((const float *)a.blocks)[(size_t)env * 2 + 1];
+    } else {
+        bx = ((const int32_t *)a.blocks)[(size_t)env * 2];
+        bz = ((const int32_t *)a.blocks)[(size_t)env * 2 + 1];
+    }
+    const bool act = !a.active || a.active[env] != 0;
+    int err = 0;
+    bool do_step = act;
+    if (act && cnt.count >= a.d.n_max) { err |= 2; do_step = false; }
+    if (act && (bx < 1 || bz < 1)) { err |= 4; do_step = false; }
+    const int step = cnt.count;
+    Placement res = {0, 0, 0, 0, 0};
+    tap_wave_lds_sync();
+
+    if (do_step) {                                                               // wave-uniform
+        const int flags = a.d.flags;
+        const bool hard = (flags & TAP_F_HARD) != 0;
+        const int vol = bx * bz;
+        int n_ems = 0;
+#define MW_PUSH(x1, z, x2)                                                                   \
+    do {                                                                                     \
+        if (n_ems < cap) { if (lane == 0) ems[n_ems] = make_int2((x1) | ((x2) << 16), (z)); ++n_ems; } \
+        else err |= 16;                                                                      \
+    } while (0)
+        // ---- (a) per-level free runs (tools.py:2517-2529); only z = 0 and z in {hm[c]} differ from below ----------
+        for (int z = 0;;) {
+            if (z + bz > H) break;                                                // :2519
+            bool in_run = false, on = false, stop = false;
+            int x1 = 0;
+            auto close_run = [&](int x2) {                                        // the run [x1, x2] is complete
+                if (x1 + bx > W) { stop = true; return; }                         // :2525
+                if (z > 0 && !on) return;                                         // :2526-2528 the same run below
+                MW_PUSH(x1, z, x2);                                               // :2529
+            };
+            for (int c0 = 0; c0 < W && !stop; c0 += 64) {
+                const int k = c0 + lane;
+                const int h = k < W ? hm[k] : INT_MAX;
+                const u64 le = __ballot(h <= z), eq = __ballot(h == z);
+                int pos = 0;
+                while (pos < 64 && !stop) {
+                    if (in_run) {
+                        const u64 t = le >> pos;
+                        const int len = t == ~0ull ? 64 : __ffsll((long long)~t) - 1;   // consecutive ones from pos (t has zeros shifted in unless pos = 0)
+                        if (len > 0) on = on || ((eq >> pos) & (len >= 64 ? ~0ull : ((1ull << len) - 1ull))) != 0ull;
+                        pos += len;
+                        if (pos < 64) { in_run = false; close_run(c0 + pos - 1); }
+                    } else {
+                        const u64 t = le >> pos;
+                        if (t == 0ull) { pos = 64; break; }
+                        pos += __ffsll((long long)t) - 1;
+                        in_run = true; x1 = c0 + pos; on = false;
+                    }
+                }
+            }
+            if (in_run && !stop) close_run(W - 1);
+            int nz = INT_MAX;
+            for (int k = lane; k < W; k += 64) { const int h = hm[k]; if (h > z) nz = min(nz, h); }   // :2520 next level that differs
+            nz = mw_min(nz);
+            if (nz == INT_MAX) break;
+            z = nz;
+        }
+        // ---- (b) tops of the blocks placed so far (tools.py:2531-2555); failed steps sit at (0, 0) ------------------
+        for (int i = 0; i < step; ++i) {
+            const int x = a.v.pos[(size_t)(i * 2) * B + env], z = a.v.pos[(size_t)(i * 2 + 1) * B + env];
+            const int xx = a.v.blk[(size_t)(i * 2) * B + env], zz = a.v.blk[(size_t)(i * 2 + 1) * B + env];
+            const int tz = z + zz;
+            if (!(tz < H)) continue;                                              // :2535
+            bool covered = false;                                                 // the slice clips at W (:2537)
+            for (int k = x + lane; k < x + xx && k < W; k += 64) covered |= hm[k] > tz;
+            const bool full = __ballot(covered) == 0ull;
+            if (full) {
+                const int2 want = make_int2(x | ((x + xx - 1) << 16), tz);
+                tap_wave_lds_sync();
+                bool dup = false;                                                 // :2538
+                for (int k = lane; k < n_ems; k += 64) dup |= ems[k].x == want.x && ems[k].y == want.y;
+                if (__ballot(dup) == 0ull) MW_PUSH(x, tz, x + xx - 1);
+            } else {
+                if (x + xx - 1 >= W) { err |= 8; continue; }                      // reference: IndexError :2550
+                const int xe = x + xx - 1;
+                int first_hi = W, last_hi = -1;                                   // first column >= x / last column <= xe above tz
+                for (int k = lane; k < W; k += 64) {
+                    const bool hi = hm[k] > tz;
+                    if (hi && k >= x) first_hi = min(first_hi, k);
+                    if (hi && k <= xe) last_hi = max(last_hi, k);
+                }
+                first_hi = mw_min(first_hi); last_hi = mw_max(last_hi);
+                if (hm[x] <= tz && x > 0 && hm[x - 1] <= tz)                      // :2543-2548 left part
+                    MW_PUSH(x, tz, x + min(first_hi - x, xx) - 1);
+                if (hm[xe] <= tz && x + xx < W && hm[x + xx] <= tz)               // :2550-2555 right part
+                    MW_PUSH(xe - min(xe - last_hi, xx) + 1, tz, xe);
+            }
+        }
+        // ---- per position: settling level, stability, height sum (mb_good) ------------------------------------------
+        const int X = W - bx + 1;
+        for (int xs = lane; xs < W; xs += 64) {
+            int v = -1, sum = 0;
+            if (xs < X) {
+                int mx = -1, first = -1, last = -1;
+                for (int k = 0; k < bx; ++k) {
+                    const int h = hm[xs + k];
+                    sum += h;
+                    if (h > mx) { mx = h; first = last = k; }
+                    else if (h == mx) last = k;
+                }
+                // is_stable_2d (tools.py:839-868): the centre strictly inside (first supported, last supported + 1)
+                const int stab = (mx == 0) ? 1 : ((2 * first < bx) && (2 * (bx - 1 - last) < bx));
+                if (stab || !hard) v = (mx << 2) | (stab << 1);                  // :2580-2581
+            }
+            lev[xs] = v; psum[xs] = sum;
+        }
+        tap_wave_lds_sync();
+        // ---- both corner walks of every EMS (tools.py:2680-2700) -> slot list ---------------------------------------
+        int n_slots = 0;
+        auto settle = [&](int xs) {
+            if (lane == 0) { lev[xs] |= 1; slots[n_slots] = xs; }
+            ++n_slots;
+            tap_wave_lds_sync();
+        };
+        for (int e = 0; e < n_ems; ++e) {
+            const int X1 = ems[e].x & 0xffff, X2 = ems[e].x >> 16, Z = ems[e].y;
+            if (X1 < X) {                                                         // :2686 left corner, slide right
+                int best = INT_MAX;
+                for (int xs = X1 + lane; xs < X; xs += 64) { const int v = lev[xs]; if (v >= 0 && !(v & 1) && (v >> 2) == Z) best = min(best, xs); }
+                best = mw_min(best);
+                if (best != INT_MAX) settle(best);
+            }
+            const int hi = X2 - bx + 1;                                           // :2694 right corner, slide left
+            if (hi >= 0) {
+                if (hi + bx > W) err |= 8;
+                else {
+                    int best = -1;
+                    for (int xs = lane; xs <= hi; xs += 64) { const int v = lev[xs]; if (v >= 0 && !(v & 1) && (v >> 2) == Z) best = max(best, xs); }
+                    best = mw_max(best);
+                    if (best >= 0) settle(best);
+                }
+            }
+        }
+        // ---- score the slots (tools.py:2590-2604), one per lane -------------------------------------------------------
+        const int valid2 = cnt.valid + vol;
+        const bool tiebreak = (flags & TAP_F_MCS_TIE) != 0, zero = (flags & TAP_F_MCS_ZERO) != 0;
+        auto eval_slot = [&](int s, int &xs, int &Z, int &sum, int &stab) -> double {
+            xs = slots[s];
+            const int v = lev[xs];
+            Z = v >> 2; stab = (v >> 1) & 1; sum = psum[xs];
+            if (zero) return 0.0;
+            int height = max(gmax, Z + bz);
+            if (Z + bx > height) height = Z + bz;                                 // :2594 (sic block_x)
+            const int emp = cnt.empty + bx * Z - sum;                             // :2598-2599
+            const double C = (double)valid2 / (double)((long long)height * W);
+            const double P = (flags & TAP_F_USE_P) ? (double)valid2 / (double)(emp + valid2) : 0.0;
+            const double S = (flags & TAP_F_USE_S) ? (double)(cnt.nstable + stab) / (double)(cnt.count + 1) : 0.0;
+            return (C + P) + S;
+        };
+        double rmax = -1.0;
+        int win = INT_MAX, max_height = gmax;
+        for (int s = lane; s < n_slots; s += 64) {
+            int xs, Z, sum, stab;
+            const double r = eval_slot(s, xs, Z, sum, stab);
+            max_height = max(max_height, Z + bz);                                 // :2719 np.max(heightmap_ems)
+            if (r > rmax) { rmax = r; win = s; }                                  // first maximum in list order
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double r2 = __hiloint2double(__shfl_xor(__double2hiint(rmax), o), __shfl_xor(__double2loint(rmax), o));
+            const int w2 = __shfl_xor(win, o);
+            if (r2 > rmax || (r2 == rmax && w2 < win)) { rmax = r2; win = w2; }
+        }
+        max_height = mw_max(max_height);
+        if (n_slots == 0) win = -1;
+        if (n_slots > 0 && tiebreak) {
+            long best_adj = 0;
+            int n_tied = 0;
+            win = -1;
+            for (int s = 0; s < n_slots; ++s) {                                   // wave-uniform: the tied slots in list order
+                int xs, Z, sum, stab;
+                if (eval_slot(s, xs, Z, sum, stab) != rmax) continue;
+                ++n_tied;
+                // usable-space score of the candidate map (mb_adj), one column j per lane
+                const int top = Z + bz, m = max(gmax, Z + bz);
+                long base = 0;
+                for (int j = lane; j < W; j += 64) {
+                    const int v = (j >= xs && j < xs + bx) ? top : hm[j];
+                    bool first = true;
+                    int next = m, best_run = 0, run = -1;
+                    for (int k = 0; k < W; ++k) {
+                        const int hk = (k >= xs && k < xs + bx) ? top : hm[k];
+                        if (hk == v && k < j) first = false;
+                        if (hk > v) next = min(next, hk);
+                        if (hk <= v) { ++run; best_run = max(best_run, run); } else run = -1;
+                    }
+                    if (first && v < m) base += (long)(next - v) * best_run;
+                }
+                const long adj = mw_sum(base) - (long)m * (W - 1);
+                if (win < 0 || adj > best_adj) { best_adj = adj; win = s; }
+            }
+            const int nt = zero ? 2 * n_ems : n_tied;
+            if (nt > 1 && max_height > H) err |= 1;                               // :2718 levels up to max_height
+        }
+        // ---- commit (tools.py:2738-2747) --------------------------------------------------------------------------------
+        if (win >= 0) {
+            int xs, Z, sum, stab;
+            (void)eval_slot(win, xs, Z, sum, stab);
+            res.placed = 1; res.x = xs; res.z = Z; res.stab = stab;
+            tap_wave_lds_sync();
+            for (int k = xs + lane; k < xs + bx; k += 64) { hm[k] = Z + bz; ghm[k] = Z + bz; }
+            cnt.valid += vol;
+            cnt.empty = cnt.empty + bx * Z - sum;
+            cnt.nstable += stab;
+            if (Z + bz > H) err |= 1;
+        }
+        cnt.count += 1;
+        tap_wave_lds_sync();
+#undef MW_PUSH
+    }
+
+    if (a.feature_out) {                                                          // tools.py:3716-3744
+        float *out = a.feature_out + (size_t)env * a.flen;
+        if (a.d.feature == TAP_FEAT_DIFF) {
+            for (int k = lane; k + 1 < W; k += 64) out[k] = (float)(hm[k + 1] - hm[k]);
+        } else {
+            int mn = 0;
+            if (a.d.feature == TAP_FEAT_ZERO) {
+                mn = INT_MAX;
+                for (int k = lane; k < W; k += 64) mn = min(mn, hm[k]);
+                mn = mw_min(mn);
+            }
+            for (int k = lane; k < W; k += 64) out[k] = (float)(hm[k] - mn);
+        }
+    }
+    if (lane == 0) {
+        if (do_step) {
+            reinterpret_cast<int4 *>(a.v.cnt)[env] = make_int4(cnt.valid, cnt.empty, cnt.nstable, cnt.count);
+            a.v.pos[(size_t)(step * 2) * B + env] = res.x;
+            a.v.pos[(size_t)(step * 2 + 1) * B + env] = res.z;
+            a.v.stable[(size_t)step * B + env] = (uint8_t)res.stab;
+            a.v.blk[(size_t)(step * 2) * B + env] = bx;                           // history the later steps read
+            a.v.blk[(size_t)(step * 2 + 1) * B + env] = bz;                       // (tools.py:2531-2533), failures too
+        }
+        if (err) a.v.err[env] |= err;
+    }
+}
+
+// -> TAP_OK when launched, TAP_E_UNSUPPORTED (no message) when a container's tile does not fit a wave's share of the LDS
+int tap_macs_wave_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
+{
+    if (a.d.B == 0) return TAP_OK;
+    const int cap = macs_big_cap(a.d.W, a.d.n_max);
+    const size_t tile = macs_wave_tile_ints(a.d.W, cap) * sizeof(int32_t);
+    int waves = TAP_BLOCK / 64;
+    while (waves > 1 && (size_t)waves * tile > tap_lds_limit(ctx)) waves >>= 1;
+    if ((size_t)waves * tile > tap_lds_limit(ctx)) return TAP_E_UNSUPPORTED;
+    TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs2d_wave_step, (size_t)waves * tile));
+    hipLaunchKernelGGL(k_macs2d_wave_step, dim3((a.d.B + waves - 1) / waves), dim3(waves * 64), (size_t)waves * tile, st, a, cap);
+    TAP_LAUNCH_CHECK(ctx, "k_macs2d_wave_step");
+    return TAP_OK;
+}
+
 int tap_macs_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     if (a.d.B == 0) return TAP_OK;
-    if (!a.v.scratch) return tap_fail(ctx, TAP_E_INVALID, "MACS above 64 columns: the state blob has no scratch section");
+    if (tap_macs_wave_step(ctx, a, st) == TAP_OK) return TAP_OK;
+    if (!a.v.scratch) return tap_fail(ctx, TAP_E_INVALID, "MACS above 64 columns: the state blob has no scratch section");           // one wavefront per container when its tile fits the LDS
     const int lpw = tap_spread_lpw(a.d.B);
     hipLaunchKernelGGL(k_macs2d_big_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.scratch,
                        macs_big_cap(a.d.W, a.d.n_max), lpw);

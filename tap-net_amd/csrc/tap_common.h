@@ -233,6 +233,7 @@ inline int tap_group_size(const tap_env_desc *d)
 // the same by-products from a launch of their own, for the steps that run as two launches (transition.hip)
 int tap_step_aux_launch(tap_ctx *ctx, const StepArgs &s, hipStream_t st);
 int tap_macs_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st);                                             // macs_big.hip
+int tap_macs_wave_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st);                                            // macs_big.hip
 int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st);                                            // macs3_big.hip
 int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st);                                      // big.hip
 int tap_big_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, int flen, hipStream_t st);   // big.hip
