@@ -162,13 +162,13 @@ int tap_desc_validate(tap_ctx *ctx, const tap_env_desc *d)
         (d->D == 2 && d->L != 1))
         return tap_fail(ctx, TAP_E_INVALID, "bad descriptor B=%d D=%d W=%d L=%d H=%d n=%d", d->B,
                         d->D, d->W, d->L, d->H, d->n_max);
-    if (tap_is_big(d)) {                                           // one thread per container (big.hip)
+    if (tap_is_big(d)) {                                           // one wavefront per container (big.hip)
         if (d->W * d->L > 4096) return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 4096", d->W * d->L);
     } else if (d->strategy == TAP_LB) {                            // one thread per container (lb.hip)
         if (d->W > 248 || (d->D == 3 && d->L > 248)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "legacy LB: side > 248");
-    } else if (tap_is_big_macs(d)) {                               // one thread per container (macs_big.hip)
+    } else if (tap_is_big_macs(d)) {                               // one wavefront per container (macs_big.hip)
         if (d->W > 4096) return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 2D: W = %d columns > 4096", d->W);
-    } else if (tap_is_big_macs3(d)) {                              // one thread per container (macs3_big.hip)
+    } else if (tap_is_big_macs3(d)) {                              // one wavefront per container (macs3_big.hip)
         if (d->W > 64 || d->L > 64) return tap_fail(ctx, TAP_E_UNSUPPORTED, "MACS / MUL 3D: side > 64 (rows are 64-bit masks)");
     } else if (tap_group_size(d) == 0) {
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "W*L = %d cells > 64 lanes per container", d->W * d->L);

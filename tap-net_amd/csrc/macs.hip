@@ -166,7 +166,7 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
     int rc = tap_macs_validate(ctx, a.d);
     if (rc) return rc;
     if (a.d.D == 3) {
-        if (tap_is_big_macs3(&a.d)) return tap_macs3_big_step(ctx, a, st);  // one thread per container (macs3_big.hip)
+        if (tap_is_big_macs3(&a.d)) return tap_macs3_big_step(ctx, a, st);  // one wavefront per container (macs3_big.hip)
         switch (tap_group_size(&a.d)) {
         case 8: return launch_macs3<8>(ctx, a, st);
         case 16: return launch_macs3<16>(ctx, a, st);

@@ -50,14 +50,14 @@ class BatchedContainer(object):
     @property
     def fused_ok(self):
         """False for the shapes / strategies whose step is not ONE kernel: the legacy 'LB' strategy, LB_GREEDY
-        and MACS 3D containers above 64 cells or with a 3D side above 8 (one thread per container, lb.hip / big.hip /
+        and MACS 3D containers above 64 cells or with a 3D side above 8 (one wavefront -- legacy 'LB': one thread -- per container, lb.hip / big.hip /
         macs3_big.hip) and MACS 2D
         containers above 16 columns (a single kernel was measured slower than the two launches there).
         tap_transition* / tap_rolling_step take them all the same and run the two launches themselves."""
         d = self.desc
         over = d.W * d.L > 64 or (d.D == 3 and (d.W > 8 or d.L > 8))
         big = over and (d.strategy == _lib.TAP_LB_GREEDY or (d.strategy == _lib.TAP_MACS and d.D == 3))   # big.hip / macs3_big.hip
-        wide_macs = d.strategy == _lib.TAP_MACS and d.D == 2 and d.W > 16           # above 64 columns: one thread per container
+        wide_macs = d.strategy == _lib.TAP_MACS and d.D == 2 and d.W > 16           # above 32 columns: one wavefront per container
         return not (big or wide_macs or d.strategy == _lib.TAP_LB)
 
     # ---- plumbing ---------------------------------------------------------------------------
