@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
     s.rows = s.occ + (size_t)cells * HW;
     s.ems = reinterpret_cast<M3BEms *>(s.rows + 64);
     s.hm = reinterpret_cast<int32_t *>(s.ems + cap);
-    s.lev = s.hm + cells; s.slots = s.lev + cells; s.lvh = s.slots + cells; s.lvr = s.lvh + a.d.n_max + 2;
+    s.lev = s.hm + cells; s.slots = s.lev + cells; s.pxy = s.slots + cells; s.bs = s.pxy + cells; s.be = s.bs + 64;
     s.pos = a.v.pos + env; s.blk = a.v.blk + env; s.hs = (size_t)B;
     int32_t *ghm = a.v.hm + (size_t)env * cells;
     m3b_u64 *gocc = a.v.occ + (size_t)env * cells * HW;
@@ -170,3 +170,12 @@ int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
     if (a.feature_out) return tap_big_feature(ctx, &a.d, a.v, a.feature_out, a.flen, st);   // tools.py:3716-3744
     return TAP_OK;
 }
+
+#ifdef M3W_PROF
+extern "C" int tap_m3w_prof_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(m3w_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(m3w_prof), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

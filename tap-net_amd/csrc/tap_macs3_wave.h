@@ -17,13 +17,20 @@
 #include "tap_place.h"
 #include "tap_macs3_big.h"
 
+#ifdef M3W_PROF     // scratch builds only: cycles per phase of m3w_place, summed over wavefronts (scripts/m3w_phases.py)
+__device__ unsigned long long m3w_prof[8];
+#define M3W_T(k) do { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m3w_prof[k], (unsigned long long)(t_ - t0_)); t0_ = t_; } while (0)
+#else
+#define M3W_T(k) do { } while (0)
+#endif
+
 struct M3WTile {                    // pointers into the wave's LDS slice
     int W, L, H, HW, flags, cap, step, n_max;
     int32_t *hm;                    // [cells]
     m3b_u64 *occ;                   // [cells][HW]
     M3BEms *ems;                    // [cap]
-    int32_t *lev, *slots;           // [cells] each
-    int32_t *lvh, *lvr;             // [n_max + 2]
+    int32_t *lev, *slots, *pxy;     // [cells] each; pxy[p] = px | py << 8 of position p = py * W + px (no division in the walks)
+    int32_t *bs, *be;               // [64] each: m3w_side_tables' maxima by first / last row
     m3b_u64 *rows;                  // [64] scratch of the rectangle searches
     const int32_t *pos, *blk;       // history in global memory: entry i, coordinate k at [(i*3 + k) * hs]
     size_t hs;
@@ -32,7 +39,7 @@ struct M3WTile {                    // pointers into the wave's LDS slice
 // 8-byte units of one container's tile
 __host__ __device__ inline size_t m3w_tile_u64(int cells, int HW, int n_max, int cap)
 {
-    return (size_t)cells * HW + 64 + (size_t)cap + ((size_t)3 * cells + 2 * (n_max + 2) + 1) / 2;
+    return (size_t)cells * HW + 64 + (size_t)cap + ((size_t)4 * cells + 128) / 2;
 }
 
 __device__ __forceinline__ m3b_u64 m3w_or64(m3b_u64 v)
@@ -91,29 +98,60 @@ __device__ inline void m3w_scan(const M3WTile &s, int x, int y, int bx, int by, 
             else if (h == mx) eq |= bit;
         }
 }
-// largest all-free rectangle at level h, the footprint counted as filled when fbx > 0: lane x builds row x, lane i1
-// searches the rectangles whose first row is i1 (every lane must call)
-__device__ inline int m3w_maxrect(const M3WTile &s, int h, int fx, int fy, int fbx, int fby, int lane)
+// The tie-break's per-level tables.  A free rectangle that avoids a (filled) footprint lies wholly on one side of it, so
+//   max rectangle at level h with footprint [px, px+bx) x [py, py+by) filled
+//     = max( best within rows [0, px), best within rows [px+bx, n), and the same two over the other axis ),
+// whether or not the footprint's cells were free.  For one axis: rows r[i] (i < n) are masks over the other axis of the
+// cells with hm <= h; the (first row, last row) pairs are dealt one per lane -- (q1, q2) = (lane / n, lane % n) is the
+// caller's -- and each pair's area (rows x longest common run) is maxed into bs[first] and be[last]; on return lane a
+// holds PL = best rectangle within rows [0, a) and PR = best within rows [a, n) (0 from lane n on).  Every lane calls.
+__device__ inline void m3w_side_tables(const M3WTile &s, int h, int n, bool over_y, int lane, int q1, int q2, int &PL, int &PR)
 {
-    const int W = s.W, L = s.L;
+    const int L = s.L, m = over_y ? s.W : s.L;                                    // bits per row
     tap_wave_lds_sync();
-    if (lane < W) {
+    if (lane < n) {
         m3b_u64 r = 0;
-        for (int y = 0; y < L; ++y) r |= (m3b_u64)(s.hm[lane * L + y] <= h) << y;
-        if (fbx > 0 && lane >= fx && lane < fx + fbx) r &= ~m3b_bits(fy, fy + fby - 1);
+        for (int b0 = 0; b0 < m; b0 += 8) {                                        // eight loads in flight (a repeated cell sets the same bit)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int b = min(b0 + j, m - 1);
+                r |= (m3b_u64)(s.hm[over_y ? b * L + lane : lane * L + b] <= h) << b;
+            }
+        }
         s.rows[lane] = r;
     }
+    s.bs[lane] = 0; s.be[lane] = 0;
     tap_wave_lds_sync();
-    int best = 0;
-    if (lane < W) {
-        m3b_u64 acc = ~0ull;
-        for (int i2 = lane; i2 < W; ++i2) {
-            acc &= s.rows[i2];
-            if (!acc) break;
-            best = max(best, (i2 - lane + 1) * m3b_longest_run(acc));
+    const int d1 = 64 / n, d2 = 64 - d1 * n;
+    for (int idx = lane; idx < n * n; idx += 64) {
+        if (q2 >= q1) {
+            m3b_u64 acc = ~0ull;                                                   // unconditional loads (a repeated row changes nothing)
+            if (n <= 12) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) acc &= s.rows[min(q1 + i, q2)];
+            } else if (n <= 24) {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) acc &= s.rows[min(q1 + i, q2)];
+            } else {
+                for (int i = q1; i <= q2 && acc; ++i) acc &= s.rows[i];
+            }
+            const int area = (q2 - q1 + 1) * m3b_longest_run(acc);
+            if (area > 0) { atomicMax(&s.bs[q1], area); atomicMax(&s.be[q2], area); }
         }
+        q1 += d1; q2 += d2;
+        if (q2 >= n) { q2 -= n; ++q1; }
     }
-    return m3w_max(best);
+    tap_wave_lds_sync();
+    int e = lane < n ? s.be[lane] : 0, b = lane < n ? s.bs[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int te = __shfl_up(e, o), tb = __shfl_down(b, o);
+        if (lane >= o) e = max(e, te);
+        if (lane + o < 64) b = max(b, tb);
+    }
+    e = __shfl_up(e, 1);
+    PL = lane == 0 ? 0 : e;
+    PR = b;
 }
 
 // One placement; every lane of the wavefront calls it with the same arguments and gets the same result.  cnt / err as
@@ -124,6 +162,10 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
     const bool hard = s.flags & M3B_F_HARD;
     M3BResult res = {0, 0, 0, 0, 0};
     int n_ems = 0;
+    const int q1 = lane / W, q2 = lane - q1 * W, q1y = lane / L, q2y = lane - q1y * L;   // m3w_side_tables' pairs of this lane
+#ifdef M3W_PROF
+    long long t0_ = __builtin_readcyclecounter();
+#endif
     int sx1 = 0;              // python's function-scope `x1` (tools.py:2823, 2870, 2901 assign it) ...
     bool x1def = false;       // ... which :2865 may read before any assignment (UnboundLocalError)
 #define M3W_PUSH(x1_, y1_, z_, x2_, y2_)                                                                   \
@@ -187,6 +229,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         }
     }
 
+    M3W_T(0);
     // ---- (b) spaces next to and on top of the blocks placed so far (tools.py:2843-2942); a block that could not be
     //      placed sits at (0,0,0) in `positions` and is visited all the same
     for (int bi = 0; bi < step; ++bi) {
@@ -273,6 +316,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         }
     }
 
+    M3W_T(1);
     // ---- the four corner walks of every EMS (tools.py:3080-3115) ------------------------------------------------
     const int X = W - bx + 1, Y = L - by + 1;
     for (int p = lane; p < cells; p += 64) {                                       // position p = py * W + px, one per lane
@@ -285,30 +329,28 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
             if (st || !hard) v = (mp << 2) | (st << 1);                            // :2963-2965
         }
         s.lev[p] = v;
+        s.pxy[p] = px | (py << 8);
     }
     tap_wave_lds_sync();
+    M3W_T(2);
     int n_slots = 0;
     // one walk: the first position, in the walk's own order, of its rectangle that settles at Z and is not taken; ORDER
     // 0: x up then y up; 1: y up then x down; 2: x down then y down; 3: y down then x up
     auto walk = [&](int order, int xa, int xb, int ya, int yb, int Z) {            // rectangle [xa, xb) x [ya, yb)
-        int best = INT_MAX;
+        int best = INT_MAX;                                                        // rank << 12 | position (cells <= 4096)
         for (int p = lane; p < cells; p += 64) {
             const int v = s.lev[p];
             if (v < 0 || (v & 1) || (v >> 2) != Z) continue;
-            const int py = p / W, px = p - py * W;
+            const int q = s.pxy[p], px = q & 255, py = q >> 8;
             if (px < xa || px >= xb || py < ya || py >= yb) continue;
             const int rank = order == 0 ? px * L + py : order == 1 ? py * W + (W - 1 - px)
                            : order == 2 ? (W - 1 - px) * L + (L - 1 - py) : (L - 1 - py) * W + px;
-            best = min(best, rank);
+            best = min(best, (rank << 12) | p);
         }
         best = m3w_min(best);
         if (best == INT_MAX) return;
-        int px, py;
-        if (order == 0) { px = best / L; py = best - px * L; }
-        else if (order == 1) { py = best / W; px = W - 1 - (best - py * W); }
-        else if (order == 2) { const int a_ = best / L; px = W - 1 - a_; py = L - 1 - (best - a_ * L); }
-        else { const int a_ = best / W; py = L - 1 - a_; px = best - a_ * W; }
-        if (lane == 0) { s.lev[py * W + px] |= 1; s.slots[n_slots] = px | (py << 8); }
+        const int p = best & 4095, q = s.pxy[p];
+        if (lane == 0) { s.lev[p] |= 1; s.slots[n_slots] = q; }
         ++n_slots;
         tap_wave_lds_sync();
     };
@@ -322,6 +364,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         if (X1 < X && yr > 0) walk(3, X1, X, 0, yr, Z);                            // :3109 y down, then x up
     }
 
+    M3W_T(3);
     // ---- score the settled positions (tools.py:2973-2987), pick (:3118-3148) -----------------------------------
     if (n_slots == 0) return res;                                                  // :3118-3121
     int gmax = 0;
@@ -330,7 +373,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
     const int vol = bx * by * bz, valid2 = cnt[0] + vol;
     const bool tiebreak = s.flags & M3B_F_TIE, zero = s.flags & M3B_F_ZERO;
     auto score = [&](int sl, int &px, int &py, int &mp, int &st, int &emp) -> double {
-        px = s.slots[sl] & 255; py = s.slots[sl] >> 8;
+        px = s.slots[sl] & 255; py = (s.slots[sl] >> 8) & 255;
         int sum; m3b_u64 eq;
         m3w_scan(s, px, py, bx, by, mp, eq, sum);
         st = (s.lev[py * W + px] >> 1) & 1;
@@ -364,53 +407,62 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         const int sl = s0 + lane;
         bool tie = false;
         if (sl < n_slots) { int px, py, mp, st, emp; tie = score(sl, px, py, mp, st, emp) == rmax; }
+        if (tie) s.slots[sl] |= 0x10000;                                           // marks the tie-break's candidates
         n_tied += __popcll(__ballot(tie));
     }
+    M3W_T(4);
     const int nt = zero ? 4 * n_ems : n_tied;            // len(best_ems_indexes): unsettled entries score 0.0
     if (tiebreak && nt > 1) {                                                      // :3132-3144
         // calc_maximal_usable_spaces = sum over levels h < max_height of the largest free rectangle; above max(hm') a
-        // level is all free, so candidates are ordered by  sum_{h < max(hm')} rect(h) - max(hm') * W * L  (tap_macs3.h)
+        // level is all free, so candidates are ordered by  sum_{h < max(hm')} rect(h) - max(hm') * W * L  (tap_macs3.h).
+        // Levels = 0 and the distinct heights, ascending; per level ONE set of side tables serves every candidate, the
+        // candidates sit one per lane.
         if (max_height > H) err |= 1;                                              // container[:, :, h] IndexError
-        int nl = 1;                                                                // level 0 and the distinct heights above it, ascending
-        {
-            const int r0 = m3w_maxrect(s, 0, 0, 0, 0, 0, lane);
-            if (lane == 0) { s.lvh[0] = 0; s.lvr[0] = r0; }
-        }
-        for (int last = 0;;) {
-            int nxt = 0x7fffffff;
-            for (int c = lane; c < cells; c += 64) { const int hc = s.hm[c]; if (hc > last && hc < nxt) nxt = hc; }
-            nxt = m3w_min(nxt);
-            if (nxt == 0x7fffffff) break;
-            const int rr = m3w_maxrect(s, nxt, 0, 0, 0, 0, lane);
-            if (lane == 0) { s.lvh[nl] = nxt; s.lvr[nl] = rr; }
-            ++nl;
-            last = nxt;
-        }
-        tap_wave_lds_sync();
         long best_adj = 0;
         win = -1;
-        for (int sl = 0; sl < n_slots; ++sl) {                                     // wave-uniform: the tied slots in list order
-            int px, py, mp, st, emp;
-            if (score(sl, px, py, mp, st, emp) != rmax) continue;
+        for (int s0 = 0; s0 < n_slots; s0 += 64) {                                 // candidates in list order, 64 at a time
+            const int sl = s0 + lane;
+            const int q = sl < n_slots ? s.slots[sl] : 0;
+            const bool mine = (q & 0x10000) != 0;
+            if (__ballot(mine) == 0ull) continue;
+            const int px = q & 255, py = (q >> 8) & 255;
+            const int mp = mine ? s.lev[py * W + px] >> 2 : 0;
             const int Zt = mp + bz, M = max(gmax, Zt);
+            const int Mtop = m3w_max(mine ? M : 0);
             long base = 0;
-            for (int k = 0; k < nl; ++k) {
-                const int lo = s.lvh[k];
-                if (lo >= M) break;
-                const int hi = min(M, k + 1 < nl ? s.lvh[k + 1] : 0x7fffffff);
-                const int a_hi = min(hi, Zt), b_lo = max(lo, Zt);
-                if (a_hi > lo) {                                                   // below the block's top: its footprint is filled
-                    bool touches = false;
-                    for (int i = 0; i < bx && !touches; ++i) for (int j = 0; j < by; ++j) if (s.hm[(px + i) * L + py + j] <= lo) { touches = true; break; }
-                    base += (long)(a_hi - lo) * (touches ? m3w_maxrect(s, lo, px, py, bx, by, lane) : s.lvr[k]);
+            for (int lo = 0; lo < Mtop;) {
+                int nxt = INT_MAX;
+                for (int c = lane; c < cells; c += 64) { const int hc = s.hm[c]; if (hc > lo && hc < nxt) nxt = hc; }
+                nxt = m3w_min(nxt);
+                int PLx, PRx, PLy, PRy;
+                m3w_side_tables(s, lo, W, false, lane, q1, q2, PLx, PRx);
+                m3w_side_tables(s, lo, L, true, lane, q1y, q2y, PLy, PRy);
+                const int full = __shfl(PRx, 0);
+                int r = max(__shfl(PLx, px), __shfl(PLy, py));
+                const int rx = __shfl(PRx, min(px + bx, 63)), ry = __shfl(PRy, min(py + by, 63));
+                if (px + bx < W) r = max(r, rx);
+                if (py + by < L) r = max(r, ry);
+                if (mine && lo < M) {
+                    const int hi = min(M, nxt), a_hi = min(hi, Zt), b_lo = max(lo, Zt);
+                    if (a_hi > lo) base += (long)(a_hi - lo) * r;                  // below the block's top: its footprint is filled
+                    if (hi > b_lo) base += (long)(hi - b_lo) * full;
                 }
-                if (hi > b_lo) base += (long)(hi - b_lo) * s.lvr[k];
+                if (nxt == INT_MAX) break;
+                lo = nxt;
             }
-            const long adj = base - (long)M * cells;
-            if (win < 0 || adj > best_adj) { best_adj = adj; win = sl; }
+            long adj = mine ? base - (long)M * cells : LONG_MIN;
+            int wsl = mine ? sl : INT_MAX;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const long a2 = ((long)__shfl_xor((int)(adj >> 32), o) << 32) | (unsigned)__shfl_xor((int)adj, o);
+                const int w2 = __shfl_xor(wsl, o);
+                if (a2 > adj || (a2 == adj && w2 < wsl)) { adj = a2; wsl = w2; }
+            }
+            if (win < 0 || adj > best_adj) { best_adj = adj; win = wsl; }
         }
     }
 
+    M3W_T(5);
     // ---- commit (tools.py:3150-3163): every lane makes the same (idempotent) writes ----------------------------------
     {
         int px, py, Z, st, emp;
@@ -441,6 +493,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         cnt[2] += st;
         if (Z + bz > H) err |= 1;                                                  // level_free_space[zz] IndexError
     }
+    M3W_T(6);
 #undef M3W_PUSH
     return res;
 }
