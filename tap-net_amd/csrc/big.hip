@@ -252,8 +252,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
     if (act && do_step && ((D == 3 && (bx > 8 || by > 8) && bx <= W && by <= L) || (D == 2 && bx > 64 && bx <= W))) {
         err |= 4; do_step = false;                                               // footprint beyond the support masks
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gmax = max(gmax, __shfl_xor(gmax, o));
+    gmax = group_max<64>(gmax);
     tap_wave_lds_sync();
     if (do_step) {                                                               // wave-uniform
         const BigCtx c = {D, W, L, a.d.H, a.d.flags, a.lut, hm, nullptr};
@@ -315,8 +314,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
             for (;;) {
                 int kmin = INT_MAX;
                 for (int cell = lane; cell < cells; cell += 64) { const int k = keys[cell]; if (k > last && k < kmin) kmin = k; }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, __shfl_xor(kmin, o));
+                kmin = group_min<64>(kmin);
                 if (kmin == INT_MAX) break;
                 last = kmin;
                 const int X0 = kmin % W;
@@ -329,8 +327,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
                     const int ms = pms[cell];
                     if (x >= X0 && y >= Y0 && ms == ((z << 1) | 1) && cell < first) first = cell;   // ms < 0: out of bounds or taken
                 }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o));
+                first = group_min<64>(first);
                 if (first == INT_MAX) continue;
                 if (lane == 0) pms[first] = -2;                                  // settled: no later walk stops here
                 const int sx = first / L, sy = first - sx * L, semp = cnt.empty + bx * by * z - psum[first];
@@ -346,8 +343,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
         const int pxy = __shfl(bxy, src), pz = __shfl(bzv, src), pstab = __shfl(bstab, src), pemp = __shfl(bemp, src);
         const int px = pxy & 4095, py = pxy >> 12;
         unsigned eall = (unsigned)err;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) eall |= (unsigned)__shfl_xor((int)eall, o);
+        eall = (unsigned)group_or<64>((int)eall);
         err = (int)eall;
         tap_wave_lds_sync();
         if (placed) {                                                            // tools.py:2167-2174
@@ -388,8 +384,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
             if (a.d.feature == TAP_FEAT_ZERO) {
                 mn = INT_MAX;
                 for (int c = lane; c < cells; c += 64) mn = min(mn, hm[c]);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mn = min(mn, __shfl_xor(mn, o));
+                mn = group_min<64>(mn);
             }
             for (int c = lane; c < cells; c += 64) out[c] = (float)(hm[c] - mn);
         }

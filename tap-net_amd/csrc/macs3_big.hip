@@ -97,10 +97,15 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
     s.ems = reinterpret_cast<M3BEms *>(s.rows + 64);
     s.hm = reinterpret_cast<int32_t *>(s.ems + cap);
     s.lev = s.hm + cells; s.slots = s.lev + cells; s.pxy = s.slots + cells; s.bs = s.pxy + cells; s.be = s.bs + 64;
-    s.pos = a.v.pos + env; s.blk = a.v.blk + env; s.hs = (size_t)B;
+    int32_t *hpos = s.be + 64, *hblk = hpos + 3 * a.d.n_max;                    // the history so far, one round trip for all of it
+    s.pos = hpos; s.blk = hblk; s.hs = 1;
     int32_t *ghm = a.v.hm + (size_t)env * cells;
     m3b_u64 *gocc = a.v.occ + (size_t)env * cells * HW;
     for (int c = lane; c < cells; c += 64) s.hm[c] = ghm[c];
+    {
+        const int nh = 3 * min(reinterpret_cast<const int4 *>(a.v.cnt)[env].w, a.d.n_max);
+        for (int k = lane; k < nh; k += 64) { hpos[k] = a.v.pos[(size_t)k * B + env]; hblk[k] = a.v.blk[(size_t)k * B + env]; }
+    }
     for (int k = lane; k < cells * HW; k += 64) s.occ[k] = gocc[k];
     int bx, by, bz;
     if (a.static_) {                                                             // model.py:404-412

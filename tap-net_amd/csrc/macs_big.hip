@@ -272,8 +272,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32
 // Tile (ints): hm[W] | lev[W] | psum[W] | slots[W] | ems[2 cap]
 __host__ __device__ inline size_t macs_wave_tile_ints(int W, int cap) { return (size_t)4 * W + (size_t)2 * cap; }
 
-__device__ __forceinline__ int mw_min(int v) { for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int mw_max(int v) { for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o)); return v; }
+__device__ __forceinline__ int mw_min(int v) { return group_min<64>(v); }     // DPP + readlane (tap_place.h): all 64 lanes call
+__device__ __forceinline__ int mw_max(int v) { return group_max<64>(v); }
 __device__ __forceinline__ long mw_sum(long v)
 {
     for (int o = 32; o > 0; o >>= 1) v += ((long)__shfl_xor((int)(v >> 32), o) << 32) | (unsigned)__shfl_xor((int)v, o);

@@ -32,34 +32,28 @@ struct M3WTile {                    // pointers into the wave's LDS slice
     int32_t *lev, *slots, *pxy;     // [cells] each; pxy[p] = px | py << 8 of position p = py * W + px (no division in the walks)
     int32_t *bs, *be;               // [64] each: m3w_side_tables' maxima by first / last row
     m3b_u64 *rows;                  // [64] scratch of the rectangle searches
-    const int32_t *pos, *blk;       // history in global memory: entry i, coordinate k at [(i*3 + k) * hs]
+    const int32_t *pos, *blk;       // history (staged in the tile by the kernel: hs = 1): entry i, coordinate k at [(i*3 + k) * hs]
     size_t hs;
 };
 
 // 8-byte units of one container's tile
 __host__ __device__ inline size_t m3w_tile_u64(int cells, int HW, int n_max, int cap)
 {
-    return (size_t)cells * HW + 64 + (size_t)cap + ((size_t)4 * cells + 128) / 2;
+    return (size_t)cells * HW + 64 + (size_t)cap + ((size_t)4 * cells + 128 + 6 * (size_t)n_max + 1) / 2;
 }
 
 __device__ __forceinline__ m3b_u64 m3w_or64(m3b_u64 v)
 {
-    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { lo |= (unsigned)__shfl_xor((int)lo, o); hi |= (unsigned)__shfl_xor((int)hi, o); }
+    const unsigned lo = (unsigned)group_or<64>((int)(unsigned)v), hi = (unsigned)group_or<64>((int)(unsigned)(v >> 32));   // DPP + readlane (tap_place.h)
     return ((m3b_u64)hi << 32) | lo;
 }
 __device__ __forceinline__ int m3w_min(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    return v;
+    return group_min<64>(v);
 }
 __device__ __forceinline__ int m3w_max(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-    return v;
+    return group_max<64>(v);
 }
 
 // container[:, y, z] == 0 / the free-list row (z, y) as masks over x: one ballot (every lane must call)
@@ -125,15 +119,10 @@ __device__ inline void m3w_side_tables(const M3WTile &s, int h, int n, bool over
     const int d1 = 64 / n, d2 = 64 - d1 * n;
     for (int idx = lane; idx < n * n; idx += 64) {
         if (q2 >= q1) {
-            m3b_u64 acc = ~0ull;                                                   // unconditional loads (a repeated row changes nothing)
-            if (n <= 12) {
+            m3b_u64 acc = ~0ull;
+            for (int i0 = q1; i0 <= q2 && acc; i0 += 4) {                          // four loads in flight (a repeated row changes nothing)
 #pragma unroll
-                for (int i = 0; i < 12; ++i) acc &= s.rows[min(q1 + i, q2)];
-            } else if (n <= 24) {
-#pragma unroll
-                for (int i = 0; i < 24; ++i) acc &= s.rows[min(q1 + i, q2)];
-            } else {
-                for (int i = q1; i <= q2 && acc; ++i) acc &= s.rows[i];
+                for (int i = 0; i < 4; ++i) acc &= s.rows[min(i0 + i, q2)];
             }
             const int area = (q2 - q1 + 1) * m3b_longest_run(acc);
             if (area > 0) { atomicMax(&s.bs[q1], area); atomicMax(&s.be[q2], area); }
@@ -331,6 +320,12 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         s.lev[p] = v;
         s.pxy[p] = px | (py << 8);
     }
+    for (int w = 0; w < HW; ++w) {                                                 // levels at which some position settles: an EMS
+        m3b_u64 mine = 0;                                                          // at any other level walks to nothing
+        for (int p = lane; p < cells; p += 64) { const int v = s.lev[p]; if (v >= 0 && (v >> 8) == w) mine |= 1ull << ((v >> 2) & 63); }
+        mine = m3w_or64(mine);
+        if (lane == 0) s.rows[w] = mine;
+    }
     tap_wave_lds_sync();
     M3W_T(2);
     int n_slots = 0;
@@ -356,6 +351,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
     };
     for (int e = 0; e < n_ems; ++e) {
         const int xy = s.ems[e].xy, Z = s.ems[e].z;
+        if (Z < 0 || Z >= H || !((s.rows[Z >> 6] >> (Z & 63)) & 1ull)) continue;
         const int X1 = xy & 255, Y1 = (xy >> 8) & 255, X2 = (xy >> 16) & 255, Y2 = (xy >> 24) & 255;
         const int xr = X2 - bx + 2, yr = Y2 - by + 2;                              // exclusive ends of the reversed ranges
         if (X1 < X && Y1 < Y) walk(0, X1, X, Y1, Y, Z);                            // :3085 x up, then y up
