@@ -8,7 +8,9 @@
 //   * the position table (settling level, stable) is filled one position per lane;
 //   * each corner walk is a wave-wide minimum of an order rank over the positions that settle at the space's level;
 //   * settled positions are scored one per lane, the first maximum by a lexicographic reduction;
-//   * the tie-break's largest-rectangle searches give every lane one first row (tools.py:3049-3077);
+//   * the tie-break (tools.py:3049-3077) tabulates, per level, the best free rectangle on either side of every row and
+//     column boundary from one pass over the (first row, last row) pairs, one pair per lane (m3w_side_tables); the tied
+//     candidates then sit one per lane and read the four sides of their footprint from those tables;
 //   * "append if absent" compares a candidate with one list entry per lane.
 // The container's working set lives in the wave's LDS tile (M3WTile).  W, L <= 64; footprints <= 8 x 8.
 #pragma once
