@@ -113,7 +113,7 @@ int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream
 /* tools.Container.add_new_block for all B envs (tools.py:3663-3744 -> calc_one_position_lb_greedy
  * 2027-2351, is_stable_2d 839-868, is_stable 710-765; with strategy TAP_MACS ->
  * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 4096, H <= 4096 -- lane-per-column
- * kernels up to 32 columns, one wavefront per container above; 3D: W, L <= 64, H <= 4096 -- lane-per-cell kernel up to
+ * kernels up to 16 columns, one wavefront per container above; 3D: W, L <= 64, H <= 4096 -- lane-per-cell kernel up to
  * 64 cells with sides <= 8, one wavefront per container above (block footprints <= 8 x 8 there); block sides <=
  * container sides, else error bit 4); model.py:451-465 is the loop it replaces).
  *   blocks      (B, D) TAP_DT_F32 | TAP_DT_I32, one block per env; f32 is truncated like

@@ -42,8 +42,10 @@ t0 = time.time(); total = 0; nbad = 0; nflag_mismatch = 0; noracle_err = 0
 fam = {}
 cases = []
 only = os.environ.get("STRESS_ONLY_MOD20")          # e.g. "2,3": only the seeds with these residues mod 20
+only25 = os.environ.get("STRESS_ONLY_MOD25")        # e.g. "1,6": only the seeds with these residues mod 25 (the wide MACS 2D cases)
 for seed in range(int(sys.argv[1])):
     if only and str(seed % 20) not in only.split(","): continue
+    if only25 and str(seed % 25) not in only25.split(","): continue
     rs = np.random.RandomState(1000 + seed)
     kind = seed % 5
     if kind == 4:    # legacy LB, 2D and 3D (voxel-level kernel)
@@ -97,7 +99,7 @@ for seed in range(int(sys.argv[1])):
         nflag_mismatch += int(fl != ne)
         print("CASE", cs, n, reward, strat, "hi", hi, "mismatch", b, "oracle-err", ne, "flagged", fl)
 import json
-summary = dict(script="scripts/stress_parity.py", configurations=sum(f["configurations"] for f in fam.values()), seeds=int(sys.argv[1]), only_seeds_mod_20=only, envs_per_configuration=2048, env_steps=total,
+summary = dict(script="scripts/stress_parity.py", configurations=sum(f["configurations"] for f in fam.values()), seeds=int(sys.argv[1]), only_seeds_mod_20=only, only_seeds_mod_25=only25, envs_per_configuration=2048, env_steps=total,
                mismatching_envs=nbad, envs_where_the_reference_raises=noracle_err,
                configurations_with_a_different_flagged_count=nflag_mismatch, families=fam, seconds=round(time.time() - t0, 1),
                compared="positions, stable flags, final height-map, fp64 calc_ratio (bit pattern) per env; flagged-container count")

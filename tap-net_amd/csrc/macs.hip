@@ -175,10 +175,11 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
         }
     }
     if (a.d.W > 64) return tap_macs_big_step(ctx, a, st);              // one wavefront per container (macs_big.hip)
-    {   // above 32 columns the wave-per-container kernel of macs_big.hip beats the 64-lane form of tap_macs_wide.h (eager
-        // steps at B = 4096, n = 20: W = 40 130 against 356 us, W = 64 174 against 1 473 us; W = 32 112 against 119, W = 20
-        // 77 against 61); TAP_MACS2D_WAVE_FROM=W moves the hand-over for A/B runs
-        static const int from = [] { const char *e = getenv("TAP_MACS2D_WAVE_FROM"); return e ? atoi(e) : 33; }();
+    {   // above 16 columns the wave-per-container kernel of macs_big.hip beats the 32- and 64-lane forms of
+        // tap_macs_wide.h, which stay as its fallback when a tile does not fit the LDS (eager steps, n = 10: at B = 4096
+        // W = 17 35 against 48 us, W = 32 35 against 120; at B = 65 536 W = 17 282 against 304, W = 32 281 against 1 696;
+        // W = 16 35.5 against 33.4 on the lane kernel); TAP_MACS2D_WAVE_FROM=W moves the hand-over for A/B runs
+        static const int from = [] { const char *e = getenv("TAP_MACS2D_WAVE_FROM"); return e ? atoi(e) : 17; }();
         if (a.d.W >= from && tap_macs_wave_step(ctx, a, st) == TAP_OK) return TAP_OK;
     }
     if (a.d.W > 32) return launch_macs_wide<64>(ctx, a, st);

@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32
 // computed one position per lane once per step (a position settles at Z iff the maximum under it IS Z, so `visited`
 // is one flag per position), a corner walk is a wave-wide min / max over the settling positions of its range, the slots
 // are scored one per lane and the usable-space score of a tied slot sums one column per lane.
-// Tile (ints): hm[W] | lev[W] | psum[W] | slots[W] | ems[2 cap]
-__host__ __device__ inline size_t macs_wave_tile_ints(int W, int cap) { return (size_t)4 * W + (size_t)2 * cap; }
+// Tile (ints): hm[W] | lev[W] | psum[W] | slots[W] | tl[W + 1] | tr[W + 1] | ems[2 cap]
+__host__ __device__ inline size_t macs_wave_tile_ints(int W, int cap) { return (size_t)6 * W + 2 + (size_t)2 * cap; }
 
 __device__ __forceinline__ int mw_min(int v) { return group_min<64>(v); }     // DPP + readlane (tap_place.h): all 64 lanes call
 __device__ __forceinline__ int mw_max(int v) { return group_max<64>(v); }
@@ -289,7 +289,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
     if (env >= B) return;                                                         // wave-uniform
     int32_t *hm = mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(W, cap);
     int32_t *lev = hm + W, *psum = lev + W, *slots = psum + W;
-    int2 *ems = reinterpret_cast<int2 *>(slots + W);
+    int32_t *tl = slots + W, *tr = tl + W + 1;                                  // the tie-break's per-level tables
+    int2 *ems = reinterpret_cast<int2 *>(tr + W + 1);
     int32_t *ghm = a.v.hm + (size_t)env * W;
     int gmax = 0;
     for (int k = lane; k < W; k += 64) { const int h = ghm[k]; hm[k] = h; gmax = max(gmax, h); }
@@ -445,7 +446,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
         const int valid2 = cnt.valid + vol;
         const bool tiebreak = (flags & TAP_F_MCS_TIE) != 0, zero = (flags & TAP_F_MCS_ZERO) != 0;
         auto eval_slot = [&](int s, int &xs, int &Z, int &sum, int &stab) -> double {
-            xs = slots[s];
+            xs = slots[s] & 0xffff;
             const int v = lev[xs];
             Z = v >> 2; stab = (v >> 1) & 1; sum = psum[xs];
             if (zero) return 0.0;
@@ -473,30 +474,85 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
         max_height = mw_max(max_height);
         if (n_slots == 0) win = -1;
         if (n_slots > 0 && tiebreak) {
-            long best_adj = 0;
             int n_tied = 0;
-            win = -1;
-            for (int s = 0; s < n_slots; ++s) {                                   // wave-uniform: the tied slots in list order
-                int xs, Z, sum, stab;
-                if (eval_slot(s, xs, Z, sum, stab) != rmax) continue;
-                ++n_tied;
-                // usable-space score of the candidate map (mb_adj), one column j per lane
-                const int top = Z + bz, m = max(gmax, Z + bz);
-                long base = 0;
-                for (int j = lane; j < W; j += 64) {
-                    const int v = (j >= xs && j < xs + bx) ? top : hm[j];
-                    bool first = true;
-                    int next = m, best_run = 0, run = -1;
-                    for (int k = 0; k < W; ++k) {
-                        const int hk = (k >= xs && k < xs + bx) ? top : hm[k];
-                        if (hk == v && k < j) first = false;
-                        if (hk > v) next = min(next, hk);
-                        if (hk <= v) { ++run; best_run = max(best_run, run); } else run = -1;
+            for (int s0 = 0; s0 < n_slots; s0 += 64) {
+                const int sl = s0 + lane;
+                bool tie = false;
+                if (sl < n_slots) { int xs, Z, sum, stab; tie = eval_slot(sl, xs, Z, sum, stab) == rmax; }
+                if (tie) slots[sl] |= 0x10000;                                    // marks the tie-break's candidates
+                n_tied += __popcll(__ballot(tie));
+            }
+            tap_wave_lds_sync();
+            // usable-space score of a candidate map (mb_adj) = sum over the levels h from its lowest column up to
+            // m = max(gmax, top) of (longest run of columns <= h) - 1, minus m (W - 1).  Below the block's top its
+            // footprint is filled, so the longest run lies left or right of it; from the top up the map is the old one.
+            // Per level of the OLD map ONE pair of tables -- tl[a] = longest free run within columns [0, a), tr[a] =
+            // within [a, W) -- serves every candidate; the candidates sit one per lane.
+            if (n_tied > 1) {
+                long best_adj = 0;
+                win = -1;
+                int hmin = INT_MAX;
+                for (int k = lane; k < W; k += 64) hmin = min(hmin, hm[k]);
+                hmin = mw_min(hmin);
+                const int nch = (W + 63) / 64;
+                for (int s0 = 0; s0 < n_slots; s0 += 64) {                        // candidates in list order, 64 at a time
+                    const int sl = s0 + lane;
+                    const int q = sl < n_slots ? slots[sl] : 0;
+                    const bool mine = (q & 0x10000) != 0;
+                    if (__ballot(mine) == 0ull) continue;
+                    const int xs = q & 0xffff;
+                    const int top = (mine ? lev[xs] >> 2 : 0) + bz, m = max(gmax, top);
+                    const int mtop = mw_max(mine ? m : 0);
+                    long base = 0;
+                    for (int lo = hmin;;) {
+                        int nxt = INT_MAX;
+                        for (int k = lane; k < W; k += 64) { const int h = hm[k]; if (h > lo && h < nxt) nxt = h; }
+                        nxt = mw_min(nxt);
+                        int ce = 0, cm = 0;                                       // run ending at the previous chunk's last column; best so far
+                        if (lane == 0) { tl[0] = 0; tr[W] = 0; }
+                        for (int ch = 0; ch < nch; ++ch) {
+                            const int k = ch * 64 + lane;
+                            const u64 le = __ballot(k < W && hm[min(k, W - 1)] <= lo);
+                            const u64 t = ~le << (63 - lane);
+                            int e = t == 0ull ? lane + 1 + ce : __clzll((long long)t);    // free columns ending at k
+                            const int e63 = __shfl(e, 63);
+                            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(e, o); if (lane >= o) e = max(e, u); }
+                            e = max(e, cm);
+                            if (k < W) tl[k + 1] = e;
+                            ce = e63; cm = __shfl(e, 63);
+                        }
+                        ce = 0; cm = 0;
+                        for (int ch = nch - 1; ch >= 0; --ch) {
+                            const int k = ch * 64 + lane;
+                            const u64 le = __ballot(k < W && hm[min(k, W - 1)] <= lo);
+                            const int c = __ffsll((long long)~(le >> lane)) - 1;  // free columns starting at k (zeros are shifted in: c <= 64 - lane)
+                            int e = (lane == 0 && le == ~0ull) ? 64 + ce : (c == 64 - lane ? c + ce : c);
+                            const int e0 = __shfl(e, 0);
+                            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_down(e, o); if (lane + o < 64) e = max(e, u); }
+                            e = max(e, cm);
+                            if (k < W) tr[k] = e;
+                            ce = e0; cm = __shfl(e, 0);
+                        }
+                        tap_wave_lds_sync();
+                        if (mine && lo < m) {
+                            const int hi = min(nxt, m), a_hi = min(hi, top), b_lo = max(lo, top);
+                            const int side = max(tl[xs], tr[xs + bx]);
+                            if (a_hi > lo && side >= 1) base += (long)(a_hi - lo) * (side - 1);
+                            if (hi > b_lo) base += (long)(hi - b_lo) * (tl[W] - 1);
+                        }
+                        tap_wave_lds_sync();
+                        if (nxt == INT_MAX || nxt >= mtop) break;
+                        lo = nxt;
                     }
-                    if (first && v < m) base += (long)(next - v) * best_run;
+                    long adj = mine ? base - (long)m * (W - 1) : LONG_MIN;
+                    int wsl = mine ? sl : INT_MAX;
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const long a2 = ((long)__shfl_xor((int)(adj >> 32), o) << 32) | (unsigned)__shfl_xor((int)adj, o);
+                        const int w2 = __shfl_xor(wsl, o);
+                        if (a2 > adj || (a2 == adj && w2 < wsl)) { adj = a2; wsl = w2; }
+                    }
+                    if (win < 0 || adj > best_adj) { best_adj = adj; win = wsl; }
                 }
-                const long adj = mw_sum(base) - (long)m * (W - 1);
-                if (win < 0 || adj > best_adj) { best_adj = adj; win = s; }
             }
             const int nt = zero ? 2 * n_ems : n_tied;
             if (nt > 1 && max_height > H) err |= 1;                               // :2718 levels up to max_height

@@ -57,7 +57,7 @@ class BatchedContainer(object):
         d = self.desc
         over = d.W * d.L > 64 or (d.D == 3 and (d.W > 8 or d.L > 8))
         big = over and (d.strategy == _lib.TAP_LB_GREEDY or (d.strategy == _lib.TAP_MACS and d.D == 3))   # big.hip / macs3_big.hip
-        wide_macs = d.strategy == _lib.TAP_MACS and d.D == 2 and d.W > 16           # above 32 columns: one wavefront per container
+        wide_macs = d.strategy == _lib.TAP_MACS and d.D == 2 and d.W > 16           # above 16 columns: one wavefront per container
         return not (big or wide_macs or d.strategy == _lib.TAP_LB)
 
     # ---- plumbing ---------------------------------------------------------------------------
