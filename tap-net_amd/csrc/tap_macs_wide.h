@@ -4,7 +4,9 @@
 // height-map stays in the group's LDS slice instead of a register array per lane (a 64-entry array would not
 // fit), column masks are 64-bit, and a level's `taken` mask is a 64-bit word.  Used by macs.hip's stand-alone
 // step only -- the reference's own MACS runs are 5 and 7 columns wide, so this is a coverage path, not a tuned
-// one (a fused transition for it was measured slower than the two launches, see transition.hip).
+// one (a fused transition for it was measured slower than the two launches, see transition.hip).  Since the end of
+// round 4 the wave-per-container kernel of macs_big.hip is faster from 17 columns up and runs first (macs.hip);
+// this one is what runs when that kernel's tile does not fit the LDS, and under TAP_MACS2D_WAVE_FROM for A/B runs.
 #pragma once
 
 #include "tap_macs.h"
