@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
 {
     extern __shared__ int32_t big_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int env = blockIdx.x * (TAP_BLOCK / 64) + wave;
+    const int env = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;               // 1 .. 4 wavefronts per workgroup (tap_big_step)
     const int B = a.d.B, D = a.d.D, W = a.d.W, L = a.d.L, cells = W * L;
     if (env >= B) return;                                                         // wave-uniform
     int32_t *hm = big_lds + (size_t)wave * cells * (HARD ? 4 : 1);
@@ -404,15 +404,18 @@ int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
     if (grid == 0) return TAP_OK;
     (void)state;
     const bool hard = (a.d.flags & TAP_F_HARD) != 0;
-    const size_t lds = (size_t)(TAP_BLOCK / 64) * a.d.W * a.d.L * sizeof(int32_t) * (hard ? 4 : 1);
-    if (lds <= tap_lds_limit(ctx)) {                                             // one wavefront per container
-        const dim3 g((a.d.B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64));
+    const size_t tile = (size_t)a.d.W * a.d.L * sizeof(int32_t) * (hard ? 4 : 1);
+    int waves = TAP_BLOCK / 64;                                                  // per workgroup: as many as the LDS holds tiles for
+    while (waves > 1 && (size_t)waves * tile > tap_lds_limit(ctx)) waves >>= 1;
+    const size_t lds = (size_t)waves * tile;
+    if (lds <= tap_lds_limit(ctx) && !tap_wave_kernels_off()) {                  // one wavefront per container
+        const dim3 g((a.d.B + waves - 1) / waves);
         if (hard) {
             TAP_HIP_CHECK(ctx, tap_allow_lds(k_big_wave_step<true>, lds));
-            hipLaunchKernelGGL(k_big_wave_step<true>, g, dim3(TAP_BLOCK), lds, st, a);
+            hipLaunchKernelGGL(k_big_wave_step<true>, g, dim3(waves * 64), lds, st, a);
         } else {
             TAP_HIP_CHECK(ctx, tap_allow_lds(k_big_wave_step<false>, lds));
-            hipLaunchKernelGGL(k_big_wave_step<false>, g, dim3(TAP_BLOCK), lds, st, a);
+            hipLaunchKernelGGL(k_big_wave_step<false>, g, dim3(waves * 64), lds, st, a);
         }
         TAP_LAUNCH_CHECK(ctx, "k_big_wave_step");
         return TAP_OK;

@@ -160,7 +160,7 @@ int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
         const size_t tile = m3w_tile_u64(cells, HW, a.d.n_max, macs3_big_cap(a.d.n_max)) * 8;
         int waves = TAP_BLOCK / 64;
         while (waves > 1 && (size_t)waves * tile > tap_lds_limit(ctx)) waves >>= 1;
-        if ((size_t)waves * tile <= tap_lds_limit(ctx)) {
+        if ((size_t)waves * tile <= tap_lds_limit(ctx) && !tap_wave_kernels_off()) {
             TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_wave_step, (size_t)waves * tile));
             hipLaunchKernelGGL(k_macs3d_wave_step, dim3((a.d.B + waves - 1) / waves), dim3(waves * 64), (size_t)waves * tile, st, a);
             TAP_LAUNCH_CHECK(ctx, "k_macs3d_wave_step");

@@ -609,7 +609,7 @@ int tap_macs_wave_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
     const size_t tile = macs_wave_tile_ints(a.d.W, cap) * sizeof(int32_t);
     int waves = TAP_BLOCK / 64;
     while (waves > 1 && (size_t)waves * tile > tap_lds_limit(ctx)) waves >>= 1;
-    if ((size_t)waves * tile > tap_lds_limit(ctx)) return TAP_E_UNSUPPORTED;
+    if ((size_t)waves * tile > tap_lds_limit(ctx) || tap_wave_kernels_off()) return TAP_E_UNSUPPORTED;
     TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs2d_wave_step, (size_t)waves * tile));
     hipLaunchKernelGGL(k_macs2d_wave_step, dim3((a.d.B + waves - 1) / waves), dim3(waves * 64), (size_t)waves * tile, st, a, cap);
     TAP_LAUNCH_CHECK(ctx, "k_macs2d_wave_step");

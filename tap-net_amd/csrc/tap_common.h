@@ -213,6 +213,9 @@ __device__ __forceinline__ int tap_spread_env(int lpw, int B)
     const int env = wave * lpw + lane;
     return (lane < lpw && env < B) ? env : -1;
 }
+// TAP_NO_WAVE_KERNELS (read once): the wave-per-container kernels of big.hip / macs_big.hip / macs3_big.hip stand aside
+// and their fallbacks -- what runs when a container's tile does not fit the LDS -- take every launch (parity tests, A/B)
+inline bool tap_wave_kernels_off() { static const bool off = getenv("TAP_NO_WAVE_KERNELS") != nullptr; return off; }
 inline int tap_spread_lpw(int B)                 // lanes per wave that carry a container
 {
     int lpw = 64;
