@@ -97,7 +97,7 @@ def main():
     rows += episode_case("2D n=30 W=5 LB_GREEDY (90 rows: two-word shadow)", 8192, 30, 2, [5, 150], "C+P+S-lb-soft", "LB_GREEDY", bits_vs_copy)
     rows += episode_case("3D n=30 5x5 LB_GREEDY (90 rows, 180 columns)", 2048, 30, 3, [5, 5, 150], "C+P+S-lb-soft", "LB_GREEDY", bits_vs_copy)
     rows += episode_case("2D n=20 W=7 LB_GREEDY (60 rows: one-word shadow, for scale)", 8192, 20, 2, [7, 100], "C+P+S-lb-soft", "LB_GREEDY", bits_vs_copy)
-    rows += episode_case("2D n=12 W=20 MACS (wide)", 8192, 12, 2, [20, 80], "C+P+S-mcs-soft", "MACS", bits_vs_copy[:1] + bits_vs_copy[2:3])
+    rows += episode_case("2D n=12 W=20 MACS (one wavefront per container since the end of round 4)", 8192, 12, 2, [20, 80], "C+P+S-mcs-soft", "MACS", bits_vs_copy[:1] + bits_vs_copy[2:3])
     rows += episode_case("2D n=10 W=40 MACS (one wavefront per container)", 4096, 10, 2, [40, 60], "C+P+S-mcs-soft", "MACS", bits_vs_copy[:1] + bits_vs_copy[2:3])
     rows += rolling_case("3D rolling N=50 child=10 (one-word graphs, for scale)", 4096, 50, 10, 3, [7, 7, 250])
     rows += rolling_case("3D rolling N=100 child=10 (two-word graphs, one wavefront per instance)", 4096, 100, 10, 3, [7, 7, 500])
