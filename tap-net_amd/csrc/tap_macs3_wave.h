@@ -98,8 +98,8 @@ __device__ inline void m3w_scan(const M3WTile &s, int x, int y, int bx, int by, 
 //   max rectangle at level h with footprint [px, px+bx) x [py, py+by) filled
 //     = max( best within rows [0, px), best within rows [px+bx, n), and the same two over the other axis ),
 // whether or not the footprint's cells were free.  For one axis: rows r[i] (i < n) are masks over the other axis of the
-// cells with hm <= h; the (first row, last row) pairs are dealt one per lane -- (q1, q2) = (lane / n, lane % n) is the
-// caller's -- and each pair's area (rows x longest common run) is maxed into bs[first] and be[last]; on return lane a
+// cells with hm <= h; the (first row, last row) pairs are dealt one per lane -- (q1, q2) = (lane / (n + 1), lane % (n + 1))
+// is the caller's -- and each pair's area (rows x longest common run) is maxed into bs[first] and be[last]; on return lane a
 // holds PL = best rectangle within rows [0, a) and PR = best within rows [a, n) (0 from lane n on).  Every lane calls.
 __device__ inline void m3w_side_tables(const M3WTile &s, int h, int n, bool over_y, int lane, int q1, int q2, int &PL, int &PR)
 {
@@ -118,19 +118,20 @@ __device__ inline void m3w_side_tables(const M3WTile &s, int h, int n, bool over
     }
     s.bs[lane] = 0; s.be[lane] = 0;
     tap_wave_lds_sync();
-    const int d1 = 64 / n, d2 = 64 - d1 * n;
-    for (int idx = lane; idx < n * n; idx += 64) {
-        if (q2 >= q1) {
-            m3b_u64 acc = ~0ull;
-            for (int i0 = q1; i0 <= q2 && acc; i0 += 4) {                          // four loads in flight (a repeated row changes nothing)
+    // the n (n + 1) / 2 pairs as ceil(n / 2) folded rows of n + 1: first rows r and n - 1 - r together have n + 1 pairs
+    // (for odd n the middle row meets itself: its pairs come twice, which a maximum does not mind)
+    const int fw = n + 1, d1 = 64 / fw, d2 = 64 - d1 * fw, total = ((n + 1) / 2) * fw;
+    for (int idx = lane; idx < total; idx += 64) {
+        const int i1 = q2 < n - q1 ? q1 : n - 1 - q1, i2 = q2 < n - q1 ? q1 + q2 : q2 - 1;   // second part: i1 + (q2 - (n - q1))
+        m3b_u64 acc = ~0ull;
+        for (int i0 = i1; i0 <= i2 && acc; i0 += 4) {                              // four loads in flight (a repeated row changes nothing)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc &= s.rows[min(i0 + i, q2)];
-            }
-            const int area = (q2 - q1 + 1) * m3b_longest_run(acc);
-            if (area > 0) { atomicMax(&s.bs[q1], area); atomicMax(&s.be[q2], area); }
+            for (int i = 0; i < 4; ++i) acc &= s.rows[min(i0 + i, i2)];
         }
+        const int area = (i2 - i1 + 1) * m3b_longest_run(acc);
+        if (area > 0) { atomicMax(&s.bs[i1], area); atomicMax(&s.be[i2], area); }
         q1 += d1; q2 += d2;
-        if (q2 >= n) { q2 -= n; ++q1; }
+        if (q2 >= fw) { q2 -= fw; ++q1; }
     }
     tap_wave_lds_sync();
     int e = lane < n ? s.be[lane] : 0, b = lane < n ? s.bs[lane] : 0;
@@ -153,7 +154,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
     const bool hard = s.flags & M3B_F_HARD;
     M3BResult res = {0, 0, 0, 0, 0};
     int n_ems = 0;
-    const int q1 = lane / W, q2 = lane - q1 * W, q1y = lane / L, q2y = lane - q1y * L;   // m3w_side_tables' pairs of this lane
+    const int q1 = lane / (W + 1), q2 = lane - q1 * (W + 1), q1y = lane / (L + 1), q2y = lane - q1y * (L + 1);   // m3w_side_tables' pairs of this lane
 #ifdef M3W_PROF
     long long t0_ = __builtin_readcyclecounter();
 #endif
