@@ -14,7 +14,7 @@ for cs, n, B in (([10, 10, 50], 10, 4096), ([12, 12, 40], 20, 2048), ([20, 20, 3
     rng = np.random.RandomState(1)
     blocks = torch.as_tensor(rng.randint(1, 5, size=(B, n, 3)).astype(np.int32), device="cuda:0")
     env = T.BatchedContainer(B, cs, n, "C+P+S-mcs-soft", "diff", packing_strategy="MACS", device="cuda:0")
-    out = (ctypes.c_ulonglong * 8)()
+    out = (ctypes.c_ulonglong * 16)()
     for rep in range(2):
         env.reset(); torch.cuda.synchronize(); lib.tap_m3w_prof_read(out, 1); t0 = time.perf_counter()
         for t in range(n):
@@ -24,4 +24,6 @@ for cs, n, B in (([10, 10, 50], 10, 4096), ([12, 12, 40], 20, 2048), ([20, 20, 3
     tot = float(sum(out[:7]))
     print(json.dumps(dict(container=cs, n=n, B=B, us_per_step=dt / n * 1e6,
                           cycles_per_placement=tot / (B * n),
-                          share={NAMES[k]: round(out[k] / tot, 3) for k in range(7)})))
+                          share={NAMES[k]: round(out[k] / tot, 3) for k in range(7)},
+                          per_placement=dict(spaces=out[8] / max(out[12], 1), walks=out[9] / max(out[12], 1), corner_hits=out[10] / max(out[12], 1),
+                                             searches_that_found=out[11] / max(out[12], 1)))))

@@ -179,8 +179,8 @@ int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 #ifdef M3W_PROF
 extern "C" int tap_m3w_prof_read(unsigned long long *out, int reset)
 {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(m3w_prof), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(m3w_prof), z, sizeof z) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(m3w_prof), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(m3w_prof), z, sizeof z) != hipSuccess) return -1; }
     return 0;
 }
 #endif

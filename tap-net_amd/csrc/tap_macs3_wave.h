@@ -20,10 +20,12 @@
 #include "tap_macs3_big.h"
 
 #ifdef M3W_PROF     // scratch builds only: cycles per phase of m3w_place, summed over wavefronts (scripts/m3w_phases.py)
-__device__ unsigned long long m3w_prof[8];
+__device__ unsigned long long m3w_prof[16];        // [0..6] cycles per phase, [8..12] counts: spaces, walks, corner hits, searches that found, placements
+#define M3W_C(k, v) do { if (lane == 0) atomicAdd(&m3w_prof[k], (unsigned long long)(v)); } while (0)
 #define M3W_T(k) do { const long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&m3w_prof[k], (unsigned long long)(t_ - t0_)); t0_ = t_; } while (0)
 #else
 #define M3W_T(k) do { } while (0)
+#define M3W_C(k, v) do { } while (0)
 #endif
 
 struct M3WTile {                    // pointers into the wave's LDS slice
@@ -336,14 +338,22 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
     // 0: x up then y up; 1: y up then x down; 2: x down then y down; 3: y down then x up
     auto walk = [&](int order, int xa, int xb, int ya, int yb, int Z) {            // rectangle [xa, xb) x [ya, yb)
         int best = INT_MAX;                                                        // rank << 12 | position (cells <= 4096)
-        for (int p = lane; p < cells; p += 64) {
-            const int v = s.lev[p], q = s.pxy[p], px = q & 255, py = q >> 8;       // both reads go out together
-            const int rank = order == 0 ? px * L + py : order == 1 ? py * W + (W - 1 - px)
-                           : order == 2 ? (W - 1 - px) * L + (L - 1 - py) : (L - 1 - py) * W + px;
-            const bool ok = v >= 0 && !(v & 1) && (v >> 2) == Z && px >= xa && px < xb && py >= ya && py < yb;
-            best = ok ? min(best, (rank << 12) | p) : best;
+        {   // the walk's own corner comes first in its order: when it settles there (the usual case) no search is needed
+            const int pc = ((order < 2 ? ya : yb - 1) * W) + ((order == 0 || order == 3) ? xa : xb - 1), vc = s.lev[pc];
+            if (vc >= 0 && !(vc & 1) && (vc >> 2) == Z) best = pc;
         }
-        best = m3w_min(best);
+        M3W_C(9, 1); M3W_C(10, best != INT_MAX);
+        if (best == INT_MAX) {                                                     // wave-uniform
+            for (int p = lane; p < cells; p += 64) {
+                const int v = s.lev[p], q = s.pxy[p], px = q & 255, py = q >> 8;   // both reads go out together
+                const int rank = order == 0 ? px * L + py : order == 1 ? py * W + (W - 1 - px)
+                               : order == 2 ? (W - 1 - px) * L + (L - 1 - py) : (L - 1 - py) * W + px;
+                const bool ok = v >= 0 && !(v & 1) && (v >> 2) == Z && px >= xa && px < xb && py >= ya && py < yb;
+                best = ok ? min(best, (rank << 12) | p) : best;
+            }
+            best = m3w_min(best);
+            M3W_C(11, best != INT_MAX);
+        }
         if (best == INT_MAX) return;
         const int p = best & 4095, q = s.pxy[p];
         if (lane == 0) { s.lev[p] |= 1; s.slots[n_slots] = q; }
@@ -365,6 +375,7 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
     //  230 / 325 / 866 for the four passes)
 
     M3W_T(3);
+    M3W_C(8, n_ems); M3W_C(12, 1);
     // ---- score the settled positions (tools.py:2973-2987), pick (:3118-3148) -----------------------------------
     if (n_slots == 0) return res;                                                  // :3118-3121
     int gmax = 0;
