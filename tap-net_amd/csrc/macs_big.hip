@@ -269,8 +269,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_big_step(StepArgs a, int32
 // computed one position per lane once per step (a position settles at Z iff the maximum under it IS Z, so `visited`
 // is one flag per position), a corner walk is a wave-wide min / max over the settling positions of its range, the slots
 // are scored one per lane and the usable-space score of a tied slot sums one column per lane.
-// Tile (ints): hm[W] | lev[W] | psum[W] | slots[W] | tl[W + 1] | tr[W + 1] | ems[2 cap]
-__host__ __device__ inline size_t macs_wave_tile_ints(int W, int cap) { return (size_t)6 * W + 2 + (size_t)2 * cap; }
+// Tile (ints): hm[W] | lev[W] | psum[W] | slots[W] | tl[W + 1] | tr[W + 1] | ems[2 cap] | history pos[2 n_max] | blk[2 n_max]
+__host__ __device__ inline size_t macs_wave_tile_ints(int W, int cap, int n_max) { return (size_t)6 * W + 2 + (size_t)2 * cap + (size_t)4 * n_max; }
 
 __device__ __forceinline__ int mw_min(int v) { return group_min<64>(v); }     // DPP + readlane (tap_place.h): all 64 lanes call
 __device__ __forceinline__ int mw_max(int v) { return group_max<64>(v); }
@@ -287,7 +287,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
     const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int B = a.d.B, W = a.d.W, H = a.d.H;
     if (env >= B) return;                                                         // wave-uniform
-    int32_t *hm = mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(W, cap);
+    int32_t *hm = mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(W, cap, a.d.n_max);
     int32_t *lev = hm + W, *psum = lev + W, *slots = psum + W;
     int32_t *tl = slots + W, *tr = tl + W + 1;                                  // the tie-break's per-level tables
     int2 *ems = reinterpret_cast<int2 *>(tr + W + 1);
@@ -317,6 +317,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
     if (act && (bx < 1 || bz < 1)) { err |= 4; do_step = false; }
     const int step = cnt.count;
     Placement res = {0, 0, 0, 0, 0};
+    int32_t *hpos = reinterpret_cast<int32_t *>(ems + cap), *hblk = hpos + 2 * a.d.n_max;   // the history so far, one round trip for all of it
+    for (int k = lane; k < 2 * min(step, a.d.n_max); k += 64) { hpos[k] = a.v.pos[(size_t)k * B + env]; hblk[k] = a.v.blk[(size_t)k * B + env]; }
     tap_wave_lds_sync();
 
     if (do_step) {                                                               // wave-uniform
@@ -368,8 +370,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
         }
         // ---- (b) tops of the blocks placed so far (tools.py:2531-2555); failed steps sit at (0, 0) ------------------
         for (int i = 0; i < step; ++i) {
-            const int x = a.v.pos[(size_t)(i * 2) * B + env], z = a.v.pos[(size_t)(i * 2 + 1) * B + env];
-            const int xx = a.v.blk[(size_t)(i * 2) * B + env], zz = a.v.blk[(size_t)(i * 2 + 1) * B + env];
+            const int x = hpos[i * 2], z = hpos[i * 2 + 1];
+            const int xx = hblk[i * 2], zz = hblk[i * 2 + 1];
             const int tz = z + zz;
             if (!(tz < H)) continue;                                              // :2535
             bool covered = false;                                                 // the slice clips at W (:2537)
@@ -606,7 +608,7 @@ int tap_macs_wave_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     if (a.d.B == 0) return TAP_OK;
     const int cap = macs_big_cap(a.d.W, a.d.n_max);
-    const size_t tile = macs_wave_tile_ints(a.d.W, cap) * sizeof(int32_t);
+    const size_t tile = macs_wave_tile_ints(a.d.W, cap, a.d.n_max) * sizeof(int32_t);
     int waves = TAP_BLOCK / 64;
     while (waves > 1 && (size_t)waves * tile > tap_lds_limit(ctx)) waves >>= 1;
     if ((size_t)waves * tile > tap_lds_limit(ctx) || tap_wave_kernels_off()) return TAP_E_UNSUPPORTED;
