@@ -391,11 +391,38 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
     }
 }
 
+// get_heightmap's feature of the current maps (tools.py:3716-3744), one wavefront per container, lanes over the cells
+// (it was one thread per container until the end of round 4: 74 .. 340 us per call at 10x10 .. 20x20, more than the
+// MACS 3D placement it follows)
 __global__ void __launch_bounds__(TAP_BLOCK) k_big_feature(tap_env_desc d, EnvView v, float *out, int flen)
 {
-    const int env = blockIdx.x * TAP_BLOCK + threadIdx.x;
-    if (env >= d.B) return;
-    big_feature(d.feature, d.D, d.W, d.L, v.hm + (size_t)env * d.W * d.L, out + (size_t)env * flen);
+    const int lane = threadIdx.x & 63;
+    const int env = (int)(((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (env >= d.B) return;                                                       // wave-uniform
+    const int W = d.W, L = d.L, cells = W * L;
+    const int32_t *hm = v.hm + (size_t)env * cells;
+    float *o = out + (size_t)env * flen;
+    if (d.feature == TAP_FEAT_DIFF) {
+        if (d.D == 2) { for (int c = lane; c + 1 < W; c += 64) o[c] = (float)(hm[c + 1] - hm[c]); }
+        else {
+            int x = lane / L, y = lane - x * L;
+            const int dx = 64 / L, dy = 64 - dx * L;
+            for (int c = lane; c < cells; c += 64) {
+                o[c] = (float)(x > 0 ? hm[c] - hm[c - L] : 0);
+                o[cells + c] = (float)(y > 0 ? hm[c] - hm[c - 1] : 0);
+                x += dx; y += dy;
+                if (y >= L) { y -= L; ++x; }
+            }
+        }
+        return;
+    }
+    int mn = 0;
+    if (d.feature == TAP_FEAT_ZERO) {
+        mn = INT_MAX;
+        for (int c = lane; c < cells; c += 64) mn = min(mn, hm[c]);
+        mn = group_min<64>(mn);
+    }
+    for (int c = lane; c < cells; c += 64) o[c] = (float)(hm[c] - mn);
 }
 
 int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
@@ -428,9 +455,9 @@ int tap_big_step(tap_ctx *ctx, const StepArgs &a, void *state, hipStream_t st)
 
 int tap_big_feature(tap_ctx *ctx, const tap_env_desc *d, const EnvView &v, float *out, int flen, hipStream_t st)
 {
-    const int grid = (d->B + TAP_BLOCK - 1) / TAP_BLOCK;
-    if (grid == 0) return TAP_OK;
-    hipLaunchKernelGGL(k_big_feature, dim3(grid), dim3(TAP_BLOCK), 0, st, *d, v, out, flen);
+    if (d->B == 0) return TAP_OK;
+    const int wpb = TAP_BLOCK / 64;
+    hipLaunchKernelGGL(k_big_feature, dim3((d->B + wpb - 1) / wpb), dim3(TAP_BLOCK), 0, st, *d, v, out, flen);
     TAP_LAUNCH_CHECK(ctx, "k_big_feature");
     return TAP_OK;
 }

@@ -149,6 +149,28 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
         }
     }
     if (lane == 0 && err) a.v.err[env] |= err;
+    if (a.feature_out) {                                                         // get_heightmap's feature of the new map (tools.py:3716-3744), from the tile
+        tap_wave_lds_sync();
+        float *o = a.feature_out + (size_t)env * a.flen;
+        if (a.d.feature == TAP_FEAT_DIFF) {
+            int x = lane / L, y = lane - x * L;
+            const int dx = 64 / L, dy = 64 - dx * L;
+            for (int c = lane; c < cells; c += 64) {
+                o[c] = (float)(x > 0 ? s.hm[c] - s.hm[c - L] : 0);
+                o[cells + c] = (float)(y > 0 ? s.hm[c] - s.hm[c - 1] : 0);
+                x += dx; y += dy;
+                if (y >= L) { y -= L; ++x; }
+            }
+        } else {
+            int mn = 0;
+            if (a.d.feature == TAP_FEAT_ZERO) {
+                mn = INT_MAX;
+                for (int c = lane; c < cells; c += 64) mn = min(mn, s.hm[c]);
+                mn = group_min<64>(mn);
+            }
+            for (int c = lane; c < cells; c += 64) o[c] = (float)(s.hm[c] - mn);
+        }
+    }
 }
 
 int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
@@ -163,8 +185,7 @@ int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
         if ((size_t)waves * tile <= tap_lds_limit(ctx) && !tap_wave_kernels_off()) {
             TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_wave_step, (size_t)waves * tile));
             hipLaunchKernelGGL(k_macs3d_wave_step, dim3((a.d.B + waves - 1) / waves), dim3(waves * 64), (size_t)waves * tile, st, a);
-            TAP_LAUNCH_CHECK(ctx, "k_macs3d_wave_step");
-            if (a.feature_out) return tap_big_feature(ctx, &a.d, a.v, a.feature_out, a.flen, st);   // tools.py:3716-3744
+            TAP_LAUNCH_CHECK(ctx, "k_macs3d_wave_step");                            // (writes the feature itself)
             return TAP_OK;
         }
     }
