@@ -134,6 +134,38 @@ M3B_HD inline int m3b_maxrect(const M3BState &s, int h, int fx, int fy, int fbx,
     return best;
 }
 
+// The tie-break's per-level tables: PLx[a] / PRx[a] = largest all-free rectangle of level h within rows x in [0, a) /
+// [a, W) (a = 0 .. W), PLy / PRy the same over y.  A free rectangle that avoids a filled footprint
+// [px, px+bx) x [py, py+by) lies wholly on one side of it, so the level's largest rectangle with that footprint filled is
+// max(PLx[px], PRx[px+bx], PLy[py], PRy[py+by]) whether or not the footprint's cells were free; PLx[W] is the level's own.
+constexpr int M3B_TIE_CHUNK = 32;
+M3B_HD inline void m3b_side_tables(const M3BState &s, int h, int *PLx, int *PRx, int *PLy, int *PRy)
+{
+    m3b_u64 rows[64];
+    for (int axis = 0; axis < 2; ++axis) {
+        const int n = axis ? s.L : s.W, m = axis ? s.W : s.L;
+        int *PL = axis ? PLy : PLx, *PR = axis ? PRy : PRx;
+        for (int i = 0; i < n; ++i) {
+            m3b_u64 r = 0;
+            for (int b = 0; b < m; ++b) r |= (m3b_u64)(s.hm[axis ? b * s.L + i : i * s.L + b] <= h) << b;
+            rows[i] = r;
+        }
+        for (int a = 0; a <= n; ++a) { PL[a] = 0; PR[a] = 0; }
+        for (int i1 = 0; i1 < n; ++i1) {
+            m3b_u64 acc = ~0ull;
+            for (int i2 = i1; i2 < n; ++i2) {
+                acc &= rows[i2];
+                if (!acc) break;
+                const int area = (i2 - i1 + 1) * m3b_longest_run(acc);
+                PR[i1] = m3b_max(PR[i1], area);                                    // by first row
+                PL[i2 + 1] = m3b_max(PL[i2 + 1], area);                            // by last row
+            }
+        }
+        for (int a = 1; a <= n; ++a) PL[a] = m3b_max(PL[a], PL[a - 1]);
+        for (int a = n - 1; a >= 0; --a) PR[a] = m3b_max(PR[a], PR[a + 1]);
+    }
+}
+
 // One placement.  STAB(bx, by, eq) = tools.is_stable on a support mask.  cnt = {valid, empty, nstable, count}; on
 // return the state (hm, occ) and cnt[0..2] are updated; the caller advances cnt[3] and appends the history.
 template <typename STAB>
@@ -364,39 +396,43 @@ M3B_HD inline M3BResult m3b_place(M3BState &s, int *cnt, int &err, int bx, int b
         // calc_maximal_usable_spaces = sum over levels h < max_height of the largest free rectangle; above max(hm') a
         // level is all free, so candidates are ordered by  sum_{h < max(hm')} rect(h) - max(hm') * W * L  (tap_macs3.h)
         if (max_height > H) err |= 1;                                              // container[:, :, h] IndexError
-        int nl = 1;                                                                // level 0 and the distinct heights above it, ascending
-        s.lvh[0] = 0;
-        s.lvr[0] = m3b_maxrect(s, 0, 0, 0, 0, 0);
-        for (int last = 0;;) {
-            int nxt = 0x7fffffff;
-            for (int c = 0; c < cells; ++c) if (s.hm[c] > last && s.hm[c] < nxt) nxt = s.hm[c];
-            if (nxt == 0x7fffffff) break;
-            s.lvh[nl] = nxt;
-            s.lvr[nl] = m3b_maxrect(s, nxt, 0, 0, 0, 0);
-            ++nl;
-            last = nxt;
-        }
+        // Per level ONE set of side tables serves every candidate (m3b_side_tables: a free rectangle that avoids the
+        // candidate's filled footprint lies wholly on one side of it); the tied candidates go through the levels
+        // M3B_TIE_CHUNK at a time, in list order.
         long best_adj = 0;
         win = -1;
-        for (int sl = 0; sl < n_slots; ++sl) {
-            int px, py, mp, st, emp;
-            if (score(sl, px, py, mp, st, emp) != rmax) continue;
-            const int Zt = mp + bz, M = m3b_max(gmax, Zt);
-            long base = 0;
-            for (int k = 0; k < nl; ++k) {
-                const int lo = s.lvh[k];
-                if (lo >= M) break;
-                const int hi = m3b_min(M, k + 1 < nl ? s.lvh[k + 1] : 0x7fffffff);
-                const int a_hi = m3b_min(hi, Zt), b_lo = m3b_max(lo, Zt);
-                if (a_hi > lo) {                                                   // below the block's top: its footprint is filled
-                    bool touches = false;
-                    for (int i = 0; i < bx && !touches; ++i) for (int j = 0; j < by; ++j) if (s.hm[(px + i) * L + py + j] <= lo) { touches = true; break; }
-                    base += (long)(a_hi - lo) * (touches ? m3b_maxrect(s, lo, px, py, bx, by) : s.lvr[k]);
-                }
-                if (hi > b_lo) base += (long)(hi - b_lo) * s.lvr[k];
+        int PLx[65], PRx[65], PLy[65], PRy[65];
+        for (int s0 = 0; s0 < n_slots;) {
+            int ids[M3B_TIE_CHUNK], cpx[M3B_TIE_CHUNK], cpy[M3B_TIE_CHUNK], cZt[M3B_TIE_CHUNK], nk = 0, Mtop = 0;
+            long base[M3B_TIE_CHUNK];
+            for (; s0 < n_slots && nk < M3B_TIE_CHUNK; ++s0) {
+                int px, py, mp, st, emp;
+                if (score(s0, px, py, mp, st, emp) != rmax) continue;
+                ids[nk] = s0; cpx[nk] = px; cpy[nk] = py; cZt[nk] = mp + bz; base[nk] = 0;
+                Mtop = m3b_max(Mtop, m3b_max(gmax, mp + bz));
+                ++nk;
             }
-            const long adj = base - (long)M * cells;
-            if (win < 0 || adj > best_adj) { best_adj = adj; win = sl; }
+            if (nk == 0) break;
+            for (int lo = 0; lo < Mtop;) {                                         // levels: 0 and the distinct heights, ascending
+                int nxt = 0x7fffffff;
+                for (int c = 0; c < cells; ++c) if (s.hm[c] > lo && s.hm[c] < nxt) nxt = s.hm[c];
+                m3b_side_tables(s, lo, PLx, PRx, PLy, PRy);
+                const int full = PLx[W];
+                for (int k = 0; k < nk; ++k) {
+                    const int Zt = cZt[k], M = m3b_max(gmax, Zt);
+                    if (lo >= M) continue;
+                    const int hi = m3b_min(M, nxt), a_hi = m3b_min(hi, Zt), b_lo = m3b_max(lo, Zt);
+                    if (a_hi > lo)                                                 // below the block's top: its footprint is filled
+                        base[k] += (long)(a_hi - lo) * m3b_max(m3b_max(PLx[cpx[k]], PRx[cpx[k] + bx]), m3b_max(PLy[cpy[k]], PRy[cpy[k] + by]));
+                    if (hi > b_lo) base[k] += (long)(hi - b_lo) * full;
+                }
+                if (nxt == 0x7fffffff) break;
+                lo = nxt;
+            }
+            for (int k = 0; k < nk; ++k) {
+                const long adj = base[k] - (long)m3b_max(gmax, cZt[k]) * cells;
+                if (win < 0 || adj > best_adj) { best_adj = adj; win = ids[k]; }
+            }
         }
     }
 
