@@ -967,6 +967,60 @@ def load_traffic(key):
     return None
 
 
+def pass_compulsory_bytes(hp, cfg, rolling):
+    """Compulsory bytes of ONE whole pass of hp (every launch of it, compulsory_bytes per kind) for all its envs."""
+    name, D, cs, n, B, reward, strategy = cfg
+    bits_on = bool(getattr(hp, "bits", True)) or rolling
+    cb = lambda k: compulsory_bytes(k, D, cs, hp.nw, bits=bits_on) * B     # noqa: E731
+    if rolling:
+        return cb("rolling_window") + (n - hp.nw) * cb("rolling_step") + hp.nw * cb("transition")
+    if hp.kind == "episode":
+        return episode_bytes(D, n) * B
+    if bits_on:
+        return hp.windows * (cb("transition_first") + (hp.nw - 1) * cb("transition"))
+    return n * cb("transition")
+
+
+def cold_reading(cfg, hp, rolling, dev, use_graph, max_slots=40, min_steps=40):
+    """The same pass with nothing cache-resident: pass i runs on instance set i % slots, each set with its own input
+    AND output buffers, the sets together several times the 256 MB Infinity Cache.  A trainer with a network between
+    the steps lives nearer this figure than the headline's (one instance set replayed, ~65 MB at c2)."""
+    name, D, cs, n, B, reward, strategy = cfg
+    if rolling:
+        per_slot = sum(t.numel() * t.element_size() for t in ([hp.rw.rel, hp.rw.blocks, hp.static, hp.static2, hp.cur, hp.feat]
+                                                              + hp.dyn + hp.maskb + [b for b in hp.bitb if b is not None]))
+        slots = min(12, max(3, int(np.ceil(1.2e9 / per_slot))), max_slots)
+        hps = [hp] + [RollingHotPath(cfg, B, 0, dev, seed=777 + 1000 * k, window=hp.nw, fused_rolling=hp.fused_rolling, mix=hp.mix)
+                      for k in range(1, slots)]
+        steps = slots * 3
+    else:
+        per_slot = sum(t.numel() * t.element_size() for t in (hp.dynamic0 + hp.static + hp.dyn + [hp.cur] + hp.maskb))
+        slots = min(max(3, int(np.ceil(1.2e9 / per_slot))), max_slots)
+
+        def slot_instances(k):
+            if hp.instances is None or isinstance(hp.instances, str) and hp.instances != "ppsg2d":
+                return hp.instances
+            # PPSG instances (30 s per 8 192 from the device generator; 64 in the fixture): the other slots hold this
+            # run's instances in another order (own buffers, own tape) -- the reading is about residency, not diversity
+            return (hp.static[0].roll(977 * k, 0).cpu().numpy(), hp.dynamic0[0].roll(977 * k, 0).cpu().numpy())
+        hps = [hp] + [HotPath(cfg, B, 0, dev, seed=777 + 1000 * k, fused=hp.fused, window=hp.nw if hp.windows > 1 else None,
+                              bits=hp.bits, instances=slot_instances(k)) for k in range(1, slots)]
+        steps = max(slots * 4, min_steps)
+    dt, _ = time_passes(hps, steps, slots, use_graph, 1)
+    for h in hps:
+        h.env.check()
+    pass_us = dt / steps * 1e6
+    ach = pass_compulsory_bytes(hp, cfg, rolling) / (pass_us * 1e-6) / 1e9
+    out = dict(value=B * n * steps / dt, unit="env-steps/s", pass_us=pass_us, achieved=ach, frac=ach / HBM_PEAK_GBS,
+               frac_how="compulsory bytes of every launch of a pass / pass time / 8 TB/s (gaps between the launches included)",
+               slots=slots, working_set_MB=round(per_slot * slots / 1e6, 1), steps=steps,
+               what="pass i runs on instance set i %% %d, each with its own input and output buffers; the working set is "
+                    "several times the 256 MB Infinity Cache" % slots)
+    del hps
+    torch.cuda.empty_cache()
+    return out
+
+
 def variants_rolling(cfg, hp, dev, use_graph, trace):
     """c5's two other readings: (a) cold -- the passes rotate over enough instance sets (relation masks, blocks,
     window and container buffers per set) to exceed the Infinity Cache; (b) rolling.validate's loop with a policy
@@ -978,20 +1032,7 @@ def variants_rolling(cfg, hp, dev, use_graph, trace):
     try:
         if "cold" in skip:
             raise RuntimeError("skipped")
-        per_slot = sum(t.numel() * t.element_size() for t in ([hp.rw.rel, hp.rw.blocks, hp.static, hp.static2, hp.cur, hp.feat]
-                                                              + hp.dyn + hp.maskb + [b for b in hp.bitb if b is not None]))
-        slots = min(12, max(3, int(np.ceil(1.2e9 / per_slot))))
-        hps = [hp] + [RollingHotPath(cfg, B, 0, dev, seed=777 + 1000 * k, window=hp.nw, fused_rolling=hp.fused_rolling, mix=hp.mix)
-                      for k in range(1, slots)]
-        steps = slots * 3
-        dt, _ = time_passes(hps, steps, slots, use_graph, 1)
-        for h in hps:
-            h.env.check()
-        out["cold"] = dict(value=B * n * steps / dt, unit="env-steps/s", slots=slots,
-                           working_set_MB=round(per_slot * slots / 1e6, 1), steps=steps,
-                           what="pass i runs on instance set i %% %d (own relation masks, blocks, window and container "
-                                "buffers); the working set is several times the 256 MB Infinity Cache" % slots)
-        del hps
+        out["cold"] = getattr(hp, "cold", None) or cold_reading(cfg, hp, True, dev, use_graph)
     except Exception as ex:                                  # pragma: no cover
         out["cold"] = dict(error=str(ex))
     trace("policy_in_loop")
@@ -1052,31 +1093,12 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
         return variants_rolling(cfg, hp, dev, use_graph, trace)
     # (a) cold: rotate over enough instance batches (inputs AND output buffers per slot) that the working set
     #     exceeds the 256 MB Infinity Cache several times over -- nothing a pass reads is cache-resident
-    per_slot = sum(t.numel() * t.element_size() for t in (hp.dynamic0 + hp.static + hp.dyn + [hp.cur] + hp.maskb))
-    slots = max(3, int(np.ceil(1.2e9 / per_slot)))
-    slots = min(slots, 40)
     skip = os.environ.get("TAP_BENCH_SKIP", "").split(",")
     trace("cold")
     try:
         if "cold" in skip:
             raise RuntimeError("skipped")
-        def slot_instances(k):
-            if hp.instances != "ppsg2d":
-                return hp.instances
-            # the perfect-packing generator takes ~30 s per 8 192 instances: the other slots hold this run's
-            # instances in another order (own buffers, own tape) -- the variant is about residency, not diversity
-            return (hp.static[0].roll(977 * k, 0).cpu().numpy(), hp.dynamic0[0].roll(977 * k, 0).cpu().numpy())
-        hps = [hp] + [HotPath(cfg, B, 0, dev, seed=777 + 1000 * k, fused=hp.fused, window=hp.nw if hp.windows > 1 else None,
-                              bits=hp.bits, instances=slot_instances(k)) for k in range(1, slots)]
-        steps = max(slots * 4, 40)
-        dt, _ = time_passes(hps, steps, slots, use_graph, 1)
-        for h in hps:
-            h.env.check()
-        out["cold"] = dict(value=B * n * steps / dt, unit="env-steps/s", slots=slots,
-                           working_set_MB=round(per_slot * slots / 1e6, 1), steps=steps,
-                           what="pass i runs on instance batch i %% %d, each with its own input and output buffers; the "
-                                "working set is several times the 256 MB Infinity Cache" % slots)
-        del hps
+        out["cold"] = getattr(hp, "cold", None) or cold_reading(cfg, hp, False, dev, use_graph)
     except Exception as ex:                                  # pragma: no cover
         out["cold"] = dict(error=str(ex))
     # (b) the loop a trainer runs: its policy between the steps, eager launches, ONE persistent pack.EpisodeStepper
@@ -1191,6 +1213,31 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
                                                      "selectable columns (uniform over them), 2 torch ops per step")
     except Exception as ex:                                  # pragma: no cover
         out.setdefault("policy_in_loop_graph", dict(error=str(ex)[:300]))
+    # (d) what the fp32 contract costs: the same graph-captured episode (recorded tour, no policy ops) on a stepper that
+    #     writes update_dynamic's result as the fp32 tensor model.py:378 feeds the encoder, and on one that keeps it as
+    #     its bit shadow only (tap_stepper_buffers.dyn = NULL) -- masks, placements, features and ratio are the same
+    try:
+        if "graph" in skip:
+            raise RuntimeError("skipped")
+        trace("no_fp32_expand")
+        tape_pol = T.TapePolicy(hp.tape[0].t())
+        vals, same = {}, None
+        for expand in (True, False):
+            env_x = T.BatchedContainer(B, cs, hp.nw, reward, "diff", packing_strategy=strategy, device=dev)
+            spx = T.EpisodeStepper(st, dy, env_x, steps=hp.nw, expand_dynamic=expand)
+            vals[expand], rec = graphed(tape_pol, lambda: None, spx, steps=200)
+            got = (rec["reward"].clone(), spx.current_mask.clone(), spx.mask.clone(), spx.decoder_dynamic.clone(),
+                   env_x.positions.clone())
+            same = got if same is None else all(bool(torch.equal(a, b)) for a, b in zip(same, got))
+        out["no_fp32_expand"] = dict(value=vals[False], unit="env-steps/s", with_expand=vals[True], steps=200,
+                                     outputs_identical=bool(same), verified=oracle_ok(rec),
+                                     what="rollout.run_episode on a recorded tour captured in one hipGraph, pack.EpisodeStepper("
+                                          "expand_dynamic=False): `dynamic` stays in its bit shadow, the (B, 3n, nR) fp32 tensor "
+                                          "of model.py:378 (78 % of a c2 step's compulsory bytes) is never written; `with_expand` "
+                                          "is the same graph on the default stepper; reward, both masks, the last feature and the "
+                                          "positions of the two runs are compared bit for bit")
+    except Exception as ex:                                  # pragma: no cover
+        out["no_fp32_expand"] = dict(error=str(ex)[:300])
     finally:
         T.pack.set_binary_check('check')
     return out
@@ -1246,6 +1293,174 @@ def _spawned_rank(rank, argv, world, port):
     main()
 
 
+def roofline_of(hp, config, cfg, rolling, steps, graphs):
+    """Per-kernel event times of `hp`'s pass and the roofline object of its dominant kernel -> (roof, kernels)."""
+    name, D, cs, n, B, reward, strategy = cfg
+    npass = max(3, min(steps, 20))
+    kt, empty_us, pass_us = kernel_event_times(hp, npass, graphs[0] if graphs else None)
+    env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
+    R_ = 2 if D == 2 else 6
+    win_b = (1 + D) * hp.nw * R_ * 4 + 3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 4 + 32   # static + dynamic + mask + state
+    per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B,
+                  "transition_first": (env_b + mask_b) * B,
+                  "rolling_window": win_b * B, "rolling_step": (win_b + env_b) * B,
+                  "episode": episode_bytes(D, n) * B,
+                  "dyn_bits": (3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 8) * B}
+    names = [k for k in ("transition", "transition_first", "rolling_step", "rolling_window", "episode", "mask_step", "env_step", "dyn_bits",
+                         "ratio", "reset") if k in kt]
+    dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
+    # the dominant kernel's duration: (event-bracketed launch) - (an empty event pair); for a pass that is
+    # nothing but that kernel the graph-replayed pass / launches is the cleaner figure (it includes the gap)
+    launches = hp.launches_per_pass()
+    if hp.kind == "transition" and hp.fused:
+        other = sum(max(kt[k]["med_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
+        dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
+        how = ("(graph-replayed pass - the other kernels' event time) / launches, passes replayed %d per graph launch as "
+               "in the timed loop; includes the inter-kernel gap" % getattr(hp, "passes_per_graph", GATHER_EVERY))
+    elif hp.kind == "episode":
+        dom_us, how = pass_us, "event-bracketed pass (one launch)"
+    elif kt[dom].get("run_len", 1) >= 8:
+        dom_us = kt[dom]["run_us"]
+        how = ("one event pair around each run of %d consecutive launches of the kernel, per launch (median over the "
+               "passes); includes the gap between launches" % kt[dom]["run_len"])
+    else:
+        dom_us = kt[dom]["med_us"]
+        how = ("median event-bracketed launch, uncorrected: reads about 2 us longer than the kernel (an empty event pair "
+               "takes %.1f us, but most of that overlaps a kernel placed between the two records)" % empty_us)
+    bits_on = bool(getattr(hp, "bits", True)) or rolling
+    comp = {k: compulsory_bytes(k, D, cs, hp.nw, bits=bits_on) * B
+            for k in ("env_step", "mask_step", "transition", "transition_first", "rolling_window", "rolling_step", "dyn_bits")}
+    comp["episode"] = per_launch["episode"]
+    ach = comp[dom] / (dom_us * 1e-6) / 1e9
+    ach_survey = per_launch[dom] / (dom_us * 1e-6) / 1e9
+    cal = load_calibration()
+    kernels = {}
+    for k in names:
+        kernels[k] = dict(med_us_event_pair=round(kt[k]["med_us"], 3), avg_us_event_pair=round(kt[k]["avg_us"], 3),
+                          launches_per_pass=kt[k]["launches"] // npass)
+        if "run_us" in kt[k]:
+            kernels[k]["us_per_launch_in_runs"] = round(kt[k]["run_us"], 3)
+        if k in comp:
+            kernels[k]["bytes_per_launch"] = comp[k]
+        if k in per_launch:
+            kernels[k]["alg_bytes_per_launch_survey"] = per_launch[k]
+    tkey = config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")
+    tr = load_traffic(tkey)
+    traffic = tr["bytes"] if tr else None
+    # write-dominated kernels are held against the measured fill rate, the first-step / copy forms against the copy
+    ceiling_kind = "copy" if (dom == "transition_first" or (dom in ("transition", "mask_step") and not bits_on)) else "fill"
+    ceiling = (cal or {}).get("%s_GBps_beyond_cache" % ceiling_kind)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS,
+            "bytes_per_launch": comp[dom],
+            "bytes_how": "compulsory bytes of the implemented kernel (inputs it did not produce + outputs; the bit-shadow "
+                         "step writes the fp32 tensor and never reads it) x envs per launch",
+            "frac_alg_survey": ach_survey / HBM_PEAK_GBS,
+            "frac_alg_survey_how": "SURVEY 8(d)'s per-env-step figure (prices an fp32 read AND write of dynamic) / kernel_us / "
+                                   "peak: speed relative to a perfect fp32 copy, NOT a bandwidth fraction -- it passes 1.0 "
+                                   "where the bit-shadow kernel, which never performs the priced fp32 read, outruns such a copy "
+                                   "(`frac` and `frac_hbm` are the bandwidth fractions and stay below 1)",
+            "frac_hbm": (traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "peak_measured": dict(GBps=ceiling, kind=ceiling_kind + " beyond the Infinity Cache, 16 B per lane",
+                                  frac=(ach / ceiling) if ceiling else None,
+                                  source=(cal or {}).get("source")) if cal else None,
+            "traffic": traffic,
+            "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profile set %s "
+                               "(profiles/%s_%s_pmc_summary.csv); not re-measured in this run"
+                               % (tr["profile"], tr["profile"].split()[0], config)) if tr else None,
+            "bytes_per_env_step": comp[dom] // B, "alg_bytes_per_env_step_survey": per_launch[dom] // B, "units_per_launch": B,
+            "kernel_us": dom_us, "kernel_us_how": how, "kernel_us_rocprof": tr.get("kernel_us") if tr else None,
+            "pass_us": pass_us, "launches_per_pass": launches, "event_pair_overhead_us": empty_us}
+    return roof, kernels
+
+
+def build_hotpath(config, args, rank, dev, batch=None):
+    """The pre-allocated pass of one config on this rank's share of the batch -> (hot path, cfg tuple, rolling?)."""
+    cfg = CONFIGS[config]
+    name, D, cs, n, B, reward, strategy = cfg
+    if batch:
+        B = batch
+        cfg = (name, D, cs, n, B, reward, strategy)
+    rolling = config in ROLLING and not args.approx_windows
+    if rolling:
+        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[config], fused_rolling=not args.two_launch_rolling,
+                            overlap=args.overlap, mix=not args.rand_only)
+        if not hp.mix:
+            name = name.replace("3D MIX", "3D RAND")
+            cfg = (name, D, cs, n, B, reward, strategy)
+    elif config == "k6":
+        hp = EpisodeHotPath(cfg, B, rank * B, dev)
+    else:
+        instances = None
+        if config in ("c2", "c3") and not args.synthetic_precedence:
+            instances = "generate"
+        if config == "c4" and args.ppsg_device:
+            instances = "ppsg2d"                                    # device-side perfect-packing generator (~30 s of set-up)
+            name = name.replace("RAND-marginal blocks", "device-generated PPSG instances")
+            cfg = (name, D, cs, n, B, reward, strategy)
+        elif config == "c4" and not args.rand_blocks:
+            fx = os.path.join(ROOT, "tests", "golden", "ppsg_2d.npz")
+            if os.path.exists(fx):                                  # 64 PPSG instances written by the reference
+                z = np.load(fx)                                     # (tests/golden/make_golden.py --only ppsg)
+                instances = (z["static"].astype(np.float32), z["dynamic"].astype(np.float32))
+                name = name.replace("RAND-marginal blocks", "the reference's PPSG generator: 64 instances tiled x%d" % (B // 64))
+                cfg = (name, D, cs, n, B, reward, strategy)
+        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(config), bits=not args.no_bits,
+                     instances=instances)
+    hp.config = config
+    return hp, cfg, rolling
+
+
+def measure_config(config, args, rank, world, dev, use_graph, steps, warmup, repeats, cold=False):
+    """One more BASELINE config on the same clock as the headline: graph-replayed brackets of exactly `steps` passes
+    (barrier + synchronize on both sides, MAX over ranks; with N > 1 every rank steps its own shard and the reward
+    vectors are all-gathered as in the headline), the oracle check of the last pass on every rank, and -- rank 0 -- the
+    roofline object of its dominant kernel.  Called by EVERY rank; rank 0 gets the record."""
+    t0 = time.perf_counter()
+    hp, cfg, rolling = build_hotpath(config, args, rank, dev, batch=args.configs_batch)
+    torch.cuda.synchronize(dev)
+    setup_s = time.perf_counter() - t0
+    name, D, cs, n, B, reward, strategy = cfg
+    dt, graphs = time_passes(hp, steps, warmup, use_graph, world, repeats=repeats)
+    hp.env.check()
+    ver = hp.verify()
+    if getattr(hp, "gathered_ok", None) is not None:
+        ver["gathered_rows_match"] = hp.gathered_ok
+        if not hp.gathered_ok:
+            ver["verified"] = False
+            ver.setdefault("mismatch", []).append("the all-gathered rewards differ from the local rows")
+    pid = getattr(hp, "passes_identical", None)
+    if pid is not None:
+        ver["passes_compared_with_the_last"] = pid["passes_compared"]
+        ver["all_passes_identical"] = pid["identical"]
+        if not pid["identical"]:
+            ver["verified"] = False
+            ver.setdefault("mismatch", []).append("replayed passes differ from each other")
+    ok_all = tdist.max_over_ranks(0.0 if ver.get("verified") else 1.0, dev) == 0.0
+    rec = None
+    if rank == 0:
+        roof, _ = roofline_of(hp, config, cfg, rolling, steps, graphs)
+        for k in ("bytes_how", "frac_alg_survey_how", "traffic_source", "kernel_us_how", "peak_measured"):
+            roof.pop(k, None)                                 # the headline's roofline object spells these out once
+        total = B * world * n * steps
+        rec = dict(workload=name, value=total / dt, unit="env-steps/s", n_gpus=world, ms_per_step=dt / steps * 1e3, steps=steps,
+                   warmup=warmup, batch_per_gpu=B, nodes=n, container=cs, packing_strategy=strategy, reward_type=reward,
+                   verified=bool(ver.get("verified")) and ok_all, verification={k: v for k, v in ver.items() if k != "what"},
+                   brackets=len(hp.bracket_times),
+                   spread=(max(hp.bracket_times) - min(hp.bracket_times)) / dt,
+                   launch=("hipGraph replay, %d passes per graph launch" % getattr(hp, "passes_per_graph", GATHER_EVERY)) if use_graph else "eager",
+                   roofline=roof, setup_s=round(setup_s, 1))
+        if cold and world == 1:
+            try:
+                rec["roofline"]["cold"] = cold_reading(cfg, hp, rolling, dev, use_graph, max_slots=16, min_steps=16)
+            except Exception as ex:                           # pragma: no cover
+                rec["roofline"]["cold"] = dict(error=str(ex)[:200])
+        rec["total_s"] = round(time.perf_counter() - t0, 1)
+    del hp, graphs
+    torch.cuda.empty_cache()
+    return rec, ok_all
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1253,10 +1468,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch override")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=50,
                     help="timed brackets of exactly --steps passes each (barrier + synchronize on both sides, MAX over "
                          "ranks); value is their median, the line carries all of them")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--configs", default=None,
+                    help="comma-separated BASELINE configs measured after the headline and reported in the line's `configs` "
+                         "object (default: c3,c4,c5 when the headline is c2 at its own batch on one GPU; 'none' to skip)")
+    ap.add_argument("--configs-batch", type=int, default=None, help="per-GPU batch of the `configs` entries (self-tests)")
+    ap.add_argument("--no-cold", action="store_true", help="skip roofline.cold (the pass with nothing cache-resident)")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (mask_step, env_step) + reset + ratio")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the cold and policy-in-loop readings")
@@ -1277,9 +1497,10 @@ def main():
     ap.add_argument("--approx-windows", action="store_true",
                     help="c5: consecutive independent 10-node windows instead of true rolling windows")
     ap.add_argument("--rand-only", action="store_true", help="c5: RAND instances only instead of the MIX series")
-    ap.add_argument("--ppsg-fixture", action="store_true",
-                    help="c4: the 64 instances the reference's own generator wrote (tests/golden/ppsg_2d.npz) tiled, instead "
-                         "of instances from the device-side perfect-packing generator")
+    ap.add_argument("--ppsg-device", action="store_true",
+                    help="c4: 8 192 distinct instances from the device-side perfect-packing generator (~30 s of set-up) instead "
+                         "of the 64 instances the reference's own generator wrote (tests/golden/ppsg_2d.npz, SURVEY 8(d)) tiled")
+    ap.add_argument("--ppsg-fixture", action="store_true", help="(default since round 5; kept for old command lines)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1308,60 +1529,13 @@ def main():
     local = local % torch.cuda.device_count()   # > 1 rank per GPU only happens in the gloo self-test
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    cfg = CONFIGS[args.config]
+    hp, cfg, rolling = build_hotpath(args.config, args, rank, dev, batch=args.batch)
     name, D, cs, n, B, reward, strategy = cfg
-    if args.batch:
-        B = args.batch
-        cfg = (name, D, cs, n, B, reward, strategy)
-    rolling = args.config in ROLLING and not args.approx_windows
-    if rolling:
-        hp = RollingHotPath(cfg, B, rank * B, dev, window=WINDOW[args.config], fused_rolling=not args.two_launch_rolling,
-                            overlap=args.overlap, mix=not args.rand_only)
-        if not hp.mix:
-            name = name.replace("3D MIX", "3D RAND")
-            cfg = (name, D, cs, n, B, reward, strategy)
-    elif args.config == "k6":
-        hp = EpisodeHotPath(cfg, B, rank * B, dev)
-    else:
-        instances = None
-        if args.config in ("c2", "c3") and not args.synthetic_precedence:
-            instances = "generate"
-        if args.config == "c4" and not args.rand_blocks and not args.ppsg_fixture:
-            instances = "ppsg2d"                                    # device-side perfect-packing generator
-            name = name.replace("RAND-marginal blocks", "device-generated PPSG instances")
-            cfg = (name, D, cs, n, B, reward, strategy)
-        elif args.config == "c4" and not args.rand_blocks:
-            fx = os.path.join(ROOT, "tests", "golden", "ppsg_2d.npz")
-            if os.path.exists(fx):                                  # 64 PPSG instances written by the reference
-                z = np.load(fx)                                     # (tests/golden/make_golden.py --only ppsg)
-                instances = (z["static"].astype(np.float32), z["dynamic"].astype(np.float32))
-                name = name.replace("RAND-marginal blocks", "the reference's PPSG generator: 64 instances tiled x%d" % (B // 64))
-                cfg = (name, D, cs, n, B, reward, strategy)
-        hp = HotPath(cfg, B, rank * B, dev, fused=not args.unfused, window=WINDOW.get(args.config), bits=not args.no_bits,
-                     instances=instances)
     use_graph = not args.no_graph
     dt, graphs = time_passes(hp, args.steps, args.warmup, use_graph, world, repeats=args.repeats)
     hp.env.check()
     total_steps = B * world * n * args.steps
     value = total_steps / dt
-    # who ran where, and how fast each rank was on its own clock (the job's figure is the MAX over ranks)
-    props = torch.cuda.get_device_properties(local)
-    mine = dict(rank=rank, device_index=local, device=torch.cuda.get_device_name(local), pid=os.getpid(),
-                host=socket.gethostname(), pci_bus_id=getattr(props, "pci_bus_id", None),
-                value=B * n * args.steps / statistics.median(hp.local_bracket_times))
-    per_rank = [mine]
-    if world > 1:
-        import torch.distributed as dist
-        per_rank = [None] * world
-        dist.all_gather_object(per_rank, mine)
-        # one process per GPU: under RCCL two ranks on one device would still produce a line, at half the speed and
-        # with an exchange that never left the chip -- refuse loudly instead (the gloo self-test shares a GPU on purpose)
-        distinct = len({(r["host"], r["device_index"]) for r in per_rank})
-        if dist.get_backend() == "nccl" and distinct != world:
-            if rank == 0:
-                print("bench.py: %d RCCL ranks on %d distinct device(s): %s -- refusing to report a line"
-                      % (world, distinct, [(r["rank"], r["host"], r["device_index"]) for r in per_rank]), file=sys.stderr)
-            sys.exit(3)
     # every rank checks its own last pass against the oracle; the line says "verified" only if all did
     ver = dict(verified=None, why="--no-verify") if args.no_verify else hp.verify()
     if getattr(hp, "gathered_ok", None) is not None and not args.no_verify:
@@ -1377,85 +1551,48 @@ def main():
         if not pid["identical"]:
             ver["verified"] = False
             ver.setdefault("mismatch", []).append("replayed passes differ from each other")
+    # who ran where, and how fast each rank was on its own clock (the job's figure is the MAX over ranks)
+    props = torch.cuda.get_device_properties(local)
+    mine = dict(rank=rank, device_index=local, device=torch.cuda.get_device_name(local), pid=os.getpid(),
+                host=socket.gethostname(), pci_bus_id=getattr(props, "pci_bus_id", None),
+                value=B * n * args.steps / statistics.median(hp.local_bracket_times),
+                verified=ver.get("verified"), gathered_rows_match=ver.get("gathered_rows_match"))
+    per_rank = [mine]
+    if world > 1:
+        import torch.distributed as dist
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        # one process per GPU: under RCCL two ranks on one device would still produce a line, at half the speed and
+        # with an exchange that never left the chip -- refuse loudly instead (the gloo self-test shares a GPU on purpose)
+        distinct = len({(r["host"], r["device_index"]) for r in per_rank})
+        if dist.get_backend() == "nccl" and distinct != world:
+            if rank == 0:
+                print("bench.py: %d RCCL ranks on %d distinct device(s): %s -- refusing to report a line"
+                      % (world, distinct, [(r["rank"], r["host"], r["device_index"]) for r in per_rank]), file=sys.stderr)
+            sys.exit(3)
     ok_all = tdist.max_over_ranks(0.0 if ver.get("verified") in (True, None) else 1.0, dev) == 0.0
+
+    # The other BASELINE configs on the same clock (every rank takes part: barriers, MAX over ranks, the all-gather).
+    # N = 1: c3, c4 and c5's 8 192-env shard; N > 1: c5 -- the config BASELINE shards over the node -- beside the c2
+    # weak-scaling value the metric names.
+    more = args.configs if args.configs is not None else (
+        "none" if (args.config != "c2" or args.batch) else "c3,c4,c5" if world == 1 else "c5")
+    extra = {}
+    if more != "none":
+        for c in [x for x in more.split(",") if x and x != args.config]:
+            try:
+                rec, ok_c = measure_config(c, args, rank, world, dev, use_graph, args.steps, args.warmup,
+                                           max(3, min(args.repeats, 10)), cold=not args.no_cold and c == "c3")
+            except Exception as ex:                           # pragma: no cover
+                if world > 1:
+                    raise                                     # a rank that stopped would leave the others in a collective
+                rec, ok_c = dict(error=str(ex)[:300], verified=False), False
+            extra[c] = rec
+            ok_all = ok_all and ok_c
 
     out = None
     if rank == 0:
-        npass = max(3, min(args.steps, 20))
-        kt, empty_us, pass_us = kernel_event_times(hp, npass, graphs[0] if graphs else None)
-        env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
-        R_ = 2 if D == 2 else 6
-        win_b = (1 + D) * hp.nw * R_ * 4 + 3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 4 + 32   # static + dynamic + mask + state
-        per_launch = {"env_step": env_b * B, "mask_step": mask_b * B, "transition": (env_b + mask_b) * B,
-                      "transition_first": (env_b + mask_b) * B,
-                      "rolling_window": win_b * B, "rolling_step": (win_b + env_b) * B,
-                      "episode": episode_bytes(D, n) * B,
-                      "dyn_bits": (3 * hp.nw * hp.nw * R_ * 4 + hp.nw * R_ * 8) * B}
-        names = [k for k in ("transition", "transition_first", "rolling_step", "rolling_window", "episode", "mask_step", "env_step", "dyn_bits",
-                             "ratio", "reset") if k in kt]
-        dom = max([k for k in names if k in per_launch], key=lambda k: kt[k]["total_us"])
-        # the dominant kernel's duration: (event-bracketed launch) - (an empty event pair); for a pass that is
-        # nothing but that kernel the graph-replayed pass / launches is the cleaner figure (it includes the gap)
-        launches = hp.launches_per_pass()
-        if hp.kind == "transition" and hp.fused:
-            other = sum(max(kt[k]["med_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
-            dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
-            how = ("(graph-replayed pass - the other kernels' event time) / launches, passes replayed %d per graph launch as "
-                   "in the timed loop; includes the inter-kernel gap" % getattr(hp, "passes_per_graph", GATHER_EVERY))
-        elif hp.kind == "episode":
-            dom_us, how = pass_us, "event-bracketed pass (one launch)"
-        elif kt[dom].get("run_len", 1) >= 8:
-            dom_us = kt[dom]["run_us"]
-            how = ("one event pair around each run of %d consecutive launches of the kernel, per launch (median over the "
-                   "passes); includes the gap between launches" % kt[dom]["run_len"])
-        else:
-            dom_us = kt[dom]["med_us"]
-            how = ("median event-bracketed launch, uncorrected: reads about 2 us longer than the kernel (an empty event pair "
-                   "takes %.1f us, but most of that overlaps a kernel placed between the two records)" % empty_us)
-        bits_on = bool(getattr(hp, "bits", True)) or rolling
-        comp = {k: compulsory_bytes(k, D, cs, hp.nw, bits=bits_on) * B
-                for k in ("env_step", "mask_step", "transition", "transition_first", "rolling_window", "rolling_step", "dyn_bits")}
-        comp["episode"] = per_launch["episode"]
-        ach = comp[dom] / (dom_us * 1e-6) / 1e9
-        ach_survey = per_launch[dom] / (dom_us * 1e-6) / 1e9
-        cal = load_calibration()
-        kernels = {}
-        for k in names:
-            kernels[k] = dict(med_us_event_pair=round(kt[k]["med_us"], 3), avg_us_event_pair=round(kt[k]["avg_us"], 3),
-                              launches_per_pass=kt[k]["launches"] // npass)
-            if "run_us" in kt[k]:
-                kernels[k]["us_per_launch_in_runs"] = round(kt[k]["run_us"], 3)
-            if k in comp:
-                kernels[k]["bytes_per_launch"] = comp[k]
-            if k in per_launch:
-                kernels[k]["alg_bytes_per_launch_survey"] = per_launch[k]
-        tkey = args.config + ":" + dom + ("_copy" if dom == "transition" and not rolling and not getattr(hp, "bits", False) else "")
-        tr = load_traffic(tkey)
-        traffic = tr["bytes"] if tr else None
-        # write-dominated kernels are held against the measured fill rate, the first-step / copy forms against the copy
-        ceiling_kind = "copy" if (dom == "transition_first" or (dom in ("transition", "mask_step") and not bits_on)) else "fill"
-        ceiling = (cal or {}).get("%s_GBps_beyond_cache" % ceiling_kind)
-        roof = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBS,
-                "bytes_per_launch": comp[dom],
-                "bytes_how": "compulsory bytes of the implemented kernel (inputs it did not produce + outputs; the bit-shadow "
-                             "step writes the fp32 tensor and never reads it) x envs per launch",
-                "frac_alg_survey": ach_survey / HBM_PEAK_GBS,
-                "frac_alg_survey_how": "SURVEY 8(d)'s per-env-step figure (prices an fp32 read AND write of dynamic) / kernel_us / "
-                                       "peak: speed relative to a perfect fp32 copy, NOT a bandwidth fraction -- it passes 1.0 "
-                                       "where the bit-shadow kernel, which never performs the priced fp32 read, outruns such a copy "
-                                       "(`frac` and `frac_hbm` are the bandwidth fractions and stay below 1)",
-                "frac_hbm": (traffic / (dom_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                "peak_measured": dict(GBps=ceiling, kind=ceiling_kind + " beyond the Infinity Cache, 16 B per lane",
-                                      frac=(ach / ceiling) if ceiling else None,
-                                      source=(cal or {}).get("source")) if cal else None,
-                "traffic": traffic,
-                "traffic_source": ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profile set %s "
-                                   "(profiles/%s_%s_pmc_summary.csv); not re-measured in this run"
-                                   % (tr["profile"], tr["profile"].split()[0], args.config)) if tr else None,
-                "bytes_per_env_step": comp[dom] // B, "alg_bytes_per_env_step_survey": per_launch[dom] // B, "units_per_launch": B,
-                "kernel_us": dom_us, "kernel_us_how": how, "kernel_us_rocprof": tr.get("kernel_us") if tr else None,
-                "pass_us": pass_us, "launches_per_pass": launches, "event_pair_overhead_us": empty_us}
+        roof, kernels = roofline_of(hp, args.config, cfg, rolling, args.steps, graphs)
         if rolling:
             inst = ("MIX (pack.py:67-97): envs [0,B/2) perfect-packing (PPSG) instances, [B/2,B) RAND, both device-generated "
                     "into a 7x7x250 initial container.  PPSG = generate_blocks_with_GT's steps on 5 stacked 10-block "
@@ -1516,6 +1653,14 @@ def main():
             "roofline": roof,
             "kernels": kernels,
         }
+        if world == 1 and not args.no_cold and hp.kind in ("transition", "rolling") and not args.no_variants:
+            try:
+                hp.cold = cold_reading(cfg, hp, rolling, dev, use_graph)
+                out["roofline"]["cold"] = hp.cold
+            except Exception as ex:                           # pragma: no cover
+                out["roofline"]["cold"] = dict(error=str(ex)[:200])
+        if extra:
+            out["configs"] = extra
         if not args.no_cpu_baseline and world == 1:
             cb = cpu_baseline_rolling(hp) if rolling else cpu_baseline(hp)
             attach_reference_cpu(cb, args.config)

@@ -440,7 +440,10 @@ typedef struct tap_stepper tap_stepper;
 
 typedef struct tap_stepper_buffers {
     unsigned long long *bits[2]; /* (B, nR) uint64 -- (B, 2, nR) above 64 rows: the bit shadow of dyn[w] */
-    float *dyn[2];               /* (B, rows, nR): update_dynamic's result (pack.py:333-376) */
+    float *dyn[2];               /* (B, rows, nR): update_dynamic's result (pack.py:333-376) as the fp32 tensor model.py:378
+                                    feeds the encoder.  Both NULL: the step keeps `dynamic` as bits[w] only and skips the
+                                    expansion (78 % of a c2 step's bytes) -- for callers that consume the shadow; masks,
+                                    placements, features and ratio are the same either way */
     float *current[2];           /* (B, nR): update_mask's new_mask.float() (pack.py:329-331) */
     float *mask[2];              /* (B, nR): update_mask's chosen_mask */
     float *feature;              /* (B, feature_len) nullable: add_new_block's return, layout of model.py:456-465 */

@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import tap_net_amd as T          # noqa: E402
 from tap_net_amd import _lib     # noqa: E402
 
-KINDS = {0: "copy", 1: "copy_nt", 2: "fill", 3: "fill_nt", 4: "read", 5: "fill_wt", 6: "fill_wt_slab_shape", 7: "fill_wt_wave_linear"}
+KINDS = {0: "copy", 1: "copy_nt", 2: "fill", 3: "fill_nt", 4: "read", 5: "fill_wt", 6: "fill_wt_slab_shape", 7: "fill_wt_wave_linear", 8: "fill_wt_run_of_rows"}
 
 
 def run(kind, nbytes, cold, dev, reps=30, slots=None):
@@ -82,7 +82,7 @@ def main():
     dev = torch.device("cuda", 0)
     rows = []
     if args.store_shapes:
-        for kind in (2, 3, 5, 6, 7):
+        for kind in (2, 3, 5, 6, 7, 8):
             for cold in (False, True):
                 r = run(kind, 19_660_800, cold, dev)
                 rows.append(r)

@@ -27,14 +27,14 @@ NOSTREAM, NOPLACE = 1 << 8, 1 << 9
 SHAPES = {"c2": (2, [5, 50], 10, 8192), "c3": (3, [5, 5, 50], 10, 4096)}
 
 
-def setup(shape):
+def setup(shape, seed=1):
     import numpy as np, torch
     import tap_net_amd as T
     from tap_net_amd import _lib, synth
     D, cs, n, B = SHAPES[shape]
     dev = torch.device("cuda:0")
-    static, dynamic = synth.rand_instances(B, n, D, seed=1)
-    tape = synth.random_feasible_tape(static, dynamic, n, seed=2).t().contiguous().to(dev)    # (n, B)
+    static, dynamic = synth.rand_instances(B, n, D, seed=seed)
+    tape = synth.random_feasible_tape(static, dynamic, n, seed=seed + 1).t().contiguous().to(dev)    # (n, B)
     st, dy = static.to(dev), dynamic.to(dev)
     env = T.BatchedContainer(B, cs, n, "C+P+S-lb-soft", "diff", device=dev)
     R = 2 if D == 2 else 6
@@ -45,12 +45,12 @@ def setup(shape):
                cur=[torch.empty(B, nR, **f32) for _ in range(2)], mask=[torch.ones(B, nR, **f32) for _ in range(2)],
                ones=torch.ones(B, nR, **f32), feat=env._new_feature(), ratio=torch.empty(B, **f32), cnt=torch.zeros(1, dtype=torch.int32, device=dev))
     L, ctx = _lib.lib(), _lib.ctx(dev)
-    P = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    P = lambda t: C.c_void_p(t.data_ptr() if t is not None else None)   # noqa: E731
 
-    def step(t, extra=0, inplace=False, stream=None):
+    def step(t, extra=0, inplace=False, stream=None, nodyn=False):
         s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         w, r = t & 1, (t & 1) ^ 1
-        out = buf["dyn"][0] if inplace else buf["dyn"][w]
+        out = None if nodyn else buf["dyn"][0] if inplace else buf["dyn"][w]
         flags = (1 if t == 0 else 0) | (2 if t == n - 1 else 0) | extra
         if t == 0:
             rc = L.tap_transition_first(ctx, C.byref(env.desc), P(env._state), n, R, rows, 3, P(dy), P(st), st.shape[1], P(tape[0]),
@@ -64,26 +64,32 @@ def setup(shape):
     return dict(torch=torch, np=np, L=L, n=n, B=B, dev=dev, step=step, buf=buf, env=env, D=D, cs=cs)
 
 
-def run_switch(shape):
-    S = setup(shape)
+def run_switch(shape, slots=1):
+    """slots > 1: the COLD form -- pass i of the graph runs on instance set i % slots (own instances, tape, containers and
+    every output buffer), the sets together several times the 256 MB Infinity Cache (bench.py: roofline.cold)."""
+    sets = [setup(shape, seed=1 + 10 * k) for k in range(slots)]
+    S = sets[0]
     torch, n = S["torch"], S["n"]
     res = {}
-    PASSES = 16
-    for name, extra, inplace in (("empty", NOSTREAM | NOPLACE, False), ("place", NOSTREAM, False), ("mask", NOPLACE, False),
-                                 ("fused", 0, False), ("fused_inplace", 0, True)):
-        def one_pass():
+    PASSES = 16 if slots == 1 else slots
+    for name, extra, inplace, nodyn in (("empty", NOSTREAM | NOPLACE, False, False), ("place", NOSTREAM, False, False),
+                                        ("mask", NOPLACE, False, False), ("mask_no_fp32", NOPLACE, False, True),
+                                        ("fused", 0, False, False), ("fused_no_fp32", 0, False, True),
+                                        ("fused_inplace", 0, True, False)):
+        def one_pass(k=0):
             for t in range(n):
-                S["step"](t, extra, inplace)
+                sets[k % slots]["step"](t, extra, inplace, nodyn=nodyn)
         side = torch.cuda.Stream(device=S["dev"])
         side.wait_stream(torch.cuda.current_stream(S["dev"]))
         with torch.cuda.stream(side):
-            one_pass(); one_pass()
+            for k in range(slots):
+                one_pass(k); one_pass(k)
         torch.cuda.current_stream(S["dev"]).wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            for _ in range(PASSES):
-                one_pass()
+            for k in range(PASSES):
+                one_pass(k)
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
@@ -97,7 +103,8 @@ def run_switch(shape):
         vals.sort()
         res[name] = dict(us_per_launch=round(vals[len(vals) // 2], 3), min=round(vals[0], 3), max=round(vals[-1], 3))
     res["how"] = ("per-launch time of a graph of %d passes x %d launches (step 0 = tap_transition_first, the others "
-                  "tap_transition_bits), median of 7 brackets of 10 replays; the first step's fp32 read is in the average" % (PASSES, n))
+                  "tap_transition_bits) over %d instance set(s), median of 7 brackets of 10 replays; the first step's fp32 read is "
+                  "in the average; *_no_fp32 = dyn_out NULL (the step keeps `dynamic` as its bit shadow only)" % (PASSES, n, slots))
     return res
 
 
@@ -159,18 +166,23 @@ if __name__ == "__main__":
     ap.add_argument("--out", default=None)
     ap.add_argument("--child", default=None)
     ap.add_argument("--shape", default="c2")
+    ap.add_argument("--slots", type=int, default=1)
+    ap.add_argument("--no-timeline", action="store_true")
     a = ap.parse_args()
     if a.child:
-        r = run_switch(a.shape) if a.child == "switch" else run_timeline(a.shape)
+        r = run_switch(a.shape, a.slots) if a.child == "switch" else run_timeline(a.shape)
         print("RESULT " + json.dumps(r))
         sys.exit(0)
     allr = {}
     for shape in ("c2", "c3"):
         allr[shape] = {}
-        for kind, lib in (("switch", "libtapenv_PROF_SWITCH.so"), ("timeline", "libtapenv_PROF.so")):
+        kinds = [("switch", "libtapenv_PROF_SWITCH.so", 1), ("switch_cold", "libtapenv_PROF_SWITCH.so", 20 if shape == "c2" else 14)]
+        if not a.no_timeline:
+            kinds.append(("timeline", "libtapenv_PROF.so", 1))
+        for kind, lib, slots in kinds:
             env = dict(os.environ, TAP_LIB_PATH=os.path.join(ROOT, "build_prof", lib))
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", kind, "--shape", shape], env=env,
-                               capture_output=True, text=True)
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", kind.split("_")[0], "--shape", shape,
+                                "--slots", str(slots)], env=env, capture_output=True, text=True)
             line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
             if not line:
                 print(p.stdout[-2000:], p.stderr[-3000:], file=sys.stderr)

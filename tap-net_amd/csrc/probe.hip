@@ -49,6 +49,8 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe(v4f *__restrict__ dst, c
 //      a 4-wave workgroup owns 8 consecutive slabs, a wave two of them; lane (rsub, c4) = (lane / 5, lane % 5) of 60
 //      writes the float4 of rows rsub, rsub + 12, rsub + 24 -- store instructions of 960 / 960 / 480 contiguous bytes
 //   7  the same 4 800 bytes per wave written linearly: float4 i * 64 + lane, five instructions of 1 024 ... 704 bytes
+//   8  (round 5) the wave's two slabs as ONE run of 60 rows: lane (rsub, c4) of 60 writes rows rsub + 12 i, i = 0 .. 4 --
+//      five instructions of 960 bytes, each starting on a 64-byte granule (the round-5 stream wave's shape)
 template <int KIND>
 __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_slab(v4f *__restrict__ dst, size_t n_wg)
 {
@@ -62,6 +64,10 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_slab(v4f *__restrict__ d
             for (int k = 0; k < 2; ++k)
                 for (int r = rsub; r < 30; r += 12)
                     asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + k * 150 + r * 5 + c4), "v"(v) : "memory");
+    } else if (KIND == 8) {
+        if (lane < 60)
+            for (int q = lane; q < 300; q += 60)
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + q), "v"(v) : "memory");
     } else {
         for (int q = lane; q < 300; q += 64)
             asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + q), "v"(v) : "memory");
@@ -84,10 +90,10 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_wt(v4f *__restrict__ dst
 extern "C" int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, size_t bytes, void *stream)
 {
     if (!ctx) return TAP_E_INVALID;
-    if (kind < 0 || kind > 7 || bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16)
-        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kind 0..7, 16-byte aligned buffers and sizes");
+    if (kind < 0 || kind > 8 || bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16)
+        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kind 0..8, 16-byte aligned buffers and sizes");
     if (kind >= 6 && bytes % 19200)
-        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kinds 6 / 7 write whole workgroups of 8 slabs x 2400 bytes");
+        return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kinds 6 .. 8 write whole workgroups of 8 slabs x 2400 bytes");
     if ((kind != 4 && !dst) || ((kind == 0 || kind == 1 || kind == 4) && !src))
         return tap_fail(ctx, TAP_E_INVALID, "bw_probe: null buffer");
     const size_t n4 = bytes / 16;
@@ -102,7 +108,8 @@ extern "C" int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, 
         if (!dst) return tap_fail(ctx, TAP_E_INVALID, "bw_probe: null buffer");
         if (kind == 5) hipLaunchKernelGGL(k_bw_probe_wt<5>, grid, dim3(TAP_BLOCK), 0, st, d, n4);
         else if (kind == 6) hipLaunchKernelGGL(k_bw_probe_slab<6>, dim3((unsigned)(bytes / 19200)), dim3(TAP_BLOCK), 0, st, d, bytes / 19200);
-        else hipLaunchKernelGGL(k_bw_probe_slab<7>, dim3((unsigned)(bytes / 19200)), dim3(TAP_BLOCK), 0, st, d, bytes / 19200);
+        else if (kind == 7) hipLaunchKernelGGL(k_bw_probe_slab<7>, dim3((unsigned)(bytes / 19200)), dim3(TAP_BLOCK), 0, st, d, bytes / 19200);
+        else hipLaunchKernelGGL(k_bw_probe_slab<8>, dim3((unsigned)(bytes / 19200)), dim3(TAP_BLOCK), 0, st, d, bytes / 19200);
         TAP_LAUNCH_CHECK(ctx, "k_bw_probe");
         return TAP_OK;
     }

@@ -42,6 +42,18 @@ struct RollArgs {
     int wt;                   // flavour of dynamic_out's stores (tap_masks.h: store_stream / tap_write_through)
 };
 
+// the window's fp32 tensor is expanded like the step's (tap_masks.h): lane roles rotated by the slab's offset inside
+// its 64-byte granule; `dy` = this instance's slab
+__device__ __forceinline__ LaneRole roll_lane_role(int v, const float *dy, int C4, int RP, int rows)
+{
+#ifdef TAP_STREAM_UNALIGNED
+    const int add = 0;
+#else
+    const int add = ((RP * C4) & 3) == 0 ? (int)((reinterpret_cast<uintptr_t>(dy) >> 4) & 3) : 0;
+#endif
+    return stream_lane_role(v, 0, C4, RP, 65536 / C4 + 1, 0, add, (rows + RP - 1) / RP);
+}
+
 __device__ __forceinline__ bool rng_meet(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
 
 // ---- relations: the same box predicates as k_precedence (generate.hip), one lane per node --------
@@ -461,20 +473,18 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
     if (!packed) return;
     tap_wave_lds_sync();
     PROF(6);
-    const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
-    if (rsub < RP) {
-        // rows rsub, rsub + RP, ...: the words are shifted down by rsub once, so that row i*RP sits at the
-        // wave-uniform bit i*RP and the per-row work is a bit-field extract and a convert
-        const u64 w0 = S.cw[c4 * 4] >> rsub, w1 = S.cw[c4 * 4 + 1] >> rsub, w2 = S.cw[c4 * 4 + 2] >> rsub,
-                  w3 = S.cw[c4 * 4 + 3] >> rsub;
-        float4 *dst = reinterpret_cast<float4 *>(dy) + c4 + (size_t)rsub * C4;
-        for (int q = 0; q * RP + rsub < rows; ++q) {
-            const int sh = q * RP;                                       // wave-uniform
-            const unsigned h0 = sh < 32 ? (unsigned)w0 : (unsigned)(w0 >> 32), h1 = sh < 32 ? (unsigned)w1 : (unsigned)(w1 >> 32),
-                           h2 = sh < 32 ? (unsigned)w2 : (unsigned)(w2 >> 32), h3 = sh < 32 ? (unsigned)w3 : (unsigned)(w3 >> 32);
-            const int s5 = sh & 31;
-            store_stream(&dst[(size_t)sh * C4], make_float4((float)((h0 >> s5) & 1u), (float)((h1 >> s5) & 1u),
-                                                            (float)((h2 >> s5) & 1u), (float)((h3 >> s5) & 1u)), a.wt);
+    const int C4 = nRc >> 2, RP = 64 / C4;
+    if (v < RP * C4) {
+        // lane roles rotated so that every store instruction starts on a 64-byte granule (tap_masks.h: stream_lane_role)
+        const LaneRole role = roll_lane_role(v, dy, C4, RP, rows);
+        const int c4 = role.c4;
+        const u64 w0 = S.cw[c4 * 4], w1 = S.cw[c4 * 4 + 1], w2 = S.cw[c4 * 4 + 2], w3 = S.cw[c4 * 4 + 3];
+        float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
+        int rw = role.r0;
+        for (int i = 0; i < role.nq; ++i, rw += RP) {
+            if ((unsigned)rw >= (unsigned)rows) continue;
+            store_stream(&dst[(size_t)rw * C4], make_float4(bit_as_float(w0, rw), bit_as_float(w1, rw), bit_as_float(w2, rw),
+                                                            bit_as_float(w3, rw)), a.wt);
         }
     }
     PROF(7);
@@ -541,8 +551,21 @@ __device__ __forceinline__ void rolling_emit_fast_tail(const RollArgs &a, int in
     tap_wave_lds_sync();
     PROF(6);
     {
-        const int rsub = v / C4, c4 = v - rsub * C4;
-        if (rsub < RP) {
+        // Lane roles rotated by sb = (slab start / 16) mod 4 so that every store instruction starts on a 64-byte
+        // granule (tap_masks.h: stream_lane_role): a 7 200-byte slab (c5) starts 32 bytes into one for every other
+        // instance.  The sb lanes that wrapped run one instruction late.
+        constexpr int K = RP * C4;
+        constexpr bool AL = (K & 3) == 0;
+#ifdef TAP_STREAM_UNALIGNED
+        const int sb = 0;
+#else
+        const int sb = AL ? __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<uintptr_t>(dy) >> 4) & 3)) : 0;
+#endif
+        if (v < K) {
+            int role = v - sb;
+            const int late = role < 0 ? 1 : 0;
+            role += late ? K : 0;
+            const int rsub = role / C4, c4 = role - rsub * C4;
             const uint4 cq = *reinterpret_cast<const uint4 *>(&S.f.cw32[c4 * 4]);
             unsigned mk = 0u;
 #pragma unroll
@@ -553,9 +576,13 @@ __device__ __forceinline__ void rolling_emit_fast_tail(const RollArgs &a, int in
             il |= ((cq.z >> rsub) & mk) << 2;
             il |= ((cq.w >> rsub) & mk) << 3;
             float4 *dst = reinterpret_cast<float4 *>(dy) + c4 + (size_t)rsub * C4;
+            // the late lanes play roles K - sb .. K - 1 (row groups (K - 3) / C4 and up): one more instruction only if
+            // such a lane still has a row in its last round
+            constexpr int NI = QN + ((AL && RP * (QN - 1) + (K - 3) / C4 < ROWS) ? 1 : 0);
+            int q = -late;
 #pragma unroll
-            for (int q = 0; q < QN; ++q) {
-                if (RP * q + rsub < ROWS) {
+            for (int i = 0; i < NI; ++i, ++q) {
+                if (q >= 0 && RP * q + rsub < ROWS) {
                     const unsigned nib = (il >> (RP * q)) & 15u;
                     store_stream(&dst[(size_t)RP * q * C4], *reinterpret_cast<const float4 *>(&S.f.lut[nib][0]), a.wt);
                 }
@@ -810,13 +837,18 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
     }
     if (!packed) return;
     tap_wave_lds_sync();
-    const int C4 = nRc >> 2, rsub = v / C4, c4 = v - rsub * C4, RP = 64 / C4;
-    if (rsub < RP) {
+    const int C4 = nRc >> 2, RP = 64 / C4;
+    if (v < RP * C4) {
+        const LaneRole role = roll_lane_role(v, dy, C4, RP, rows);       // store instructions start on 64-byte granules
+        const int c4 = role.c4;
         const u64 c0 = S.cw[c4 * 4], c1 = S.cw[c4 * 4 + 1], c2 = S.cw[c4 * 4 + 2], c3 = S.cw[c4 * 4 + 3];
         float4 *dst = reinterpret_cast<float4 *>(dy) + c4;
-        for (int rw = rsub; rw < rows; rw += RP)
+        int rw = role.r0;
+        for (int i = 0; i < role.nq; ++i, rw += RP) {
+            if ((unsigned)rw >= (unsigned)rows) continue;
             store_stream(&dst[(size_t)rw * C4], make_float4(bit_as_float(c0, rw), bit_as_float(c1, rw), bit_as_float(c2, rw),
                                                             bit_as_float(c3, rw)), a.wt);
+        }
     }
 }
 

@@ -31,6 +31,9 @@ struct MaskArgs {
     // host so that no kernel divides by a run-time value: c4_magic = ceil(2^16 / (nR/4)), rp = 64 / (nR/4)
     int c4_magic, rp;
     int wt;   // flavour of the fp32 expansion's stores (store_stream), set by mask_finish()
+    // 64-byte alignment of the expansion's store instructions (stream_lane_role): float4 offset of env b's slab
+    // inside its 64-byte granule = (b * sb_mul + sb_add) & 3; nq = ceil(rows / rp)
+    int sb_mul, sb_add, nq, nq2;   // nq2 = ceil(2 * rows / rp): a fused step's stream wave expands two slabs as one run
 };
 
 inline int tap_write_through(size_t bytes);
@@ -41,7 +44,44 @@ inline MaskArgs mask_finish(MaskArgs a)
     a.c4_magic = c4 > 0 ? 65536 / c4 + 1 : 0;
     a.rp = c4 > 0 ? 64 / c4 : 0;
     a.wt = tap_write_through((size_t)a.B * a.rows * a.nR * sizeof(float));
+    const bool al = c4 > 0 && ((a.rp * c4) & 3) == 0;     // a store instruction's rp * c4 float4 are whole 64-byte granules
+    a.sb_mul = al ? (a.rows * c4) & 3 : 0;
+    a.sb_add = al ? (int)((reinterpret_cast<uintptr_t>(a.dyn_out) >> 4) & 3) : 0;
+    a.nq = a.rp > 0 ? (a.rows + a.rp - 1) / a.rp : 0;
+    a.nq2 = a.rp > 0 ? (2 * a.rows + a.rp - 1) / a.rp : 0;
     return a;
+}
+
+// ---- which rows a lane expands, and when (round 5) ------------------------------------------------------------
+// The expansion's store instructions cover K = rp * (nR/4) consecutive float4 (rp whole rows) of a slab, but a
+// slab of rows * nR * 4 bytes starts wherever the previous one ended: at c2 (2 400 B) three slabs in four start 32
+// or 96 bytes into a 64-byte granule, at c3 / c5 (7 200 B) every other one.  Every store instruction then
+// begins and ends inside a granule, and on buffers that are not cache-resident the memory side has to merge the
+// pieces: a bare write-through fill in that shape takes 6.14 us per 19.66 MB against 4.02 us for stores that
+// start on 64 bytes (profiles/r04_bw_store_shapes.json, kinds 6 / 7).  The cure costs no data movement between
+// lanes: ROTATE the lanes' roles by sb = (slab start / 16) mod 4.  Lane l plays role (l - sb) mod K =
+// (rsub, c4); the sb lanes that wrapped run one instruction late, so instruction i covers the float4
+// [K*i - sb, K*i + K - sb) of the slab -- a range that starts on a granule.  Every lane still writes exactly the
+// rows rsub, rsub + rp, ... of its own four columns, from words it loaded itself; only the instruction in which it
+// does so moved.
+struct LaneRole {
+    int rsub, c4;    // role: rows rsub + rp*q of column quad c4
+    int r0;          // row of the lane's store in instruction 0 (negative: the lane starts one instruction late)
+    int nq;          // store instructions of the run: the caller's count, + 1 when the roles are rotated (wave-uniform)
+};
+
+__device__ __forceinline__ LaneRole stream_lane_role(int lane, int env, int C4, int RP, int c4_magic, int sb_mul, int sb_add, int nq)
+{
+    const int sb = __builtin_amdgcn_readfirstlane((env * sb_mul + sb_add) & 3);     // env is wave-uniform
+    int role = lane - sb;
+    const bool late = role < 0;
+    role += late ? RP * C4 : 0;
+    LaneRole o;
+    o.rsub = (int)(((unsigned)role * (unsigned)c4_magic) >> 16);
+    o.c4 = role - o.rsub * C4;
+    o.r0 = o.rsub - (late ? RP : 0);
+    o.nq = nq + (sb != 0);
+    return o;
 }
 
 __host__ __device__ __forceinline__ bool mask_builds_bits(const MaskArgs &a) { return !a.bits_in && a.bits_out && a.dyn_in; }
@@ -416,10 +456,22 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
                                                  float *lds = nullptr)
 {
     typedef unsigned long long u64;
+    static_assert(NS <= 2, "a stream wave expands one or two slabs");
     if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
     const int nR = a.nR, C4 = nR >> 2, rows = a.rows, n = a.n;
-    const int rsub = (int)(((unsigned)lane * (unsigned)a.c4_magic) >> 16), c4 = lane - rsub * C4, RP = a.rp;
-    const bool lane_on = rsub < RP;
+    const int RP = a.rp;
+    const bool lane_on = lane < RP * C4;
+    // ONE role per wave: the wave's slabs are contiguous, so their rows form one run of NS * rows rows of nR floats; the
+    // lane keeps column quad c4 of EVERY slab and walks the rows r0, r0 + RP, ... of the whole run (stream_lane_role:
+    // rotated so that each store instruction starts on a 64-byte granule).  Same registers as the fixed (rsub, c4)
+    // mapping of round 4 -- per-slab roles cost six more and a wave per SIMD (68 VGPRs, measured: 1 264 against
+    // 1 450 M env-steps/s at B = 1 M).
+#ifdef TAP_STREAM_UNALIGNED   // A/B builds: round 4's fixed roles (store instructions start wherever the slab does)
+    const LaneRole role = stream_lane_role(lane, 0, C4, RP, a.c4_magic, 0, 0, 0);
+#else
+    const LaneRole role = stream_lane_role(lane, senv0, C4, RP, a.c4_magic, a.sb_mul, a.sb_add, 0);
+#endif
+    const bool first_row = role.rsub == 0;               // these lanes also write the slab's new shadow words
     u64 *tile = reinterpret_cast<u64 *>(lds);
     // a readable, 16-byte aligned address for the inputs a caller may leave out (ptr / static: the initial mask,
     // model.py:297-307; mask_in: a stepper's first step starts from ones)
@@ -452,7 +504,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             const int env = on[k] ? senv0 + k : senv0;
 #pragma unroll
             for (int c = 0; c < NC; ++c) bj[k][c] = a.bits_in[(size_t)env * nR + min(lane + 64 * c, nR - 1)];
-            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + c4 * 4);
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + role.c4 * 4);
             w[k][0] = src[0];
             w[k][1] = src[1];
         }
@@ -463,7 +515,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         for (int k = 0; k < NS; ++k) {
 #pragma unroll
             for (int c = 0; c < NC; ++c) bj[k][c] = tile[(size_t)k * nR + min(lane + 64 * c, nR - 1)];
-            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(tile + (size_t)k * nR + c4 * 4);
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(tile + (size_t)k * nR + role.c4 * 4);
             w[k][0] = src[0];
             w[k][1] = src[1];
         }
@@ -497,40 +549,60 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         clr[k] = m;
         pm[k] = valid ? tap_mod_small(p, n) : -1;                             // pack.py:314-316; -1 matches no column
     }
+    // the new words of this lane's column quad, per slab
+    u64 nw[NS][4];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        nw[k][0] = w[k][0].x & ~clr[k]; nw[k][1] = w[k][0].y & ~clr[k];
+        nw[k][2] = w[k][1].x & ~clr[k]; nw[k][3] = w[k][1].y & ~clr[k];
+    }
+    if (lane_on) {
+        if (a.dyn_out) {
+            // the fp32 tensor: instruction i = the lane's row r0 + RP * i of the wave's run when that is a row of it (late
+            // lanes skip i = 0); rows >= `rows` belong to the second slab
+            const int non = (NS > 1 && on[NS - 1]) ? 2 : 1;
+            const int total = non * rows;
+            const int nq = (non > 1 ? a.nq2 : a.nq) + role.nq;                // role.nq: one more instruction when rotated
+            float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)senv0 * rows * nR) + role.c4;
+            int rr = role.r0;
+            if (rows <= 32) {
+                // n <= 10 (every BASELINE window): the column words fit 32 bits -- a bit-field extract and a
+                // convert per element, no half selection
+                for (int i = 0; i < nq; ++i, rr += RP) {
+                    if ((unsigned)rr >= (unsigned)total) continue;
+                    const bool up = NS > 1 && rr >= rows;
+                    const int r = up ? rr - rows : rr;
+                    const unsigned m0 = up ? (unsigned)nw[NS - 1][0] : (unsigned)nw[0][0], m1 = up ? (unsigned)nw[NS - 1][1] : (unsigned)nw[0][1],
+                                   m2 = up ? (unsigned)nw[NS - 1][2] : (unsigned)nw[0][2], m3 = up ? (unsigned)nw[NS - 1][3] : (unsigned)nw[0][3];
+                    const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
+                                                 (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
+                    store_stream(&dst[(size_t)rr * C4], v, a.wt);
+                }
+            } else {
+                for (int i = 0; i < nq; ++i, rr += RP) {
+                    if ((unsigned)rr >= (unsigned)total) continue;
+                    const bool up = NS > 1 && rr >= rows;
+                    const int r = up ? rr - rows : rr;
+                    const float4 v = make_float4(bit_as_float(up ? nw[NS - 1][0] : nw[0][0], r), bit_as_float(up ? nw[NS - 1][1] : nw[0][1], r),
+                                                 bit_as_float(up ? nw[NS - 1][2] : nw[0][2], r), bit_as_float(up ? nw[NS - 1][3] : nw[0][3], r));
+                    store_stream(&dst[(size_t)rr * C4], v, a.wt);
+                }
+            }
+        }
+        if (first_row && a.bits_out) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (!on[k]) continue;
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + (size_t)(senv0 + k) * nR + role.c4 * 4);
+                dst[0] = make_ulonglong2(nw[k][0], nw[k][1]);
+                dst[1] = make_ulonglong2(nw[k][2], nw[k][3]);
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         if (!on[k]) continue;
-#ifdef TAP_STREAM_PACE        // A/B builds: a slab's stores acknowledged before the next slab's go out (what round 3 did by accident)
-        if (k > 0) __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
         const int env = senv0 + k;
-        if (lane_on) {
-            const u64 n0 = w[k][0].x & ~clr[k], n1 = w[k][0].y & ~clr[k], n2 = w[k][1].x & ~clr[k], n3 = w[k][1].y & ~clr[k];
-            if (a.dyn_out) {
-                float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
-                if (rows <= 32) {
-                    // n <= 10 (every BASELINE window): the column words fit 32 bits -- a bit-field extract and a
-                    // convert per element, no half selection
-                    const unsigned m0 = (unsigned)n0, m1 = (unsigned)n1, m2 = (unsigned)n2, m3 = (unsigned)n3;
-                    for (int r = rsub; r < rows; r += RP) {
-                        const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
-                                                     (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
-                        store_stream(&dst[(size_t)r * C4], v, a.wt);
-                    }
-                } else {
-                    for (int r = rsub; r < rows; r += RP) {
-                        const float4 v = make_float4(bit_as_float(n0, r), bit_as_float(n1, r), bit_as_float(n2, r),
-                                                     bit_as_float(n3, r));
-                        store_stream(&dst[(size_t)r * C4], v, a.wt);
-                    }
-                }
-            }
-            if (rsub == 0 && a.bits_out) {
-                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + (size_t)env * nR + c4 * 4);
-                dst[0] = make_ulonglong2(n0, n1);
-                dst[1] = make_ulonglong2(n2, n3);
-            }
-        }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
@@ -746,6 +818,7 @@ __device__ __forceinline__ void stream_wave_bits2(const MaskArgs &a, int env, in
         tap_wave_lds_sync_m();
     }
     const u64 *win = BUILD ? tile : a.bits_in + (size_t)env * 2 * nR;
+    const LaneRole role = stream_lane_role(lane, env, C4, RP, a.c4_magic, a.sb_mul, a.sb_add, a.nq);   // expansion: rotated roles
     u64 bj[NC][2], w4[2][4];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -755,7 +828,7 @@ __device__ __forceinline__ void stream_wave_bits2(const MaskArgs &a, int env, in
     }
 #pragma unroll
     for (int w = 0; w < 2; ++w) {
-        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(win + w * nR + c4 * 4);
+        const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(win + w * nR + role.c4 * 4);
         const ulonglong2 s0 = lane_on ? src[0] : make_ulonglong2(0, 0), s1 = lane_on ? src[1] : make_ulonglong2(0, 0);
         w4[w][0] = s0.x; w4[w][1] = s0.y; w4[w][2] = s1.x; w4[w][3] = s1.y;
     }
@@ -777,8 +850,10 @@ __device__ __forceinline__ void stream_wave_bits2(const MaskArgs &a, int env, in
 #pragma unroll
             for (int q = 0; q < 4; ++q) w4[w][q] &= ~clr[w];
         if (a.dyn_out) {
-            float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
-            for (int r = rsub; r < rows; r += RP) {
+            float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + role.c4;
+            int r = role.r0;
+            for (int i = 0; i < role.nq; ++i, r += RP) {
+                if ((unsigned)r >= (unsigned)rows) continue;
                 const bool up = r >= 64;
                 const int rb = r & 63;
                 const float4 v = make_float4(bit_as_float(up ? w4[1][0] : w4[0][0], rb), bit_as_float(up ? w4[1][1] : w4[0][1], rb),
@@ -786,10 +861,10 @@ __device__ __forceinline__ void stream_wave_bits2(const MaskArgs &a, int env, in
                 store_stream(&dst[(size_t)r * C4], v, a.wt);
             }
         }
-        if (rsub == 0 && a.bits_out) {
+        if (role.rsub == 0 && a.bits_out) {
 #pragma unroll
             for (int w = 0; w < 2; ++w) {
-                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + ((size_t)env * 2 + w) * nR + c4 * 4);
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + ((size_t)env * 2 + w) * nR + role.c4 * 4);
                 dst[0] = make_ulonglong2(w4[w][0], w4[w][1]);
                 dst[1] = make_ulonglong2(w4[w][2], w4[w][3]);
             }

@@ -367,9 +367,13 @@ extern "C" int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *sta
     if (d->B > 0) {                                  // an empty batch has no buffers to check
         if (!state) return tap_fail(ctx, TAP_E_INVALID, "bad stepper arguments");
         for (int w = 0; w < 2; ++w)
-            if (!buf->bits[w] || !buf->dyn[w] || !buf->current[w] || !buf->mask[w])
-                return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of bits / dyn / current / mask");
-        if (buf->bits[0] == buf->bits[1] || buf->dyn[0] == buf->dyn[1] || buf->current[0] == buf->current[1] ||
+            if (!buf->bits[w] || !buf->current[w] || !buf->mask[w])
+                return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of bits / current / mask");
+        // dyn: both phases, or neither -- a caller whose encoder consumes the bit shadow skips the fp32 expansion of
+        // update_dynamic's result (78 % of a c2 step's bytes); masks, placements and ratio do not depend on it
+        if ((buf->dyn[0] == nullptr) != (buf->dyn[1] == nullptr))
+            return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of dyn, or neither (no fp32 expansion)");
+        if (buf->bits[0] == buf->bits[1] || (buf->dyn[0] && buf->dyn[0] == buf->dyn[1]) || buf->current[0] == buf->current[1] ||
             buf->mask[0] == buf->mask[1] || !buf->ratio)
             return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers and ratio is required");
     }

@@ -233,7 +233,15 @@ class BatchedContainer(object):
 # within a round, or any attribute / calc_ratio read, completes the round early (the members not yet called just do
 # not step), so nothing is ever left un-run -- but a row read before its round completed holds no data.  Off by
 # default (every Container is then its own one-env launch + sync, correct for any pattern); switch it on with
+# `with tools.lockstep_scope():` around the forward (the pool is closed at the end of the block),
 # tools.lockstep_containers(True) or TAP_LOCKSTEP_CONTAINERS=1.
+# Membership: the Containers built back to back with the same arguments while the pool is open (it closes at its first
+# use, at the end of a lockstep_scope, or at the next lockstep_containers call).  A Container that was collected before
+# the pool's first use is not waited for; one that is alive but never called (a probe built with the same arguments
+# outside a scope) makes the first "second call" raise LockstepError and is dropped -- rows are handed out holding a
+# sentinel (int64 min), never stale memory.  The 'mul' input types pool containers_a and containers_b together
+# (model.py:290-292 builds them alternately with the same arguments): every env calls exactly one method on each of
+# its two Containers per step (model.py:419-427), so a round is 2 * batch_size calls.
 import os as _os
 
 _lockstep = _os.environ.get("TAP_LOCKSTEP_CONTAINERS", "0") not in ("", "0")
@@ -241,21 +249,49 @@ _open_pool = None
 
 
 def lockstep_containers(on=True):
-    """Pool the Containers built from now on (see above) -> the previous setting."""
+    """Pool the Containers built from now on (see above) -> the previous setting.  Any pool still open is closed:
+    Containers built after this call never join a pool started before it."""
     global _lockstep, _open_pool
     prev, _lockstep, _open_pool = _lockstep, bool(on), None
     return prev
+
+
+class lockstep_scope(object):
+    """``with lockstep_scope():`` -- pooling on for the Containers built inside the block, and the pool CLOSED at its
+    end, so that a later Container with the same arguments (a probe, a warm-up forward, the next forward) can never
+    join it; the previous setting is restored."""
+
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = lockstep_containers(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        lockstep_containers(self.prev)
+        return False
+
+
+_UNFILLED = np.iinfo(np.int64).min    # a row handed out before its round completed holds this, never stale data
+
+
+class LockstepError(RuntimeError):
+    """A lock-step round was completed with members that were never called (see _Pool.flush)."""
 
 
 class _Pool(object):
     def __init__(self, key, args):
         self.key, self.args = key, args
         self.members = 0
+        self.refs = []                  # weak references to the member Containers (a collected one leaves the pool)
         self.env = None                 # built when the first member is used: the pool is sealed then
 
-    def join(self):
+    def join(self, owner):
+        import weakref
         i = self.members
         self.members += 1
+        self.refs.append(weakref.ref(owner))
         return i
 
     def seal(self):
@@ -271,6 +307,10 @@ class _Pool(object):
         self.blocks = np.zeros((B, D), np.float32)
         self.active = np.zeros(B, np.uint8)
         self.called = np.zeros(B, bool)
+        self.ever = np.zeros(B, bool)                            # called in any round so far
+        # members whose Container was already collected when the pool is first used (an abandoned forward) are not
+        # waited for; the others are expected once per round
+        self.live = np.array([r() is not None for r in self.refs], bool)
         self.n_called = 0
         self.out = None                                          # this round's result rows
         self.ratios = None
@@ -284,16 +324,31 @@ class _Pool(object):
         """member i's call of this round: block = None for get_heightmap (report only)"""
         self.seal()
         if self.called[i]:
-            self.flush()                                         # second call within a round: complete it first
+            # a second call within a round: the caller believes the round is over.  Members that were never called
+            # in ANY round are phantoms (a probe or warm-up Container built with the same arguments): the rows handed
+            # out this round were only filled now, after the caller may have stacked them -- say so instead of
+            # letting uninitialised features through, and stop waiting for the phantoms
+            phantom = self.live & ~self.ever & ~self.called
+            self.flush()
+            if phantom.any():
+                self.live &= ~phantom
+                raise LockstepError(
+                    "%d of the %d Containers of this lock-step pool were never called: the round could not complete on "
+                    "its last call and its rows were filled late.  Build the pooled Containers inside "
+                    "`with tools.lockstep_scope():` (or call tools.lockstep_containers(True) right before model.py:294 "
+                    "builds them) so that no other Container with the same arguments joins the pool.  The phantom "
+                    "members have been dropped; the next rounds are complete." % (int(phantom.sum()), self.members))
         if self.out is None:
-            self.out = np.empty((self.members,) + self._fshape, np.int64)
+            self.out = np.full((self.members,) + self._fshape, _UNFILLED, np.int64)
         if block is not None:
             self.blocks[i] = block
             self.active[i] = 1
         self.called[i] = True
+        self.ever[i] = True
+        self.live[i] = True
         self.n_called += 1
         row = self.out[i]
-        if self.n_called == self.members:
+        if self.n_called >= int(self.live.sum()) and bool(self.called[self.live].all()):
             self.flush()
         return row
 
@@ -301,14 +356,18 @@ class _Pool(object):
         if self.env is None or self.n_called == 0:
             return
         env = self.env
-        feat = env.add_new_blocks(torch.from_numpy(self.blocks), active=torch.from_numpy(self.active))
-        self.out[...] = feat.detach().cpu().numpy().reshape(self.out.shape)
-        env.check()
+        out = self.out
+        # the round's bookkeeping is reset BEFORE anything that can raise: an error in one member (TapOverflowError
+        # from check()) must not leave `called` set and replay the same blocks on the next request
+        blocks, active = torch.from_numpy(self.blocks.copy()), torch.from_numpy(self.active.copy())
         self.active[:] = 0
         self.called[:] = False
         self.n_called = 0
         self.out = None
         self.ratios = None
+        feat = env.add_new_blocks(blocks, active=active)
+        out[...] = feat.detach().cpu().numpy().reshape(out.shape)
+        env.check()
 
     def ratio(self, i):
         self.seal()
@@ -337,7 +396,7 @@ class Container(object):
                 _open_pool = _Pool(key, (list(container_size), blocks_num, reward_type, heightmap_type, initial_container_size,
                                          max_height, packing_strategy, device))
             self._pool = _open_pool
-            self._i = self._pool.join()
+            self._i = self._pool.join(self)
             strategy = packing_strategy
             if reward_type in ('C+P+S-mul-soft', 'C+P+S-mul-hard'):          # tools.py:3617-3620
                 strategy = 'MUL'

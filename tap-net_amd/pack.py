@@ -482,7 +482,7 @@ class EpisodeStepper(object):
     the count stays on the device until ``check_binary()`` (or ``check()``) asks for it."""
 
     def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True, steps=None, want_tour=True,
-                 tour=None, tour_col0=0):
+                 tour=None, tour_col0=0, expand_dynamic=True):
         import ctypes as C
         self.block_dim = _block_dim(static, input_type)
         self.R = _rotate_types(self.block_dim, allow_rot)
@@ -502,7 +502,10 @@ class EpisodeStepper(object):
         D = self.block_dim
         words = _bit_planes(self.rows) * self.nR
         self._bits = [torch.empty(self.B, words, dtype=torch.int64, device=dev) for _ in range(2)]
-        self._dyn = [torch.empty(self.B, self.rows, self.nR, **f32) for _ in range(2)]
+        # expand_dynamic=False: update_dynamic's result stays in its bit shadow (``dynamic_bits``) and the fp32 tensor
+        # of model.py:378 is not written -- 78 % of a c2 step's bytes; ``dynamic`` is then None after a step
+        self.expand_dynamic = bool(expand_dynamic)
+        self._dyn = [torch.empty(self.B, self.rows, self.nR, **f32) if expand_dynamic else None for _ in range(2)]
         self._cur = [torch.empty(self.B, self.nR, **f32) for _ in range(2)]
         self._mask = [torch.empty(self.B, self.nR, **f32) for _ in range(2)]
         # the decoder inputs are zeros before step 0 (pack.py:258-264); one flat buffer so that begin() clears both
@@ -527,7 +530,7 @@ class EpisodeStepper(object):
         _steppers.add(self)
         buf = _lib.StepperBuffers()
         for w in range(2):
-            buf.bits[w], buf.dyn[w] = self._bits[w].data_ptr(), self._dyn[w].data_ptr()
+            buf.bits[w], buf.dyn[w] = self._bits[w].data_ptr(), (self._dyn[w].data_ptr() if expand_dynamic else None)
             buf.current[w], buf.mask[w] = self._cur[w].data_ptr(), self._mask[w].data_ptr()
         buf.feature, buf.decoder_static = self.decoder_dynamic.data_ptr(), self.decoder_static.data_ptr()
         buf.ratio = self.ratio.data_ptr()
@@ -545,7 +548,7 @@ class EpisodeStepper(object):
         self._step_fn, self._begin_fn, self._begin_shadow_fn = L.tap_stepper_step, L.tap_stepper_begin, L.tap_stepper_begin_shadow
         self._views = [(self._dyn[w], self._cur[w], self._mask[w]) for w in range(2)]
         self._ones = None
-        self.static = self.dynamic = self.current_mask = self.mask = None
+        self.static = self.dynamic = self.current_mask = self.mask = self.dynamic_bits = None
         self.k = 0
 
     def __del__(self):
@@ -616,6 +619,7 @@ class EpisodeStepper(object):
         w = self.k & 1
         self.k += 1
         self.dynamic, self.current_mask, self.mask = self._views[w]
+        self.dynamic_bits = self._bits[w]
         return w
 
     def _raise_nonbinary(self):

@@ -10,6 +10,7 @@ import torch
 from . import _lib
 from .env import BatchedContainer
 from .pack import EnvTransition, EpisodeStepper, bits_supported
+from .rollout import _flagged_reward
 
 
 class RollingWindows(object):
@@ -273,14 +274,15 @@ class RollingDataset(object):
 
 def run_rolling_episode(blocks, positions, initial_container_size, policy, container_width, container_height,
                         child_graph_size=10, reward_type='C+P+S-lb-soft', heightmap_type='diff',
-                        packing_strategy='LB_GREEDY', record=False, fused=True, steppers=None):
+                        packing_strategy='LB_GREEDY', record=False, fused=True, steppers=None, check='nan'):
     """rolling.validate's loop for a batch (rolling.py:589-637 around DRL.forward(one_step),
     rolling.py:294-460): N - child windows of ONE decoding step each, then a full episode on the
     last window; one long-lived target container per instance.
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
     -> ptr (B,) int64 as in rollout.run_episode.  Returns dict(tour (B, N) of window-local picks,
-    nodes (B, N) global block ids in packing order, reward, env).
+    nodes (B, N) global block ids in packing order, reward, env).  ``check`` as in rollout.run_episode: containers
+    that raised an error bit report NaN ('nan', default, no host sync), raise ('raise'), or keep the raw ratio (False).
 
     ``fused`` runs on a RollingStepper + pack.EpisodeStepper pair: per decoding step the policy's call and one C
     call (decoder_static, the tour and the picked ids are written by the step's own launch).  ``steppers``: the
@@ -289,13 +291,13 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
     rw = RollingWindows(blocks, positions, initial_container_size, child_graph_size)
     if fused and bits_supported(3 * rw.child, rw.child * rw.R):
         return _run_rolling_steppers(rw, policy, container_width, container_height, reward_type, heightmap_type,
-                                     packing_strategy, record, steppers)
+                                     packing_strategy, record, steppers, check)
     return _run_rolling_eager(rw, policy, container_width, container_height, reward_type, heightmap_type,
-                              packing_strategy, record, fused)
+                              packing_strategy, record, fused, check)
 
 
 def _run_rolling_steppers(rw, policy, container_width, container_height, reward_type, heightmap_type, packing_strategy,
-                          record, steppers):
+                          record, steppers, check='nan'):
     B, N, D, child = rw.B, rw.N, rw.D, rw.child
     dev = rw.device
     if steppers is None:
@@ -335,14 +337,14 @@ def _run_rolling_steppers(rw, policy, container_width, container_height, reward_
         step += 1
     tour = roll.tour
     roll.picked[:, N - child:] = torch.gather(nodes_last, 1, (tour[:, N - child:] % child))   # sub_graph_nodes[ptr]
-    out = dict(tour_idx=tour, nodes=roll.picked, reward=-last.ratio, env=env, windows=rw, steppers=(roll, last))
+    out = dict(tour_idx=tour, nodes=roll.picked, reward=_flagged_reward(-last.ratio, check, env), env=env, windows=rw, steppers=(roll, last))
     if record:
         out['features'] = feats
     return out
 
 
 def _run_rolling_eager(rw, policy, container_width, container_height, reward_type, heightmap_type, packing_strategy,
-                       record, fused):
+                       record, fused, check='nan'):
     """The same loop on fresh tensors per step (RollingWindows.step / next, pack.EnvTransition): every window shape,
     also the ones without a bit shadow."""
     from . import pack as tpack
@@ -389,7 +391,7 @@ def _run_rolling_eager(rw, policy, container_width, container_height, reward_typ
         if record:
             feats.append(decoder_dynamic)
         step += 1
-    out = dict(tour_idx=torch.cat(tour, 1), nodes=torch.cat(picked, 1), reward=-ratio, env=env, windows=rw)
+    out = dict(tour_idx=torch.cat(tour, 1), nodes=torch.cat(picked, 1), reward=_flagged_reward(-ratio, check, env), env=env, windows=rw)
     if record:
         out['features'] = feats
     return out

@@ -85,10 +85,31 @@ class UniformKeysPolicy(object):
         return torch.argmax(current_mask * self.v[step], dim=1)
 
 
+def _flagged_reward(reward, check, *envs):
+    """What an episode reports for containers whose sticky error word is set (a placement above the container's
+    height -- the reference's IndexError --, a block the container cannot take, a footprint beyond the big-container
+    kernels' support masks, tapenv.h: tap_env_errors): their placements were skipped, so their score is not the
+    episode's.  check='nan' (default): NaN reward for exactly those containers, no host sync (two small launches,
+    capturable in a hipGraph); 'raise': env.check() -- one host sync, TapOverflowError / TapError like the reference's
+    raise; False / None: the raw calc_ratio (the caller checks, e.g. once per epoch with stepper.check())."""
+    if not check:
+        return reward
+    if check == 'raise':
+        for e in envs:
+            e.check()
+        return reward
+    if check != 'nan':
+        raise ValueError("check must be 'nan', 'raise' or False, not %r" % (check,))
+    err = envs[0].errors
+    for e in envs[1:]:
+        err = err | e.errors
+    return torch.where(err != 0, torch.full_like(reward, float('nan')), reward)
+
+
 def run_episode(static, dynamic, policy, container_width, container_height,
                 reward_type='C+P+S-lb-soft', heightmap_type='diff', packing_strategy='LB_GREEDY',
                 input_type='bot', allow_rot=True, env=None, record=False, steps=None, fused=True, bits=None,
-                container_length=None, stepper=None):
+                container_length=None, stepper=None, check='nan'):
     """One episode for a batch (model.py:254-515 minus the network).
 
     ``policy(step=, static=, dynamic=, current_mask=, mask=, decoder_static=, decoder_dynamic=)``
@@ -102,11 +123,12 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     policy the host makes ONE C call and issues no torch op (the step's launch also writes ``decoder_static`` and
     the tour column).  ``stepper``: a stepper to re-use across episodes (a trainer builds one per run: nothing is
     allocated per episode; the returned tensors are then views of its buffers, valid until its next ``begin``);
-    None builds one for this call.
+    None builds one for this call.  ``check``: what ``reward`` holds for containers that raised an error bit
+    (_flagged_reward: 'nan' -- NaN, no host sync --, 'raise', or False for the raw ratio).
     """
     if input_type in ('mul', 'mul-with'):
         return _run_episode_mul(static, dynamic, policy, container_width, container_height, reward_type,
-                                heightmap_type, packing_strategy, input_type, allow_rot, record, steps)
+                                heightmap_type, packing_strategy, input_type, allow_rot, record, steps, check)
     block_dim = int(static.shape[1]) - 1
     n = int(dynamic.shape[-1]) // (math.factorial(block_dim) if allow_rot else 1)
     B, D = int(static.shape[0]), block_dim
@@ -117,7 +139,7 @@ def run_episode(static, dynamic, policy, container_width, container_height,
         try:
             return _run_episode_stepper(static, dynamic, policy, container_width, container_height, reward_type,
                                         heightmap_type, packing_strategy, input_type, allow_rot, env, record, nsteps,
-                                        container_length, stepper, dev, n, D)
+                                        container_length, stepper, dev, n, D, check)
         except NonBinaryDynamic:
             if bits is True or stepper is not None:
                 raise ValueError("dynamic cannot be carried as a bit shadow (it holds values other than 0 and 1)")
@@ -155,7 +177,7 @@ def run_episode(static, dynamic, policy, container_width, container_height,
             feats.append(decoder_dynamic); curs.append(masks.current_mask); msks.append(masks.mask)
     if ratio is None:
         ratio = env.calc_ratios()                                 # model.py:499-510
-    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -ratio, 'env': env,
+    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': _flagged_reward(-ratio, check, env), 'env': env,
            'dynamic': masks.dynamic, 'mask': masks.mask}
     if record:
         out.update(features=feats, current_masks=curs, masks=msks)
@@ -169,7 +191,8 @@ def _as_instances(t, dev):
 
 
 def _run_episode_stepper(static, dynamic, policy, container_width, container_height, reward_type, heightmap_type,
-                         packing_strategy, input_type, allow_rot, env, record, nsteps, container_length, stepper, dev, n, D):
+                         packing_strategy, input_type, allow_rot, env, record, nsteps, container_length, stepper, dev, n, D,
+                         check='nan'):
     """run_episode's loop on a pack.EpisodeStepper: per decoding step the policy's call and one C call."""
     static, dynamic = _as_instances(static, dev), _as_instances(dynamic, dev)
     if stepper is None:
@@ -190,15 +213,15 @@ def _run_episode_stepper(static, dynamic, policy, container_width, container_hei
         sp.step(ptr)                                              # model.py:376-465, one launch
         if record:
             feats.append(sp.decoder_dynamic.clone()); curs.append(sp.current_mask.clone()); msks.append(sp.mask.clone())
-    out = {'tour_idx': sp.tour, 'reward': -sp.ratio, 'env': sp.env, 'dynamic': sp.dynamic, 'mask': sp.mask,
-           'stepper': sp}
+    out = {'tour_idx': sp.tour, 'reward': _flagged_reward(-sp.ratio, check, sp.env), 'env': sp.env, 'dynamic': sp.dynamic,
+           'mask': sp.mask, 'stepper': sp}
     if record:
         out.update(features=feats, current_masks=curs, masks=msks)
     return out
 
 
 def _run_episode_mul(static, dynamic, policy, container_width, container_height, reward_type,
-                     heightmap_type, packing_strategy, input_type, allow_rot, record, steps):
+                     heightmap_type, packing_strategy, input_type, allow_rot, record, steps, check='nan'):
     """The two-container variant (input types 'mul' / 'mul-with', model.py:290-292, 396-447,
     503-507): the last row of ``static`` holds each block's target container id; per step the chosen
     block is placed in container a (id 0) or b (id 1) and the other one only reports its height-map
@@ -232,7 +255,7 @@ def _run_episode_mul(static, dynamic, policy, container_width, container_height,
         if record:
             feats.append(decoder_dynamic); curs.append(masks.current_mask); msks.append(masks.mask)
     ratio = (env_a.calc_ratios() + env_b.calc_ratios()) / 2.0                                  # model.py:503-507
-    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': -ratio, 'env': env_a, 'env_b': env_b,
+    out = {'tour_idx': torch.cat(tour, dim=1), 'reward': _flagged_reward(-ratio, check, env_a, env_b), 'env': env_a, 'env_b': env_b,
            'dynamic': masks.dynamic, 'mask': masks.mask}
     if record:
         out.update(features=feats, current_masks=curs, masks=msks)

@@ -4,7 +4,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .env import BatchedContainer, Container, lockstep_containers   # noqa: F401
+from .env import BatchedContainer, Container, LockstepError, lockstep_containers, lockstep_scope   # noqa: F401
 from .pack import reward as _reward            # noqa: F401
 
 
