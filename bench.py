@@ -79,6 +79,15 @@ CONFIGS = {
            3, [5, 5, 250], 50, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
     "c6": ("3D RAND nodes=10 container_width=5x5 MACS batch=4096 on 1xMI355X (not a BASELINE config: SURVEY 8(f) f3)",
            3, [5, 5, 50], 10, 4096, "C+P+S-mcs-soft", "MACS"),
+    "c7": ("3D RAND nodes=10 container_width=10x10 LB_GREEDY batch=4096 on 1xMI355X (not a BASELINE config: the "
+           "wave-per-container kernels, model.py:279 builds W x W for any --container_width)",
+           3, [10, 10, 50], 10, 4096, "C+P+S-lb-soft", "LB_GREEDY"),
+    "c8": ("3D RAND nodes=10 container_width=10x10 MACS batch=4096 on 1xMI355X (not a BASELINE config: the "
+           "wave-per-container MACS 3D kernel, two launches per step)",
+           3, [10, 10, 50], 10, 4096, "C+P+S-mcs-soft", "MACS"),
+    "c9": ("2D RAND nodes=10 container_width=100 MACS batch=4096 on 1xMI355X (not a BASELINE config: the "
+           "wave-per-container MACS 2D kernel, two launches per step)",
+           2, [100, 50], 10, 4096, "C+P+S-mcs-soft", "MACS"),
     "k6": ("2D RAND nodes=10 container_width=5 LB_GREEDY batch=8192: whole episode per launch "
            "(pack.reward / calc_positions_lb_greedy, SURVEY K6; not a BASELINE config)",
            2, [5, 50], 10, 8192, "C+P+S-lb-soft", "LB_GREEDY"),
@@ -1392,7 +1401,7 @@ def build_hotpath(config, args, rank, dev, batch=None):
         hp = EpisodeHotPath(cfg, B, rank * B, dev)
     else:
         instances = None
-        if config in ("c2", "c3") and not args.synthetic_precedence:
+        if config in ("c2", "c3", "c7", "c8", "c9") and not args.synthetic_precedence:
             instances = "generate"
         if config == "c4" and args.ppsg_device:
             instances = "ppsg2d"                                    # device-side perfect-packing generator (~30 s of set-up)

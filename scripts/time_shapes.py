@@ -66,7 +66,7 @@ def rolling_case(name, B, N, child, D, init):
         g.manual_seed(1)
         blocks = torch.randint(1, 5, (B, N, D), device=DEV, generator=g, dtype=torch.int32)
         positions, _, _ = generate.pack_blocks(blocks, init, 'C+P+S-lb-soft')
-    H = 4 * N + 10
+    H = min(4 * N + 10, 4000)
     gen = torch.Generator(device=DEV)
 
     def policy(step, static, dynamic, current_mask, **_):
@@ -90,8 +90,14 @@ def rolling_case(name, B, N, child, D, init):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
+    ap.add_argument("--only", default=None, help="substring of the case names to run")
     a = ap.parse_args()
     rows = []
+    global episode_case, rolling_case
+    if a.only:                                            # skip the other cases without touching the list below
+        ep0, ro0 = episode_case, rolling_case
+        episode_case = lambda name, *x, **k: ep0(name, *x, **k) if a.only in name else []     # noqa: E731
+        rolling_case = lambda name, *x, **k: ro0(name, *x, **k) if a.only in name else []     # noqa: E731
     bits_vs_copy = [("fused step, bit shadow", dict(fused=True)), ("fused step, fp32 copy", dict(fused=True, bits=False)),
                     ("two launches, bit shadow", dict(fused=False)), ("two launches, fp32 copy", dict(fused=False, bits=False))]
     rows += episode_case("2D n=30 W=5 LB_GREEDY (90 rows: two-word shadow)", 8192, 30, 2, [5, 150], "C+P+S-lb-soft", "LB_GREEDY", bits_vs_copy)
@@ -102,7 +108,10 @@ def main():
     rows += rolling_case("3D rolling N=50 child=10 (one-word graphs, for scale)", 4096, 50, 10, 3, [7, 7, 250])
     rows += rolling_case("3D rolling N=100 child=10 (two-word graphs, one wavefront per instance)", 4096, 100, 10, 3, [7, 7, 500])
     rows += rolling_case("3D rolling N=128 child=10", 4096, 128, 10, 3, [7, 7, 600])
-    rows += rolling_case("3D rolling N=130 child=10 (one thread per instance)", 4096, 130, 10, 3, [7, 7, 600])
+    rows += rolling_case("3D rolling N=130 child=10 (three-word graphs, one wavefront per instance; round 4: one thread)", 4096, 130, 10, 3, [7, 7, 600])
+    rows += rolling_case("3D rolling N=200 child=10 (four-word graphs, one wavefront per instance)", 4096, 200, 10, 3, [7, 7, 900])
+    rows += rolling_case("3D rolling N=256 child=10 (four-word graphs)", 4096, 256, 10, 3, [7, 7, 1100])
+    rows += rolling_case("3D rolling N=300 child=10 (one thread per instance, 16-word masks)", 1024, 300, 10, 3, [7, 7, 1300])
     # round 4: the one-thread-per-container paths (correctness paths for unusual --container_width values), next to the
     # lane-per-cell kernels at the nearest shapes they cover
     one = bits_vs_copy[:1]

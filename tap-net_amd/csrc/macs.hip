@@ -161,6 +161,9 @@ int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d)
     return TAP_OK;
 }
 
+// from which width MACS 2D runs one wavefront per container (TAP_MACS2D_WAVE_FROM=W moves the hand-over for A/B runs)
+int tap_macs2d_wave_from() { static const int from = [] { const char *e = getenv("TAP_MACS2D_WAVE_FROM"); return e ? atoi(e) : 17; }(); return from; }
+
 int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     int rc = tap_macs_validate(ctx, a.d);
@@ -179,8 +182,11 @@ int tap_macs2d_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
         // tap_macs_wide.h, which stay as its fallback when a tile does not fit the LDS (eager steps, n = 10: at B = 4096
         // W = 17 35 against 48 us, W = 32 35 against 120; at B = 65 536 W = 17 282 against 304, W = 32 281 against 1 696;
         // W = 16 35.5 against 33.4 on the lane kernel); TAP_MACS2D_WAVE_FROM=W moves the hand-over for A/B runs
-        static const int from = [] { const char *e = getenv("TAP_MACS2D_WAVE_FROM"); return e ? atoi(e) : 17; }();
-        if (a.d.W >= from && tap_macs_wave_step(ctx, a, st) == TAP_OK) return TAP_OK;
+        const int from = tap_macs2d_wave_from();
+        if (a.d.W >= from) {
+            const int rc_w = tap_macs_wave_step(ctx, a, st);
+            if (rc_w != TAP_E_UNSUPPORTED) return rc_w;                  // launched, or a real error; only "the tile does not fit" falls back
+        }
     }
     if (a.d.W > 32) return launch_macs_wide<64>(ctx, a, st);
     if (a.d.W > 16) return launch_macs_wide<32>(ctx, a, st);

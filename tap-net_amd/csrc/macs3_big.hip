@@ -8,6 +8,8 @@
 #include "tap_place.h"
 #include "tap_macs3_big.h"
 #include "tap_macs3_wave.h"
+#include "tap_masks.h"
+#include "tap_transition.h"
 
 static_assert(M3B_F_HARD == TAP_F_HARD && M3B_F_USE_P == TAP_F_USE_P && M3B_F_USE_S == TAP_F_USE_S &&
               M3B_F_ZERO == TAP_F_MCS_ZERO && M3B_F_TIE == TAP_F_MCS_TIE, "flag bits are passed through");
@@ -50,7 +52,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32
     // sides larger than the container are rejected as invalid input, as in tap_macs3.h (the reference keeps such a
     // block in its history at (0,0,0) and its later slices run out of range, tools.py:2858, 2914); footprints above
     // 8 x 8 are beyond the support mask of the stability test
-    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > L || bx > 8 || by > 8)) { err |= 4; do_step = false; }
+    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > L || bx > TAP_WIDE_MAX_SIDE || by > TAP_WIDE_MAX_SIDE)) { err |= 4; do_step = false; }
     if (do_step) {
         const int step = cnt[3], cap = macs3_big_cap(a.d.n_max);
         int32_t *sc = scratch + (size_t)env * scratch_ints;
@@ -81,17 +83,13 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_big_step(StepArgs a, int32
 }
 
 // ---- one WAVEFRONT per container (tap_macs3_wave.h): the container's working set in the wave's LDS tile ---------------
-__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
+// one MACS 3D step of container `env` by one wavefront (every lane calls; env < B); base = the wave's LDS tile
+__device__ __forceinline__ void macs3d_wave_body(const StepArgs &a, int env, int lane, m3b_u64 *base)
 {
-    extern __shared__ unsigned long long m3w_lds[];
-    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
-    const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int B = a.d.B, W = a.d.W, L = a.d.L, H = a.d.H, cells = W * L, HW = (H + 63) / 64;
-    if (env >= B) return;                                                         // wave-uniform
     const int cap = macs3_big_cap(a.d.n_max);
     M3WTile s;
     s.W = W; s.L = L; s.H = H; s.HW = HW; s.flags = a.d.flags; s.cap = cap; s.n_max = a.d.n_max;
-    m3b_u64 *base = m3w_lds + (size_t)wave_in_wg * m3w_tile_u64(cells, HW, a.d.n_max, cap);
     s.occ = base;
     s.rows = s.occ + (size_t)cells * HW;
     s.ems = reinterpret_cast<M3BEms *>(s.rows + 64);
@@ -127,7 +125,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
     int err = 0;
     bool do_step = act;
     if (act && cnt[3] >= a.d.n_max) { err |= 2; do_step = false; }                   // tools.py:3677 IndexError
-    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > L || bx > 8 || by > 8)) { err |= 4; do_step = false; }   // as k_macs3d_big_step
+    if (act && (bx < 1 || by < 1 || bz < 1 || bx > W || by > L || bx > TAP_WIDE_MAX_SIDE || by > TAP_WIDE_MAX_SIDE)) { err |= 4; do_step = false; }   // as k_macs3d_big_step
     tap_wave_lds_sync();
     if (do_step) {                                                               // wave-uniform
         const int step = cnt[3];
@@ -171,6 +169,72 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
             for (int c = lane; c < cells; c += 64) o[c] = (float)(s.hm[c] - mn);
         }
     }
+}
+
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_step(StepArgs a)
+{
+    extern __shared__ unsigned long long m3w_lds[];
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (env >= a.d.B) return;                                                     // wave-uniform
+    const int cells = a.d.W * a.d.L, HW = (a.d.H + 63) / 64;
+    macs3d_wave_body(a, env, lane, m3w_lds + (size_t)wave_in_wg * m3w_tile_u64(cells, HW, a.d.n_max, macs3_big_cap(a.d.n_max)));
+}
+
+// The decoding step in ONE launch (round 5): a container's wavefront runs update_dynamic + update_mask of its own
+// precedence slab on the bit shadow (tap_transition.h), then its placement.
+template <int NC, int MODE>
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_transition(TransArgs a, int PW, int tile_u64)
+{
+    extern __shared__ unsigned long long m3w_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int env = blockIdx.x * PW + wave;
+    if (env >= a.s.d.B) return;                                                   // wave-uniform
+    // The wave first runs its container's precedence update (one slab: inputs in one round trip, write-through stores
+    // that drain while the placement runs), then the placement.  Stream waves of their own, as in k_transition, would
+    // occupy wave slots at this kernel's register count: with 4 + 2 waves per workgroup a CU held 8 placement waves
+    // instead of 16 and the step took 218 against 148 us (MACS 3D 10 x 10, B = 4 096, round 5).
+    trans_stream_wave<1, NC, MODE>(a.m, env, lane, reinterpret_cast<float *>(m3w_lds + (size_t)PW * tile_u64) + (size_t)wave * 3 * a.m.nR);
+    if (lane == 0 && a.s.static_ && (a.s.dec_static_out || a.s.tour_out || a.s.picked_out)) {   // the gather's by-products
+        bool badp;
+        const long praw = (long)a.s.ptr[env];
+        const long p = tap_col(praw, a.s.nR, badp);
+        float fv[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < a.s.d.D; ++k) fv[k] = badp ? 0.f : a.s.static_[((size_t)env * a.s.static_rows + 1 + k) * a.s.nR + p];
+        tap_step_aux(a.s, env, a.s.d.D, fv, praw);
+    }
+    macs3d_wave_body(a.s, env, lane, m3w_lds + (size_t)wave * tile_u64);
+}
+
+static int macs3d_transition_pw(const tap_ctx *ctx, const tap_env_desc *d, int nR)
+{
+    if (tap_wave_kernels_off()) return 0;
+    const size_t tile = m3w_tile_u64(d->W * d->L, (d->H + 63) / 64, d->n_max, macs3_big_cap(d->n_max)) * 8;
+    for (int pw = 4; pw >= 1; pw >>= 1)
+        if ((size_t)pw * tile + (size_t)pw * 3 * nR * sizeof(float) <= tap_lds_limit(ctx)) return pw;
+    return 0;
+}
+
+bool tap_macs3_wave_transition_ok(const tap_ctx *ctx, const tap_env_desc *d, int nR) { return macs3d_transition_pw(ctx, d, nR) > 0; }
+
+int tap_macs3_wave_transition(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st)
+{
+    const int pw = macs3d_transition_pw(ctx, d, a.m.nR);
+    if (pw == 0) return tap_fail(ctx, TAP_E_UNSUPPORTED, "no fused step for this container");
+    if (!a.s.v.scratch || !a.s.v.occ) return tap_fail(ctx, TAP_E_INVALID, "MACS 3D above 64 cells: the state blob has no scratch section");
+    const int tile_u64 = (int)m3w_tile_u64(d->W * d->L, (d->H + 63) / 64, d->n_max, macs3_big_cap(d->n_max));
+    const int mode = a.m.bits_in ? 1 : 2;
+    const size_t lds = (size_t)pw * tile_u64 * 8 + (size_t)pw * 3 * a.m.nR * sizeof(float);
+    const dim3 g((d->B + pw - 1) / pw), blk(64 * pw);
+    if (g.x == 0) return TAP_OK;
+#define TAP_MT(NC_, M_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_wave_transition<NC_, M_>, lds)); \
+        hipLaunchKernelGGL((k_macs3d_wave_transition<NC_, M_>), g, blk, lds, st, a, pw, tile_u64); } while (0)
+#define TAP_MT_M(NC_) do { if (mode == 1) TAP_MT(NC_, 1); else TAP_MT(NC_, 2); } while (0)
+    switch (mask_fast_path_cols(a.m)) { case 1: TAP_MT_M(1); break; case 2: TAP_MT_M(2); break; default: TAP_MT_M(4); break; }
+#undef TAP_MT_M
+#undef TAP_MT
+    TAP_LAUNCH_CHECK(ctx, "k_macs3d_wave_transition");
+    return TAP_OK;
 }
 
 int tap_macs3_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)

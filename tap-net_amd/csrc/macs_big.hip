@@ -9,6 +9,8 @@
 // blob's (W <= 4096).  gfx950 only.
 #include "tap_common.h"
 #include "tap_place.h"
+#include "tap_masks.h"
+#include "tap_transition.h"
 
 // EMS entries one step can produce: the runs of level 0 (at most (W+1)/2), one run per level z > 0 for which some
 // column of the run has hm == z (a run without such a column is the same run as on the level below and is skipped,
@@ -280,14 +282,11 @@ __device__ __forceinline__ long mw_sum(long v)
     return v;
 }
 
-__global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int cap)
+// one MACS 2D step of container `env` by one wavefront (every lane calls; env < B); tile = the wave's LDS tile
+__device__ __forceinline__ void macs2d_wave_body(const StepArgs &a, int cap, int env, int lane, int32_t *tile)
 {
-    extern __shared__ int32_t mw_lds[];
-    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
-    const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int B = a.d.B, W = a.d.W, H = a.d.H;
-    if (env >= B) return;                                                         // wave-uniform
-    int32_t *hm = mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(W, cap, a.d.n_max);
+    int32_t *hm = tile;
     int32_t *lev = hm + W, *psum = lev + W, *slots = psum + W;
     int32_t *tl = slots + W, *tr = tl + W + 1;                                  // the tie-break's per-level tables
     int2 *ems = reinterpret_cast<int2 *>(tr + W + 1);
@@ -603,6 +602,72 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int 
     }
 }
 
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int cap)
+{
+    extern __shared__ int32_t mw_lds[];
+    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (env >= a.d.B) return;                                                     // wave-uniform
+    macs2d_wave_body(a, cap, env, lane, mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(a.d.W, cap, a.d.n_max));
+}
+
+// The decoding step in ONE launch (round 5): a container's wavefront runs update_dynamic + update_mask of its own
+// precedence slab on the bit shadow (tap_transition.h) and then its placement -- round 4 ran a mask launch and a
+// placement launch.  MODE 1: on the shadow, 2: the episode's first step.
+template <int NC, int MODE>
+__global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_transition(TransArgs a, int cap, int PW, int tile_ints)
+{
+    extern __shared__ int32_t mw_lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int env = blockIdx.x * PW + wave;
+    if (env >= a.s.d.B) return;                                                   // wave-uniform
+    // The wave first runs its container's precedence update (one slab: inputs in one round trip, write-through stores
+    // that drain while the placement runs), then the placement.  Stream waves of their own, as in k_transition, would
+    // occupy wave slots at this kernel's register count: with 4 + 2 waves per workgroup a CU held 8 placement waves
+    // instead of 16 and the step took 218 against 148 us (MACS 3D 10 x 10, B = 4 096, round 5).
+    trans_stream_wave<1, NC, MODE>(a.m, env, lane, reinterpret_cast<float *>(mw_lds + (size_t)PW * tile_ints) + (size_t)wave * 3 * a.m.nR);
+    if (lane == 0 && a.s.static_ && (a.s.dec_static_out || a.s.tour_out || a.s.picked_out)) {   // the gather's by-products
+        bool badp;
+        const long praw = (long)a.s.ptr[env];
+        const long p = tap_col(praw, a.s.nR, badp);
+        float fv[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < a.s.d.D; ++k) fv[k] = badp ? 0.f : a.s.static_[((size_t)env * a.s.static_rows + 1 + k) * a.s.nR + p];
+        tap_step_aux(a.s, env, a.s.d.D, fv, praw);
+    }
+    macs2d_wave_body(a.s, cap, env, lane, mw_lds + (size_t)wave * tile_ints);
+}
+
+static int macs2d_transition_pw(const tap_ctx *ctx, const tap_env_desc *d, int nR)
+{
+    if (tap_wave_kernels_off()) return 0;
+    const size_t tile = macs_wave_tile_ints(d->W, macs_big_cap(d->W, d->n_max), d->n_max) * sizeof(int32_t);
+    for (int pw = 4; pw >= 1; pw >>= 1)
+        if ((size_t)pw * tile + (size_t)pw * 3 * nR * sizeof(float) <= tap_lds_limit(ctx)) return pw;
+    return 0;
+}
+
+bool tap_macs_wave_transition_ok(const tap_ctx *ctx, const tap_env_desc *d, int nR) { return macs2d_transition_pw(ctx, d, nR) > 0; }
+
+// mask update + placement of a MACS 2D container above 16 columns in one launch (the caller resets / emits calc_ratio)
+int tap_macs_wave_transition(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st)
+{
+    const int pw = macs2d_transition_pw(ctx, d, a.m.nR);
+    if (pw == 0) return tap_fail(ctx, TAP_E_UNSUPPORTED, "no fused step for this container");
+    const int cap = macs_big_cap(d->W, d->n_max), tile_ints = (int)macs_wave_tile_ints(d->W, cap, d->n_max);
+    const int mode = a.m.bits_in ? 1 : 2;
+    const size_t lds = (size_t)pw * tile_ints * sizeof(int32_t) + (size_t)pw * 3 * a.m.nR * sizeof(float);
+    const dim3 g((d->B + pw - 1) / pw), blk(64 * pw);
+    if (g.x == 0) return TAP_OK;
+#define TAP_MT(NC_, M_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs2d_wave_transition<NC_, M_>, lds)); \
+        hipLaunchKernelGGL((k_macs2d_wave_transition<NC_, M_>), g, blk, lds, st, a, cap, pw, tile_ints); } while (0)
+#define TAP_MT_M(NC_) do { if (mode == 1) TAP_MT(NC_, 1); else TAP_MT(NC_, 2); } while (0)
+    switch (mask_fast_path_cols(a.m)) { case 1: TAP_MT_M(1); break; case 2: TAP_MT_M(2); break; default: TAP_MT_M(4); break; }
+#undef TAP_MT_M
+#undef TAP_MT
+    TAP_LAUNCH_CHECK(ctx, "k_macs2d_wave_transition");
+    return TAP_OK;
+}
+
 // -> TAP_OK when launched, TAP_E_UNSUPPORTED (no message) when a container's tile does not fit a wave's share of the LDS
 int tap_macs_wave_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
@@ -621,7 +686,8 @@ int tap_macs_wave_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 int tap_macs_big_step(tap_ctx *ctx, const StepArgs &a, hipStream_t st)
 {
     if (a.d.B == 0) return TAP_OK;
-    if (tap_macs_wave_step(ctx, a, st) == TAP_OK) return TAP_OK;
+    const int rc_w = tap_macs_wave_step(ctx, a, st);
+    if (rc_w != TAP_E_UNSUPPORTED) return rc_w;                                  // launched, or a real error: only "does not fit" falls through
     if (!a.v.scratch) return tap_fail(ctx, TAP_E_INVALID, "MACS above 64 columns: the state blob has no scratch section");           // one wavefront per container when its tile fits the LDS
     const int lpw = tap_spread_lpw(a.d.B);
     hipLaunchKernelGGL(k_macs2d_big_step, dim3(tap_spread_grid(a.d.B, lpw, TAP_BLOCK)), dim3(TAP_BLOCK), 0, st, a, a.v.scratch,

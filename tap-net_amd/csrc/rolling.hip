@@ -155,8 +155,10 @@ __device__ inline int pyset_probe(const int *table, int mask, int key)
 
 constexpr int PYSET_CAP = 256;
 
-// keys[0..n) in list order -> order[0..n) in set iteration order; tbl/tmp: PYSET_CAP ints each
-__device__ inline void pyset_order(const unsigned char *keys, int n, unsigned char *order, int *tbl, int *tmp)
+// keys[0..n) in list order -> order[0..n) in set iteration order; tbl/tmp: PYSET_CAP ints each (n <= 64 keys: the table
+// never grows beyond 256 slots whatever the keys' values)
+template <class K>
+__device__ inline void pyset_order(const K *keys, int n, K *order, int *tbl, int *tmp)
 {
     int size = 8, fill = 0;
     for (int i = 0; i < size; ++i) tbl[i] = -1;
@@ -175,7 +177,7 @@ __device__ inline void pyset_order(const unsigned char *keys, int n, unsigned ch
         }
     }
     int m = 0;
-    for (int i = 0; i < size; ++i) if (tbl[i] >= 0) order[m++] = (unsigned char)tbl[i];
+    for (int i = 0; i < size; ++i) if (tbl[i] >= 0) order[m++] = (K)tbl[i];
 }
 
 // The same for tables of at most 64 slots (n <= 18 keys: 8 -> 32 slots), held across the wave: lane l
@@ -644,87 +646,138 @@ __device__ __forceinline__ void rolling_emit_fast(const RollArgs &a, int inst, i
 }
 
 
-// ---- 65 .. 128 blocks per instance: still ONE wavefront per instance, lane v = nodes v and v + 64 -------------
-// Every graph is two 64-bit words per node (the layout k_rolling_init_big writes: NW = 2 words per mask, the N
-// movement masks first, then per node its four side masks), the state is (entered, window) of two words each, held
-// wave-uniform.  The steps are the ones above: layers are two ballots, a node's rank counts both words.  The
-// emission turns every window node's masks into words over the sub-graph ROWS first (bit rm = node ord[rm]), after
-// which nothing depends on N any more.  Windows of at most 32 nodes (side[k][2*slot + word] fills the relation
-// slots exactly); the tensor goes out packed (rolling_emit_wave's float4 expansion) when it has the bit-shadow
-// shape, element by element otherwise.
-constexpr int ROLL_CH_WIDE = -2;      // template tag: this form instead of the one-word graph step
+// ---- 65 .. 256 blocks per instance: still ONE wavefront per instance, lane v = nodes v, v + 64, v + 128, v + 192 ----
+// Every graph is NW = ceil(N / 64) 64-bit words per node (the layout k_rolling_init_big writes: the N movement masks
+// first, then per node its four side masks), the state is (entered, window) of NW words each, held wave-uniform.  The
+// steps are the ones above: a layer is NW ballots, a node's rank counts the words below its own.  The emission turns
+// every window node's masks into words over the sub-graph ROWS first (bit rm = node ord[rm]), after which nothing
+// depends on N any more.  Windows of at most 64 / NW nodes (side[k][NW * slot + word] fills the relation slots
+// exactly: 32 nodes up to 128 blocks, 21 up to 192, 16 up to 256); the tensor goes out packed (rolling_emit_wave's
+// float4 expansion) when it has the bit-shadow shape, element by element otherwise.  (Round 4 had this form for two
+// words only; 129 .. 256 blocks ran one THREAD per instance: 853 against 80 us per step at N = 130 / 128.)
+constexpr int ROLL_CH_WIDE = -2;      // template tags: this form with NW = -CH words instead of the one-word graph step
 // window sizes with a compile-time-shaped kernel (0 = any window, shapes read from the arguments)
 __host__ __device__ constexpr bool roll_fast_ok(int D, int child) { return child == 10 && (D == 2 || D == 3); }
 
-template <int D>
-__device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, RollLds &S)
+template <int D, int NW>
+__device__ inline void rolling_window_waveN(const RollArgs &a, int inst, int v, RollLds &S)
 {
+    static_assert(NW >= 2 && NW <= 4, "two to four words per node mask");
     if (inst >= a.B) return;
     const int N = a.N, child = a.child;
-    constexpr int R = D == 2 ? 2 : 6, NW = 2;
+    constexpr int R = D == 2 ? 2 : 6;
     const int nRc = child * R;
-    const u64 all_lo = ~0ull, all_hi = N >= 128 ? ~0ull : ((1ull << (N - 64)) - 1ull);
     const u64 bit = 1ull << v, below = bit - 1ull;
-    const bool has_hi = v + 64 < N;                                   // this lane's second node exists
+    u64 all[NW];
+    bool has[NW];                                                     // this lane's h-th node exists
+#pragma unroll
+    for (int h = 0; h < NW; ++h) {
+        all[h] = N >= 64 * (h + 1) ? ~0ull : (N > 64 * h ? ((1ull << (N - 64 * h)) - 1ull) : 0ull);
+        has[h] = v + 64 * h < N;
+    }
     auto uniform64 = [](u64 x) -> u64 {
         return ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)x);
     };
     const u64 *relb = a.rel + (size_t)inst * 5 * N * NW;
-    const ulonglong2 *mv = reinterpret_cast<const ulonglong2 *>(relb);
-    const ulonglong2 m_lo = mv[v], m_hi = has_hi ? mv[v + 64] : make_ulonglong2(0ull, 0ull);
+    u64 m[NW][NW];                                                    // m[h] = movement mask of node v + 64 h
+#pragma unroll
+    for (int h = 0; h < NW; ++h) {
+        const u64 *q = relb + (size_t)(has[h] ? v + 64 * h : 0) * NW;
+        if constexpr (NW % 2 == 0) {
+#pragma unroll
+            for (int k = 0; k < NW; k += 2) {
+                const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(q + k);
+                m[h][k] = has[h] ? t.x : 0ull; m[h][k + 1] = has[h] ? t.y : 0ull;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) { const u64 t = q[k]; m[h][k] = has[h] ? t : 0ull; }
+        }
+    }
     u64 *stp = a.state + (size_t)inst * 2 * NW;
-    const u64 s0 = stp[0], s1 = stp[1], s2 = stp[2], s3 = stp[3];
+    u64 sraw[2 * NW];
+#pragma unroll
+    for (int k = 0; k < 2 * NW; ++k) sraw[k] = stp[k];
     const long ptr_raw = a.remove_ptr ? (long)a.remove_ptr[inst] : 0;
-    u64 e_lo = uniform64(s0), e_hi = uniform64(s1), w_lo = uniform64(s2), w_hi = uniform64(s3);
+    u64 e[NW], w[NW];
+#pragma unroll
+    for (int k = 0; k < NW; ++k) { e[k] = uniform64(sraw[k]); w[k] = uniform64(sraw[NW + k]); }
 
     // (1) remove_block(sub_graph_nodes[ptr mod child])  rolling.py:632-637, generate.py:1824-1835
     if (a.remove_ptr) {
         const long slot = tap_mod_col((long)uniform64((u64)ptr_raw), child, nRc);
-        const int nlo = __popcll(w_lo);
-        const bool hit_lo = (w_lo & bit) && __popcll(w_lo & below) == slot;
-        const bool hit_hi = (w_hi & bit) && nlo + __popcll(w_hi & below) == slot;
-        w_lo &= ~__ballot(hit_lo);
-        w_hi &= ~__ballot(hit_hi);
+        int base = 0;
+        u64 hitm[NW];
+#pragma unroll
+        for (int h = 0; h < NW; ++h) {
+            const bool hit = (w[h] & bit) && base + __popcll(w[h] & below) == slot;
+            hitm[h] = __ballot(hit);
+            base += __popcll(w[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < NW; ++h) w[h] &= ~hitm[h];
     }
     // (2) top the window up (generate.py:1724-1750)
-    int count = __popcll(w_lo) + __popcll(w_hi);
-    if (w_lo & bit) S.lst[__popcll(w_lo & below)] = (unsigned char)v;
-    if (w_hi & bit) S.lst[__popcll(w_lo) + __popcll(w_hi & below)] = (unsigned char)(v + 64);
-    u64 a_lo = 0, a_hi = 0;
-    while (count < child) {
-        const u64 g_lo = all_lo & ~(e_lo | a_lo), g_hi = all_hi & ~(e_hi | a_hi);     // nodes still in gm_copy
-        const bool single = __popcll(g_lo) + __popcll(g_hi) == 1;
-        const bool f_lo = (g_lo & bit) && (single || ((m_lo.x & g_lo) | (m_lo.y & g_hi)) == 0);
-        const bool f_hi = has_hi && (g_hi & bit) && (single || ((m_hi.x & g_lo) | (m_hi.y & g_hi)) == 0);
-        const u64 fm_lo = __ballot(f_lo), fm_hi = __ballot(f_hi);
-        if ((fm_lo | fm_hi) == 0) break;
-        const int need = child - count;
-        const int r_lo = __popcll(fm_lo & below), r_hi = __popcll(fm_lo) + __popcll(fm_hi & below);
-        const bool t_lo = f_lo && r_lo < need, t_hi = f_hi && r_hi < need;
-        if (t_lo) S.lst[count + r_lo] = (unsigned char)v;
-        if (t_hi) S.lst[count + r_hi] = (unsigned char)(v + 64);
-        const u64 tm_lo = __ballot(t_lo), tm_hi = __ballot(t_hi);
-        a_lo |= tm_lo; a_hi |= tm_hi;
-        count += __popcll(tm_lo) + __popcll(tm_hi);
+    int count = 0;
+#pragma unroll
+    for (int h = 0; h < NW; ++h) {
+        if (w[h] & bit) S.lst[count + __popcll(w[h] & below)] = (unsigned char)(v + 64 * h);
+        count += __popcll(w[h]);
     }
-    e_lo |= a_lo; e_hi |= a_hi;
-    w_lo |= a_lo; w_hi |= a_hi;
+    u64 ad[NW];
+#pragma unroll
+    for (int h = 0; h < NW; ++h) ad[h] = 0ull;
+    while (count < child) {
+        u64 g[NW];                                                    // nodes still in gm_copy
+        int left = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { g[k] = all[k] & ~(e[k] | ad[k]); left += __popcll(g[k]); }
+        const bool single = left == 1;
+        bool f[NW];
+        u64 fm[NW], any = 0ull;
+#pragma unroll
+        for (int h = 0; h < NW; ++h) {
+            u64 blocked = 0ull;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) blocked |= m[h][k] & g[k];
+            f[h] = has[h] && (g[h] & bit) && (single || blocked == 0ull);
+            fm[h] = __ballot(f[h]);
+            any |= fm[h];
+        }
+        if (any == 0ull) break;
+        const int need = child - count;
+        int base = 0;
+        u64 tm[NW];
+#pragma unroll
+        for (int h = 0; h < NW; ++h) {
+            const int r = base + __popcll(fm[h] & below);
+            const bool t = f[h] && r < need;
+            if (t) S.lst[count + r] = (unsigned char)(v + 64 * h);
+            tm[h] = __ballot(t);
+            base += __popcll(fm[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < NW; ++h) { ad[h] |= tm[h]; count += __popcll(tm[h]); }
+    }
+#pragma unroll
+    for (int h = 0; h < NW; ++h) { e[h] |= ad[h]; w[h] |= ad[h]; }
     const int short_window = count != child;
-    const bool in_lo = (w_lo & bit) != 0, in_hi = (w_hi & bit) != 0;
-    const int nlo = __popcll(w_lo);
     // the side records and block sides of this lane's window node, in flight under the set order.  A lane seldom holds
-    // two window nodes (v and v + 64): the second one's are fetched afterwards, when it exists (keeps 19 registers free)
-    const bool both = in_lo && in_hi;
-    const int h1 = in_lo ? 0 : 1;                                        // the half served first
-    ulonglong2 sd[4];
+    // two window nodes (v, v + 64, ...): the others' are fetched afterwards, when they exist (keeps the registers free)
+    int h1 = -1, nin = 0;                                             // the first half this lane has a window node in
+#pragma unroll
+    for (int h = NW - 1; h >= 0; --h) if (w[h] & bit) { h1 = h; ++nin; }
+    u64 sd[4][NW];
     int bd[3] = {0, 0, 0};
     {
-        const bool on = (in_lo || in_hi) && !short_window;
-        const int node = v + 64 * h1;
-        const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(relb + (size_t)N * NW + (size_t)node * 4 * NW);
+        const bool on = h1 >= 0 && !short_window;
+        const int node = v + 64 * (h1 < 0 ? 0 : h1);
+        const u64 *q = relb + (size_t)N * NW + (size_t)(on ? node : 0) * 4 * NW;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sd[k] = on ? q[k] : make_ulonglong2(0ull, 0ull);
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int x = 0; x < NW; ++x) { const u64 t = q[k * NW + x]; sd[k][x] = on ? t : 0ull; }
 #pragma unroll
         for (int k = 0; k < D; ++k) bd[k] = on ? a.blocks[((size_t)inst * N + node) * D + k] : 0;
     }
@@ -740,7 +793,8 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0) while only loads are outstanding (see rolling_window_wave)
 #endif
     if (v == 0) {
-        stp[0] = e_lo; stp[1] = e_hi; stp[2] = w_lo; stp[3] = w_hi;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) { stp[k] = e[k]; stp[NW + k] = w[k]; }
         if (a.err_out && (short_window || !a.err_sticky)) a.err_out[inst] = short_window;
     }
     if (short_window) return;
@@ -755,48 +809,74 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
     const int dstride = fast ? 4 : 3;
     if (fast && v < 16)
         *reinterpret_cast<float4 *>(&S.f.lut[v][0]) = make_float4((float)(v & 1), (float)((v >> 1) & 1), (float)((v >> 2) & 1), (float)((v >> 3) & 1));
-    auto publish = [&](int h, const ulonglong2 (&rec)[4], const int (&sides)[3]) {
-        const int node = v + 64 * h;
-        const int slot = h ? nlo + __popcll(w_hi & below) : __popcll(w_lo & below);    // sorted position
-        const ulonglong2 m0 = h ? m_hi : m_lo;
-        S.side[0][2 * slot] = m0.x; S.side[0][2 * slot + 1] = m0.y;
+    u64 *side0 = &S.side[0][0];                                        // [5][64] words: relation k, slot, word
+    auto slot_of = [&](int h) -> int {                                 // sorted position of node v + 64 h
+        int sl = __popcll(w[h] & below);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { S.side[1 + k][2 * slot] = rec[k].x; S.side[1 + k][2 * slot + 1] = rec[k].y; }
+        for (int k = 0; k < NW; ++k) if (k < h) sl += __popcll(w[k]);
+        return sl;
+    };
+    auto publish = [&](int h, const u64 (&mv)[NW], const u64 (&rec)[4][NW], const int (&sides)[3]) {
+        const int node = v + 64 * h;
+        const int slot = slot_of(h);
+#pragma unroll
+        for (int x = 0; x < NW; ++x) side0[NW * slot + x] = mv[x];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int x = 0; x < NW; ++x) side0[(1 + k) * 64 + NW * slot + x] = rec[k][x];
 #pragma unroll
         for (int k = 0; k < 3; ++k) dims[slot * dstride + k] = sides[k];
         S.srt[slot] = (unsigned char)node;
         if (a.nodes_out) a.nodes_out[(size_t)inst * child + slot] = node;
     };
-    if (in_lo || in_hi) publish(h1, sd, bd);
-    if (__ballot(both)) {                                              // rare: a lane with two window nodes
-        if (both) {
-            const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(relb + (size_t)N * NW + (size_t)(v + 64) * 4 * NW);
-            ulonglong2 rec[4];
-            int sides[3] = {0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rec[k] = q[k];
+    for (int h = 0; h < NW; ++h) if (h == h1) publish(h, m[h], sd, bd);
+    if (__ballot(nin > 1)) {                                           // rare: a lane with two or more window nodes
 #pragma unroll
-            for (int k = 0; k < D; ++k) sides[k] = a.blocks[((size_t)inst * N + v + 64) * D + k];
-            publish(1, rec, sides);
+        for (int h = 1; h < NW; ++h) {
+            if (nin > 1 && h != h1 && (w[h] & bit)) {
+                const u64 *q = relb + (size_t)N * NW + (size_t)(v + 64 * h) * 4 * NW;
+                u64 rec[4][NW];
+                int sides[3] = {0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int x = 0; x < NW; ++x) rec[k][x] = q[k * NW + x];
+#pragma unroll
+                for (int k = 0; k < D; ++k) sides[k] = a.blocks[((size_t)inst * N + v + 64 * h) * D + k];
+                publish(h, m[h], rec, sides);
+            }
         }
     }
     tap_wave_lds_sync();
-    const u64 af_lo = all_lo & ~e_lo, af_hi = all_hi & ~e_hi;          // after_nodes_list
+    u64 af[NW];                                                        // after_nodes_list
+#pragma unroll
+    for (int k = 0; k < NW; ++k) af[k] = all[k] & ~e[k];
     for (int idx = v; idx < 5 * child; idx += 64) {                    // (relation k, sub-graph column cm)
         const int k = idx / child, cm = idx - k * child;
-        const int u = S.ord[cm];
-        const int slot = u < 64 ? __popcll(w_lo & ((1ull << u) - 1ull)) : nlo + __popcll(w_hi & ((1ull << (u - 64)) - 1ull));
-        u64 lo = S.side[k][2 * slot], hi = S.side[k][2 * slot + 1];
+        const int u = S.ord[cm], uh = u >> 6;
+        const u64 ubelow = (1ull << (u & 63)) - 1ull;
+        int slot = 0;
+#pragma unroll
+        for (int x = 0; x < NW; ++x) slot += x < uh ? __popcll(w[x]) : x == uh ? __popcll(w[x] & ubelow) : 0;
+        u64 wd[NW];
+        u64 outside = 0ull;
+#pragma unroll
+        for (int x = 0; x < NW; ++x) { wd[x] = side0[k * 64 + NW * slot + x]; outside |= wd[x] & af[x]; }
         // :1690-1705: a blocker that has not entered any window yet => the side counts as self-blocked
-        const bool selfb = k > 0 && ((lo & af_lo) | (hi & af_hi)) != 0;
-        lo &= w_lo; hi &= w_hi;
-        if (selfb) { if (u < 64) lo |= 1ull << u; else hi |= 1ull << (u - 64); }
-        unsigned w = 0u;
+        const bool selfb = k > 0 && outside != 0ull;
+#pragma unroll
+        for (int x = 0; x < NW; ++x) { wd[x] &= w[x]; if (selfb && x == uh) wd[x] |= 1ull << (u & 63); }
+        unsigned ww = 0u;
         for (int rm = 0; rm < child; ++rm) {
-            const int node = S.ord[rm];
-            w |= (unsigned)(((node >= 64 ? hi : lo) >> (node & 63)) & 1ull) << rm;
+            const int node = S.ord[rm], nh = node >> 6;
+            u64 sel = wd[0];
+#pragma unroll
+            for (int x = 1; x < NW; ++x) sel = nh == x ? wd[x] : sel;
+            ww |= (unsigned)((sel >> (node & 63)) & 1ull) << rm;
         }
-        iw[idx] = w;
+        iw[idx] = ww;
     }
     tap_wave_lds_sync();
     if (fast) {                                                        // kernel-uniform
@@ -825,9 +905,9 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
         if (a.cur_mask_out)                                                           // model.py:297-307
             a.cur_mask_out[(size_t)inst * nRc + col] = (__popc(ws[1]) * __popc(ws[2]) + __popc(ws[0]) != 0) ? 0.f : 1.f;
         if (packed) {
-            const u64 w = (u64)ws[0] | ((u64)ws[1] << child) | ((u64)ws[2] << (2 * child));
-            S.cw[col] = w;
-            if (a.bits_out) a.bits_out[(size_t)inst * nRc + col] = w;
+            const u64 cwv = (u64)ws[0] | ((u64)ws[1] << child) | ((u64)ws[2] << (2 * child));
+            S.cw[col] = cwv;
+            if (a.bits_out) a.bits_out[(size_t)inst * nRc + col] = cwv;
         } else {
             for (int rm = 0; rm < child; ++rm)
 #pragma unroll
@@ -855,7 +935,7 @@ __device__ inline void rolling_window_wave2(const RollArgs &a, int inst, int v, 
 template <int D, int CH>
 __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, RollLds &S)
 {
-    if constexpr (CH == ROLL_CH_WIDE) { rolling_window_wave2<D>(a, inst, v, S); return; }
+    if constexpr (CH <= ROLL_CH_WIDE) { rolling_window_waveN<D, -CH>(a, inst, v, S); return; }
     if (inst >= a.B) return;
     PROF_BEGIN;
     const int N = a.N, child = CH > 0 ? CH : a.child;
@@ -941,7 +1021,9 @@ __device__ inline void rolling_window_wave(const RollArgs &a, int inst, int v, R
 }
 
 // instances the two-word wavefront form takes (rolling_window_wave2)
-__host__ __device__ constexpr bool roll_wide_ok(int N, int child) { return N > 64 && N <= 128 && child <= 32; }
+// words per node mask of the one-wavefront form for instances above 64 blocks (0: no such form -- one thread per instance)
+__host__ __device__ constexpr int roll_wide_nw(int N, int child) { return (N > 64 && N <= 256 && child * ((N + 63) / 64) <= 64) ? (N + 63) / 64 : 0; }
+__host__ __device__ constexpr bool roll_wide_ok(int N, int child) { return roll_wide_nw(N, child) != 0; }
 
 // 8 waves per SIMD (<= 64 VGPRs): at B = 8192 a CU gets 32 one-wave instances, and at 68 VGPRs only 28
 // were resident, so one workgroup in eight ran as a second round
@@ -964,6 +1046,15 @@ __global__ void __launch_bounds__(TAP_BLOCK) __attribute__((amdgpu_waves_per_eu(
     __shared__ RollLds S[TAP_BLOCK / 64];
     const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
     rolling_window_wave<D, CH>(roll_hot(a, h_rel, h_state, h_remove, h_B, h_N), blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
+}
+
+// the three- and four-word forms (129 .. 256 blocks) keep up to 16 mask words per lane: no 64-register cap
+template <int D, int NW>
+__global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window_wide(ROLL_HOT_PARAMS, RollArgs a)
+{
+    __shared__ RollLds S[TAP_BLOCK / 64];
+    const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
+    rolling_window_waveN<D, NW>(roll_hot(a, h_rel, h_state, h_remove, h_B, h_N), blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
 }
 
 // ---- fused rolling step: add_new_block for the column picked in the CURRENT window (gathered from
@@ -1022,20 +1113,23 @@ __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a, ROLL_HO
 // NW = ceil(N/64) words, ONE THREAD per instance (relations: one thread per node) -- a correctness path like
 // big.hip, not a tuned one.  Layout: rel = 5*N*NW words per instance (N movement masks, then per node the four
 // side masks), state = 2*NW words (entered, window).
-constexpr int ROLL_MAX_N = 256, ROLL_MAX_NW = ROLL_MAX_N / 64;
+// (Round 5: instances of up to ROLL_MAX_N = 4 096 blocks -- the masks are compiled for 4, 16 or 64 words, the smallest
+//  that holds N; above 256 blocks this is the only form.)
+constexpr int ROLL_MAX_N = 4096;
 
-struct NMask {
-    u64 w[ROLL_MAX_NW];
+template <int MW> struct NMaskT {
+    u64 w[MW];
 };
-__device__ __forceinline__ bool nm_test(const NMask &m, int i) { return (m.w[i >> 6] >> (i & 63)) & 1ull; }
-__device__ __forceinline__ void nm_set(NMask &m, int i) { m.w[i >> 6] |= 1ull << (i & 63); }
-__device__ __forceinline__ void nm_clear(NMask &m, int i) { m.w[i >> 6] &= ~(1ull << (i & 63)); }
-__device__ __forceinline__ int nm_count(const NMask &m, int NW) { int c = 0; for (int k = 0; k < NW; ++k) c += __popcll(m.w[k]); return c; }
-__device__ __forceinline__ bool nm_meets(const u64 *a, const NMask &b, int NW) { bool r = false; for (int k = 0; k < NW; ++k) r |= (a[k] & b.w[k]) != 0; return r; }
+template <int MW> __device__ __forceinline__ bool nm_test(const NMaskT<MW> &m, int i) { return (m.w[i >> 6] >> (i & 63)) & 1ull; }
+template <int MW> __device__ __forceinline__ void nm_set(NMaskT<MW> &m, int i) { m.w[i >> 6] |= 1ull << (i & 63); }
+template <int MW> __device__ __forceinline__ void nm_clear(NMaskT<MW> &m, int i) { m.w[i >> 6] &= ~(1ull << (i & 63)); }
+template <int MW> __device__ __forceinline__ int nm_count(const NMaskT<MW> &m, int NW) { int c = 0; for (int k = 0; k < NW; ++k) c += __popcll(m.w[k]); return c; }
+template <int MW> __device__ __forceinline__ bool nm_meets(const u64 *a, const NMaskT<MW> &b, int NW) { bool r = false; for (int k = 0; k < NW; ++k) r |= (a[k] & b.w[k]) != 0; return r; }
 
-template <int D>
+template <int D, int MW>
 __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_init_big(RollArgs a)
 {
+    typedef NMaskT<MW> NMask;
     const long t = (long)blockIdx.x * TAP_BLOCK + threadIdx.x;
     const int n = a.N, NW = (n + 63) / 64;
     if (t >= (long)a.B * n) return;
@@ -1102,9 +1196,11 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_init_big(RollArgs a)
 }
 
 // remove_block + convert_to_input of ONE instance by one thread (rolling_window_wave, serial form)
-template <int D>
+template <int D, int MW>
 __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
 {
+    typedef NMaskT<MW> NMask;
+    typedef unsigned short node_t;                                    // node ids up to 4 095
     const int inst = blockIdx.x * 64 + threadIdx.x;
     if (inst >= a.B) return;
     const int N = a.N, NW = (N + 63) / 64, child = a.child;
@@ -1121,9 +1217,9 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
         for (int i = 0; i < N; ++i)
             if (nm_test(window, i) && slot-- == 0) { nm_clear(window, i); break; }
     }
-    unsigned char lst[80], ord[80], pos[ROLL_MAX_N];
+    node_t lst[80], ord[80];
     int count = 0;                                                    // (2) generate.py:1724-1750
-    for (int i = 0; i < N; ++i) if (nm_test(window, i)) lst[count++] = (unsigned char)i;
+    for (int i = 0; i < N; ++i) if (nm_test(window, i)) lst[count++] = (node_t)i;
     NMask added = {};
     while (count < child) {
         NMask gmc;
@@ -1133,7 +1229,7 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
         int got = 0;
         NMask take = {};
         for (int j = 0; j < N && got < need; ++j)
-            if (nm_test(gmc, j) && (single || !nm_meets(rel0 + (size_t)j * NW, gmc, NW))) { nm_set(take, j); lst[count + got++] = (unsigned char)j; }
+            if (nm_test(gmc, j) && (single || !nm_meets(rel0 + (size_t)j * NW, gmc, NW))) { nm_set(take, j); lst[count + got++] = (node_t)j; }
         if (got == 0) break;
         for (int k = 0; k < NW; ++k) added.w[k] |= take.w[k];
         count += got;
@@ -1145,8 +1241,7 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
     if (short_window) return;
     int tbl[PYSET_CAP], tmp[PYSET_CAP];                               // the set-order tables, thread-private
     if (2 * child < N) pyset_order(lst, child, ord, tbl, tmp);        // (3)
-    else { int m = 0; for (int i = 0; i < N; ++i) if (nm_test(window, i)) ord[m++] = (unsigned char)i; }
-    for (int i = 0; i < child; ++i) pos[ord[i]] = (unsigned char)i;
+    else { int m = 0; for (int i = 0; i < N; ++i) if (nm_test(window, i)) ord[m++] = (node_t)i; }
     // (4) tensors (generate.py:1778-1822)
     NMask after;
     for (int k = 0; k < NW; ++k) after.w[k] = all.w[k] & ~entered.w[k];
@@ -1200,16 +1295,17 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
             if (a.bits_out && rows <= 64) a.bits_out[(size_t)inst * nRc + col] = word;
         }
     }
-    (void)pos;
 }
 
 static int roll_check(tap_ctx *ctx, int B, int D, int N, int child)
 {
-    // windows: at most 64 nodes (one 64-bit word of sub-graph rows per node); instances of 65 .. 128 blocks keep the
-    // one-wavefront kernels while the window has at most 32 nodes (roll_wide_ok), beyond that one thread per instance
+    // windows: at most 64 nodes (one 64-bit word of sub-graph rows per node); instances of 65 .. 256 blocks keep the
+    // one-wavefront kernels while the window has at most 64 / ceil(N / 64) nodes (roll_wide_nw), beyond that -- and above
+    // 256 blocks -- one thread per instance
     if ((D != 2 && D != 3) || B < 0 || N < 1 || N > ROLL_MAX_N || child < 1 || child > N || child > 64)
         return tap_fail(ctx, TAP_E_INVALID, "bad rolling arguments (total blocks <= %d, window <= min(total, 64); instances above 64 "
-                                            "blocks run on one wavefront each up to 128 blocks with windows of at most 32 nodes)", ROLL_MAX_N);
+                                            "blocks run on one wavefront each up to 256 blocks with windows of at most 64 / ceil(N / 64) "
+                                            "nodes, one thread per instance otherwise)", ROLL_MAX_N);
     return TAP_OK;
 }
 
@@ -1231,8 +1327,13 @@ extern "C" int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t
     if (N > 64) {                                                     // one thread per node, multi-word masks
         const long threads = (long)B * N;
         const unsigned g2 = (unsigned)((threads + TAP_BLOCK - 1) / TAP_BLOCK);
-        if (D == 2) hipLaunchKernelGGL(k_rolling_init_big<2>, dim3(g2), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(k_rolling_init_big<3>, dim3(g2), dim3(TAP_BLOCK), 0, (hipStream_t)stream, a);
+        hipStream_t s_ = (hipStream_t)stream;
+#define TAP_ROLL_INIT(D_) do { \
+            if (N <= 256) hipLaunchKernelGGL((k_rolling_init_big<D_, 4>), dim3(g2), dim3(TAP_BLOCK), 0, s_, a); \
+            else if (N <= 1024) hipLaunchKernelGGL((k_rolling_init_big<D_, 16>), dim3(g2), dim3(TAP_BLOCK), 0, s_, a); \
+            else hipLaunchKernelGGL((k_rolling_init_big<D_, 64>), dim3(g2), dim3(TAP_BLOCK), 0, s_, a); } while (0)
+        if (D == 2) TAP_ROLL_INIT(2); else TAP_ROLL_INIT(3);
+#undef TAP_ROLL_INIT
         TAP_LAUNCH_CHECK(ctx, "k_rolling_init_big");
         return TAP_OK;
     }
@@ -1280,16 +1381,26 @@ static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, con
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bits_out needs 3*child <= 64, (child*R) %% 4 == 0, child*R <= 256");
     const int grid = (B + TAP_BLOCK / 64 - 1) / (TAP_BLOCK / 64);
     if (grid == 0) return TAP_OK;
-    if (roll_wide_ok(N, child)) {                                     // 65 .. 128 blocks: one wavefront per instance
-        if (D == 2) hipLaunchKernelGGL((k_rolling_window<2, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
-        else hipLaunchKernelGGL((k_rolling_window<3, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, (hipStream_t)stream, ROLL_HOT_ARGS(a), a);
+    if (const int nw = roll_wide_nw(N, child)) {                      // 65 .. 256 blocks: one wavefront per instance
+        hipStream_t s_ = (hipStream_t)stream;
+#define TAP_ROLL_WIDE(D_) do { \
+            if (nw == 2) hipLaunchKernelGGL((k_rolling_window<D_, ROLL_CH_WIDE>), dim3(grid), dim3(TAP_BLOCK), 0, s_, ROLL_HOT_ARGS(a), a); \
+            else if (nw == 3) hipLaunchKernelGGL((k_rolling_window_wide<D_, 3>), dim3(grid), dim3(TAP_BLOCK), 0, s_, ROLL_HOT_ARGS(a), a); \
+            else hipLaunchKernelGGL((k_rolling_window_wide<D_, 4>), dim3(grid), dim3(TAP_BLOCK), 0, s_, ROLL_HOT_ARGS(a), a); } while (0)
+        if (D == 2) TAP_ROLL_WIDE(2); else TAP_ROLL_WIDE(3);
+#undef TAP_ROLL_WIDE
         TAP_LAUNCH_CHECK(ctx, "k_rolling_window(wide)");
         return TAP_OK;
     }
     if (N > 64) {                                                     // one thread per instance
         const int g2 = (B + 63) / 64;
-        if (D == 2) hipLaunchKernelGGL(k_rolling_window_big<2>, dim3(g2), dim3(64), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL(k_rolling_window_big<3>, dim3(g2), dim3(64), 0, (hipStream_t)stream, a);
+        hipStream_t s_ = (hipStream_t)stream;
+#define TAP_ROLL_BIG(D_) do { \
+            if (N <= 256) hipLaunchKernelGGL((k_rolling_window_big<D_, 4>), dim3(g2), dim3(64), 0, s_, a); \
+            else if (N <= 1024) hipLaunchKernelGGL((k_rolling_window_big<D_, 16>), dim3(g2), dim3(64), 0, s_, a); \
+            else hipLaunchKernelGGL((k_rolling_window_big<D_, 64>), dim3(g2), dim3(64), 0, s_, a); } while (0)
+        if (D == 2) TAP_ROLL_BIG(2); else TAP_ROLL_BIG(3);
+#undef TAP_ROLL_BIG
         TAP_LAUNCH_CHECK(ctx, "k_rolling_window_big");
         return TAP_OK;
     }
@@ -1350,9 +1461,10 @@ static int rolling_step_impl(tap_ctx *ctx, const tap_env_desc *d, void *env_stat
     if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||
         static_cur == static_next)
         return tap_fail(ctx, TAP_E_INVALID, "bad rolling_step arguments (static_cur and static_next must differ)");
-    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d) || (N > 64 && !roll_wide_ok(N, child))) {
+    if (d->strategy != TAP_LB_GREEDY || tap_is_big(d) || (N > 64 && roll_wide_nw(N, child) != 2)) {
         // no single kernel for these (MACS / legacy LB placements, thread-per-container shapes, instances above 128
-        // blocks): the same step as its two launches
+        // blocks: their window wave keeps up to 16 mask words per lane, the fused kernels are held to 72 registers):
+        // the same step as its two launches
         rc = tap_env_step_gather(ctx, d, env_state, static_cur, 1 + d->D, child * (d->D == 2 ? 2 : 6), ptr, nullptr,
                                  feature_out, stream);
         if (rc == TAP_OK && aux) {

@@ -10,9 +10,11 @@
 // are rebuilt from the placement history there; a block settles at (x, y, Z) iff Z = max of the height-map under it
 // (and, for hard rewards, the position is stable), so `visited` is one flag per position.  Here rows of the grid are
 // 64-bit masks over x (W, L <= 64) and every list operation is bit arithmetic on them.
-// Limits: W, L <= 64; block footprints up to 8 x 8 (the support mask of tools.is_stable); the EMS list holds
+// Limits: W, L <= 64; block footprints up to 16 x 16 (8 x 8: the support mask of tools.is_stable, beyond: tap_stable_wide.h); the EMS list holds
 // macs3_big_cap() entries (error bit 16 beyond, like MACS3_EMS_CAP).
 #pragma once
+
+#include "tap_stable_wide.h"
 
 #include <cstddef>
 #include <cstdint>
@@ -104,7 +106,7 @@ M3B_HD inline void m3b_scan(const M3BState &s, int x, int y, int bx, int by, int
         for (int j = 0; j < by; ++j) {
             const int h = s.hm[(x + i) * s.L + y + j];
             sum += h;
-            const m3b_u64 bit = 1ull << (i * 8 + j);
+            const m3b_u64 bit = (i < 8 && j < 8) ? 1ull << (i * 8 + j) : 0ull;   // the 8 x 8 support mask; wider footprints: tap_stable_wide.h
             if (h > mx) { mx = h; eq = bit; }
             else if (h == mx) eq |= bit;
         }
@@ -326,7 +328,9 @@ M3B_HD inline M3BResult m3b_place(M3BState &s, int *cnt, int &err, int bx, int b
             if (px < X && py < Y) {
                 int mp, sum; m3b_u64 eq;
                 m3b_scan(s, px, py, bx, by, mp, eq, sum);
-                const int st = mp == 0 ? 1 : stab_of(bx, by, eq);
+                const int st = mp == 0 ? 1 : (bx > 8 || by > 8)
+                                   ? tap_stable3d_wide([&](int i, int j) { return s.hm[(px + i) * s.L + py + j]; }, bx, by, mp)
+                                   : stab_of(bx, by, eq);
                 if (st || !hard) v = (mp << 2) | (st << 1);                        // :2963-2965
             }
             s.lev[py * W + px] = v;

@@ -15,6 +15,8 @@
 // The container's working set lives in the wave's LDS tile (M3WTile).  W, L <= 64; footprints <= 8 x 8.
 #pragma once
 
+#include "tap_stable_wide.h"
+
 #include "tap_common.h"
 #include "tap_place.h"
 #include "tap_macs3_big.h"
@@ -91,7 +93,7 @@ __device__ inline void m3w_scan(const M3WTile &s, int x, int y, int bx, int by, 
         for (int j = 0; j < by; ++j) {
             const int h = s.hm[(x + i) * s.L + y + j];
             sum += h;
-            const m3b_u64 bit = 1ull << (i * 8 + j);
+            const m3b_u64 bit = (i < 8 && j < 8) ? 1ull << (i * 8 + j) : 0ull;   // the 8 x 8 support mask; wider footprints: tap_stable_wide.h
             if (h > mx) { mx = h; eq = bit; }
             else if (h == mx) eq |= bit;
         }
@@ -319,7 +321,9 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
         if (px < X && py < Y) {
             int mp, sum; m3b_u64 eq;
             m3w_scan(s, px, py, bx, by, mp, eq, sum);
-            const int st = mp == 0 ? 1 : tap_stable3d_any(lut, bx, by, eq);
+            const int st = mp == 0 ? 1 : (bx > 8 || by > 8)
+                               ? tap_stable3d_wide([&](int i, int j) { return s.hm[(px + i) * s.L + py + j]; }, bx, by, mp)
+                               : tap_stable3d_any(lut, bx, by, eq);
             if (st || !hard) v = (mp << 2) | (st << 1);                            // :2963-2965
         }
         s.lev[p] = v;

@@ -44,7 +44,8 @@ inline MaskArgs mask_finish(MaskArgs a)
     a.c4_magic = c4 > 0 ? 65536 / c4 + 1 : 0;
     a.rp = c4 > 0 ? 64 / c4 : 0;
     a.wt = tap_write_through((size_t)a.B * a.rows * a.nR * sizeof(float));
-    const bool al = c4 > 0 && ((a.rp * c4) & 3) == 0;     // a store instruction's rp * c4 float4 are whole 64-byte granules
+    // (rotated roles only for write-through launches: the nontemporal form keeps round 4's store loops, see stream_wave_bits)
+    const bool al = a.wt && c4 > 0 && ((a.rp * c4) & 3) == 0;     // a store instruction's rp * c4 float4 are whole 64-byte granules
     a.sb_mul = al ? (a.rows * c4) & 3 : 0;
     a.sb_add = al ? (int)((reinterpret_cast<uintptr_t>(a.dyn_out) >> 4) & 3) : 0;
     a.nq = a.rp > 0 ? (a.rows + a.rp - 1) / a.rp : 0;
@@ -451,7 +452,7 @@ __device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v 
 //  cache-resident buffer, 6.14 against 4.02 us on fresh ones, profiles/r04_bw_store_shapes.json); the kernel did not
 //  agree: c2 1 295 -> 1 268 M env-steps/s, c3 520 -> 478 M, cold passes 1 009 -> 992 M, and 10-15 % slower from
 //  B = 128 k up -- the LDS read and the index arithmetic in front of every store cost more than the half lines.)
-template <int NS, int NC, bool BUILD = false>
+template <int NS, int NC, bool BUILD = false, bool MERGED = true>
 __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
                                                  float *lds = nullptr)
 {
@@ -565,7 +566,32 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             const int nq = (non > 1 ? a.nq2 : a.nq) + role.nq;                // role.nq: one more instruction when rotated
             float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)senv0 * rows * nR) + role.c4;
             int rr = role.r0;
-            if (rows <= 32) {
+            // MERGED = false (two-slab waves only): round 4's loops, one per slab on the lane's own rows.  Which form a
+            // kernel takes is decided where it is launched (transition.hip), from these A/B runs (env-steps/s, same
+            // session, profiles/r05_store_shape_ab.txt): the run-of-rows loop c2 1 279 against 1 258 M and c4 504 against
+            // 490 M, but c3 495 against 509 M (15 store instructions per run, the stream waves are that step's critical
+            // path) and, wherever the stores are nontemporal (the output no longer fits the caches), 1 549 against
+            // 1 872 M at B = 128 k and 1 333-1 368 against 1 470-1 541 M at B = 1 M in c2's shape.  Compiling both forms
+            // into one kernel behind a run-time switch cost the small-batch gain (1 256 M), hence the template.
+            bool done = false;
+            if constexpr (NS > 1 && !MERGED) {
+                if (rows <= 32) {
+#pragma unroll
+                    for (int k = 0; k < NS; ++k) {
+                        if (!on[k]) continue;
+                        float4 *dk = dst + (size_t)k * rows * C4;
+                        const unsigned m0 = (unsigned)nw[k][0], m1 = (unsigned)nw[k][1], m2 = (unsigned)nw[k][2], m3 = (unsigned)nw[k][3];
+                        for (int r = role.rsub; r < rows; r += RP) {
+                            const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
+                                                         (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
+                            store_stream(&dk[(size_t)r * C4], v, a.wt);
+                        }
+                    }
+                    done = true;
+                }
+            }
+            if (done) {
+            } else if (rows <= 32) {
                 // n <= 10 (every BASELINE window): the column words fit 32 bits -- a bit-field extract and a
                 // convert per element, no half selection
                 for (int i = 0; i < nq; ++i, rr += RP) {
@@ -735,13 +761,13 @@ __device__ __forceinline__ void stream_wave_bits_r3(const MaskArgs &a, int senv0
 }
 
 #endif
-template <int NS, int NC, bool BUILD = false>
+template <int NS, int NC, bool BUILD = false, bool MERGED = true>
 __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS], float *lds = nullptr)
 {
 #ifdef TAP_STREAM_R3
     stream_wave_bits_r3<NS, NC, BUILD>(a, senv0, lane, on, lds);
 #else
-    stream_wave_bits_r4<NS, NC, BUILD>(a, senv0, lane, on, lds);
+    stream_wave_bits_r4<NS, NC, BUILD, MERGED>(a, senv0, lane, on, lds);
 #endif
 }
 

@@ -19,17 +19,22 @@ struct TransArgs {
 
 // ---- a stream wave: out-of-place copy of SPW consecutive slabs with the chosen rows cleared
 //      (pack.py:370-374), then the column sums + both masks (pack.py:318-329)
-// MODE: 0 = fp32 copy with the column-sum shadow, 1 = on the bit shadow, 2 = first step (shadow built in the launch)
-template <int SPW, int NC, int MODE>
+// MODE & 3: 0 = fp32 copy with the column-sum shadow, 1 = on the bit shadow, 2 = first step (shadow built in the launch);
+// MODE & 4 (TAP_MODE_MERGED): the fp32 expansion walks the wave's two slabs as one run of rows (tap_masks.h:
+// stream_wave_bits, where the A/B figures are) instead of slab by slab
+constexpr int TAP_MODE_MERGED = 4;
+template <int SPW, int NC, int MODE_>
 __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
 {
+    constexpr int MODE = MODE_ & 3;
+    constexpr bool MERGED = (MODE_ & TAP_MODE_MERGED) != 0;
     bool on[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
     TL_STAMP(0);
     if (NC > 0) {
-        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false>(m, senv0, lane, on, lds);
-        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true>(m, senv0, lane, on, lds);
+        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED>(m, senv0, lane, on, lds);
+        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true, MERGED>(m, senv0, lane, on, lds);
         else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         TL_STAMP(2);
         TL_WAIT_VM();

@@ -45,7 +45,7 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TAP_
     if (wave >= ENV_WAVES ? (a.flags & TAP_T_PROF_NOSTREAM) : (a.flags & TAP_T_PROF_NOPLACE)) return;
 #endif
     if (wave >= ENV_WAVES) {
-        const MaskArgs m = tap_mask_hot(a.m, MODE == 1, TAP_MASK_HOT_NAMES);
+        const MaskArgs m = tap_mask_hot(a.m, (MODE & 3) == 1, TAP_MASK_HOT_NAMES);
         trans_stream_wave<SPW, NC, MODE>(m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * h_nR);
         return;
@@ -83,6 +83,37 @@ extern "C" int tap_prof_read_timeline(unsigned long long *out, int clear)
 //  env-steps/s): the saturated regime is not bound by vector issue -- 248 M vector instructions per 1.16 ms launch are
 //  35 % of the SIMDs' issue slots.)
 int tap_transition_macs_launch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);   // transition_macs.hip
+// big.hip: LB_GREEDY containers above 64 cells -- one wavefront per container + stream waves, on the bit shadow
+bool tap_big_transition_ok(const tap_ctx *ctx, const tap_env_desc *d, int nR);
+int tap_big_transition(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);
+// macs_big.hip / macs3_big.hip: the wave-per-container MACS placements with the stream waves beside them (mask update +
+// placement in one launch; a fresh container and calc_ratio stay launches of their own at the two ends of an episode)
+bool tap_macs_wave_transition_ok(const tap_ctx *ctx, const tap_env_desc *d, int nR);
+int tap_macs_wave_transition(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);
+bool tap_macs3_wave_transition_ok(const tap_ctx *ctx, const tap_env_desc *d, int nR);
+int tap_macs3_wave_transition(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, hipStream_t st);
+int tap_macs2d_wave_from();                                                                                 // macs.hip
+
+// 0: no wave-per-container fused step; 1: big.hip (LB_GREEDY, handles fresh / ratio itself); 2 / 3: MACS 2D / 3D
+static int transition_wave_kind(const tap_ctx *ctx, const tap_env_desc *d, int nR, int rows)
+{
+    if (rows > 64) return 0;                                                      // the fused kernels carry the one-word shadow only
+    if (tap_is_big(d)) return tap_big_transition_ok(ctx, d, nR) ? 1 : 0;
+    if (d->strategy != TAP_MACS) return 0;
+    if (d->D == 2) return (d->W > 16 && d->W >= tap_macs2d_wave_from() && tap_macs_wave_transition_ok(ctx, d, nR)) ? 2 : 0;
+    return (tap_is_big_macs3(d) && tap_macs3_wave_transition_ok(ctx, d, nR)) ? 3 : 0;
+}
+
+// the step of a wave-per-container shape on the bit shadow: a.m is filled in
+static int transition_wave_launch(tap_ctx *ctx, const tap_env_desc *d, void *state, const TransArgs &a, int kind, void *stream)
+{
+    if (kind == 1) return tap_big_transition(ctx, d, a, (hipStream_t)stream);
+    int rc = TAP_OK;
+    if ((a.flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
+    rc = kind == 2 ? tap_macs_wave_transition(ctx, d, a, (hipStream_t)stream) : tap_macs3_wave_transition(ctx, d, a, (hipStream_t)stream);
+    if (rc == TAP_OK && (a.flags & TAP_T_RATIO)) rc = tap_env_ratio(ctx, d, state, a.ratio_out, nullptr, nullptr, stream);
+    return rc;
+}
 int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d);                                                    // macs.hip
 
 template <int D, int G, int SW>
@@ -94,7 +125,11 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
 #define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, TAP_MASK_HOT_ARGS(a.m), a)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
+    // 2D windows (nR = 2n columns: five store instructions per run at c2) take the run-of-rows expansion while the stores
+    // are write-through; 3D windows and every launch beyond the write-through limit keep the slab-by-slab loops
+    const bool merged = D == 2 && a.m.wt != 0;
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) { if (D == 2 && merged) TAP_LAUNCH_T(NC_, (D == 2 ? 5 : 1), LDS_); else TAP_LAUNCH_T(NC_, 1, LDS_); } \
+        else if (mode == 2) { if (D == 2 && merged) TAP_LAUNCH_T(NC_, (D == 2 ? 6 : 2), LDS_); else TAP_LAUNCH_T(NC_, 2, LDS_); } else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;
@@ -173,6 +208,7 @@ int tap_step_aux_launch(tap_ctx *ctx, const StepArgs &s, hipStream_t st)
 extern "C" int tap_transition_launches(const tap_ctx *ctx, const tap_env_desc *d, int n, int R, int rows, int on_bits)
 {
     if (!d || n < 1 || R < 1 || rows < 1) return TAP_E_INVALID;
+    if (on_bits && transition_wave_kind(ctx, d, n * R, rows)) return 1;
     return (transition_single_kernel(ctx, d, n * R) && (!on_bits || rows <= 64)) ? 1 : 2;
 }
 
@@ -252,6 +288,13 @@ static int transition_bits_impl(tap_ctx *ctx, const tap_env_desc *d, void *state
     if (rc) return rc;
     if (!bits_in || !bits_out || bits_in == bits_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_bits arguments");
+    if (const int kind = transition_wave_kind(ctx, d, n * R, rows)) {
+        a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
+                       mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
+        if (!mask_bits_ok(a.m))
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
+        return transition_wave_launch(ctx, d, state, a, kind, stream);
+    }
     if (!transition_single_kernel(ctx, d, n * R) || rows > 64) {      // the fused kernels carry the one-word shadow only
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_bits(ctx, d->B, n, R, rows, update_rows, bits_in, static_, static_rows, ptr, mask_in, bits_out,
@@ -289,6 +332,13 @@ static int transition_first_impl(tap_ctx *ctx, const tap_env_desc *d, void *stat
     if (rc) return rc;
     if (!dyn_in || !bits_out || dyn_in == dyn_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition_first arguments");
+    if (const int kind = transition_wave_kind(ctx, d, n * R, rows)) {
+        a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
+                       mask_in, nullptr, nullptr, current_out, mask_out, nullptr, bits_out, nonbinary_out});
+        if (!mask_bits_ok(a.m))
+            return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
+        return transition_wave_launch(ctx, d, state, a, kind, stream);
+    }
     if (!transition_single_kernel(ctx, d, n * R) || rows > 64) {
         if ((flags & TAP_T_FRESH) && (rc = tap_env_reset(ctx, d, state, stream)) != TAP_OK) return rc;
         rc = tap_mask_step_first(ctx, d->B, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, bits_out,

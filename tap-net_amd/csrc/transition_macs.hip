@@ -161,7 +161,7 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs3<G, NC_, M_>, LDS_)); \
         hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 5, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 6, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)   /* 5 / 6: TAP_MODE_MERGED, the run-of-rows expansion (c4: 504 against 490 M env-steps/s) */
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;
@@ -187,7 +187,7 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs<G, NC_, M_>, LDS_)); \
         hipLaunchKernelGGL((k_transition_macs<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 5, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 6, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)   /* 5 / 6: TAP_MODE_MERGED, the run-of-rows expansion (c4: 504 against 490 M env-steps/s) */
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;

@@ -53,10 +53,33 @@ def pack_blocks(blocks, container_size, reward_type='C+P+S-lb-hard'):
     st = torch.empty(B, n, dtype=torch.uint8, device=dev)
     rew = torch.empty(B, dtype=torch.float32, device=dev)
     c = _lib.ctx(dev)
-    with torch.cuda.device(dev):
-        _lib.check(_lib.lib().tap_pack_blocks(c, C.byref(desc), B, n, _lib.ptr(blocks), _lib.ptr(rew),
-                                              _lib.ptr(pos), _lib.ptr(st), None, _lib.stream_of(dev)), c)
-    return pos, st.bool(), rew
+    try:
+        # one launch for every container size (generate.py:908 accepts any --initial_container_width): lane-per-cell
+        # groups up to 64 cells, one wavefront per container above (big.hip: k_big_wave_episode)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().tap_pack_blocks(c, C.byref(desc), B, n, _lib.ptr(blocks), _lib.ptr(rew),
+                                                  _lib.ptr(pos), _lib.ptr(st), None, _lib.stream_of(dev)), c)
+        return pos, st.bool(), rew
+    except _lib.TapError as e:
+        if e.status != _lib.TAP_E_UNSUPPORTED or not (desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))):
+            raise
+    return _pack_blocks_stepped(blocks, container_size, reward_type, dev)
+
+
+def _pack_blocks_stepped(blocks, container_size, reward_type, dev):
+    """pack_blocks without a whole-episode kernel (TAP_NO_WAVE_KERNELS): the same episode as n placement launches on a
+    state blob; a block with a side < 1 is not in the list (tap_pack_blocks' convention); NaN reward where a container
+    raised an error bit."""
+    from .env import BatchedContainer
+    B, n, D = blocks.shape
+    env = BatchedContainer(B, container_size, n, reward_type, 'full', packing_strategy='LB_GREEDY', device=dev)
+    for t in range(n):
+        blk = blocks[:, t].contiguous()
+        env.add_new_blocks(blk, active=(blk >= 1).all(dim=1), want_feature=False)
+    cps = env.calc_CPS()
+    score = torch.where(env.counters[:, 3] > 0, (cps[:, 0] + cps[:, 1]) + cps[:, 2], torch.zeros_like(cps[:, 0]))
+    rew = torch.where(env.errors != 0, torch.full_like(score, float('nan')), -score).to(torch.float32)
+    return env.positions, env.stable, rew
 
 
 def precedence_tensors(blocks, positions, container_size, arm_size=1):

@@ -689,23 +689,28 @@ def reward(static, tour_indices, reward_type, input_type, allow_rot, container_w
     cs = [container_width, container_height] if block_dim == 2 else \
         [container_width, container_width, container_height]                       # pack.py:408-411
     desc = _lib.make_desc(B, cs, n, reward_type, 'full', 'LB_GREEDY')
-    if desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8)):
-        # above the whole-episode kernel's container size: the same episode, one placement launch per block;
-        # tools.calc_positions_lb_greedy returns C + P + S un-normalised (tools.py:2442-2449)
-        from .env import BatchedContainer
-        env = BatchedContainer(B, cs, n, reward_type, 'full', packing_strategy='LB_GREEDY', device=st.device)
-        for t in range(n):
-            env.add_new_blocks_gather(st, tour[:, t].contiguous(), want_feature=False)
-        cps = env.calc_CPS()
-        return -((cps[:, 0] + cps[:, 1]) + cps[:, 2]).to(torch.float32)
     out = torch.empty(B, dtype=torch.float32, device=st.device)
     import ctypes as C
     c = _lib.ctx(st.device)
-    with torch.cuda.device(st.device):
-        _lib.check(_lib.lib().tap_episode_reward(c, C.byref(desc), B, n, _lib.ptr(st), rows, nR,
-                                                 _lib.ptr(tour), _lib.ptr(out), None, None,
-                                                 _lib.stream_of(st.device)), c)
-    return out
+    try:
+        # one launch for every container size: lane-per-cell groups up to 64 cells, one wavefront per container with the
+        # height-map in LDS above (big.hip: k_big_wave_episode)
+        with torch.cuda.device(st.device):
+            _lib.check(_lib.lib().tap_episode_reward(c, C.byref(desc), B, n, _lib.ptr(st), rows, nR,
+                                                     _lib.ptr(tour), _lib.ptr(out), None, None,
+                                                     _lib.stream_of(st.device)), c)
+        return out
+    except _lib.TapError as e:
+        if e.status != _lib.TAP_E_UNSUPPORTED or not _beyond_lane_kernels(desc):
+            raise
+    # no whole-episode kernel for this shape (TAP_NO_WAVE_KERNELS): the same episode, one placement launch per block;
+    # tools.calc_positions_lb_greedy returns C + P + S un-normalised (tools.py:2442-2449)
+    from .env import BatchedContainer
+    env = BatchedContainer(B, cs, n, reward_type, 'full', packing_strategy='LB_GREEDY', device=st.device)
+    for t in range(n):
+        env.add_new_blocks_gather(st, tour[:, t].contiguous(), want_feature=False)
+    cps = env.calc_CPS()
+    return -((cps[:, 0] + cps[:, 1]) + cps[:, 2]).to(torch.float32)
 
 
 # ---- pack.render (pack.py:670-977): the metric files of a test run ---------------------------------------------
@@ -717,6 +722,11 @@ _MCS_RATIO_TYPES = ('comp', 'soft', 'hard', 'pyrm', 'pyrm-soft', 'pyrm-hard', 'm
                     'C+P+S-mul-soft', 'C+P+S-mul-hard', 'C+P+S-mcs-soft', 'C+P+S-mcs-hard')
 _NET_REWARD_TYPES = ('C+P+S-SL-soft', 'C+P+S-RL-soft', 'C+P+S-G-soft', 'C+P+S-LG-soft')             # pack.py:728-730
 RENDER_FILES = ('ratio', 'valid_size', 'box_size', 'empty_size', 'stable_num', 'packing_height', 'time', 'ids')
+
+
+def _beyond_lane_kernels(desc):
+    """containers the lane-per-cell kernels do not take: above 64 cells, or a 3D side above 8 (tap_common.h: tap_is_big*)"""
+    return desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8))
 
 
 def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target, check=True):
@@ -760,7 +770,7 @@ def _stepped_scores(st, tour, container_size, n, reward_type, strategy, target, 
 def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, container_size, packing_strategy='LB_GREEDY',
                    target=None, check=True):
     """tools.calc_positions_lb_greedy (tools.py:2393-2449) / tools.calc_positions_mcs (tools.py:3213-3315) for
-    every sample of a batch in one launch (LB_GREEDY containers above 64 cells: one placement launch per block,
+    every sample of a batch in one launch (MACS / MUL containers above 64 cells: one placement launch per block,
     _stepped_scores): blocks in tour order into an empty container.
     -> (ratio (B,) float64, scores (B, 5) int64 = valid_size, box_size, empty_size, stable_num, max height).
     ``target`` 0 | 1: only the blocks whose target id (last row of ``static``, the two-container input types) equals
@@ -783,17 +793,22 @@ def episode_scores(static, tour_indices, reward_type, input_type, allow_rot, con
                                 "scores)" % (reward_type, 'calc_positions_mcs' if mcs else 'calc_positions_lb_greedy'))
     strategy = 'MACS' if mcs else 'LB_GREEDY'
     desc = _lib.make_desc(B, container_size, n, reward_type, 'full', strategy)
-    if desc.W * desc.L > 64 or (desc.D == 3 and (desc.W > 8 or desc.L > 8)):
-        # beyond the whole-episode kernels' container size (above 64 cells -- MACS 2D: 64 columns -- or a 3D side above 8)
+    if mcs and _beyond_lane_kernels(desc):
+        # MACS / MUL beyond the whole-episode kernels' container size (above 64 cells -- 2D: 64 columns -- or a 3D side above 8)
         return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target, check)
     ratio = torch.empty(B, dtype=torch.float64, device=st.device)
     scores = torch.empty(B, 5, dtype=torch.int64, device=st.device)
     err = torch.empty(B, dtype=torch.int32, device=st.device)
     c = _lib.ctx(st.device)
-    with torch.cuda.device(st.device):
-        _lib.check(_lib.lib().tap_episode_scores(c, C.byref(desc), B, n, _lib.ptr(st), rows, nR, _lib.ptr(tour),
-                                                 -1 if target is None else int(target), _lib.ptr(ratio), _lib.ptr(scores),
-                                                 None, None, _lib.ptr(err), _lib.stream_of(st.device)), c)
+    try:
+        with torch.cuda.device(st.device):
+            _lib.check(_lib.lib().tap_episode_scores(c, C.byref(desc), B, n, _lib.ptr(st), rows, nR, _lib.ptr(tour),
+                                                     -1 if target is None else int(target), _lib.ptr(ratio), _lib.ptr(scores),
+                                                     None, None, _lib.ptr(err), _lib.stream_of(st.device)), c)
+    except _lib.TapError as e:
+        if e.status != _lib.TAP_E_UNSUPPORTED or not _beyond_lane_kernels(desc):
+            raise
+        return _stepped_scores(st, tour, list(container_size), n, reward_type, strategy, target, check)
     if check:
         bits = int(torch.bitwise_or(err, 0).max().item()) if B else 0
         if bits:

@@ -10,13 +10,15 @@ no reference source text.  Usage:
 Fixtures:
   lbg2d.npz, lbg3d.npz, macs2d.npz, macs3d.npz, lb_legacy.npz   tools.Container.add_new_block / calc_ratio step traces
   stable3d.npz                       tools.is_stable, exhaustive over footprints <= 4x4 (+5xk samples)
+  stable3d_wide.npz                  tools.is_stable, sampled, footprints with a side of 9 .. 16
   dataset_2d.npz, dataset_3d.npz     pack.create_dataset -> text files -> pack.PACKDataset tensors
   masks_2d.npz, masks_3d.npz         pack.update_dynamic / pack.update_mask traces on random feasible tapes
   episode_2d.npz, episode_3d.npz     reference DRL.forward (pretrained actor, greedy) traces
   reward_tour.npz                    pack.reward on those tours
   kat.npz                            hand-checkable known answers
   rolling.npz                        generate.InitialContainer window traces (rolling.py's outer loop)
-  rolling_big.npz                    the same for instances of 70 .. 130 blocks (node ids above 63)
+  rolling_big.npz                    the same for instances of 70 .. 300 blocks (node ids above 63, above 255)
+  dataset_wide.npz                   pack.create_dataset with initial containers of 100 / 144 cells (3D) and 70 columns (2D)
   render.npz                         pack.render's eight metric files (LB_GREEDY / MACS / MUL, 2D / 3D, two-container types)
   ppsg3d.npz                         generate.BPP_Generator_3D / generate_blocks_with_GT (3D) under recorded seeds
   ppsg2d.npz                         generate.BPP_Generator_2D_easy / generate_blocks_with_GT (2D) under recorded seeds
@@ -227,6 +229,43 @@ def make_stable3d(tools):
          bits=np.packbits(allbits), count=np.int64(total), **sample_masks)
 
 
+WIDE_FOOTPRINTS = ((9, 9), (10, 10), (12, 7), (16, 16), (3, 16), (16, 2), (10, 4), (9, 1), (13, 13), (2, 11))
+
+
+def make_stable3d_wide(tools):
+    """tools.is_stable for footprints with a side above 8 (up to 16 x 16: the device's tap_stable_wide.h), sampled:
+    400 support patterns per footprint with 2 .. cells/2 supported cells (more is the trivial majority case), a third
+    of them confined to one or two rows / columns so that the collinear fall-back (qhull raising) is well covered.
+    Stored as one byte per footprint cell, row-major (i outer, j inner)."""
+    rng = np.random.RandomState(17)
+    out, shapes = {}, []
+    for si, (bx, by) in enumerate(WIDE_FOOTPRINTS):
+        cells = bx * by
+        masks, res = np.zeros((400, cells), np.uint8), np.zeros(400, np.uint8)
+        cont = np.zeros((bx, by, 3), dtype=int)
+        for mi in range(400):
+            k = int(rng.randint(2, max(3, cells // 2 + 2)))
+            lay = np.zeros((bx, by), int)
+            kind = mi % 6
+            if kind == 0 and by > 1:                       # one column of constant j (collinear)
+                lay[rng.choice(bx, size=min(k, bx), replace=False), rng.randint(by)] = 1
+            elif kind == 1 and bx > 1:                     # one row of constant i (collinear, p0 == p1 quirk)
+                lay[rng.randint(bx), rng.choice(by, size=min(k, by), replace=False)] = 1
+            elif kind == 2 and min(bx, by) > 2:            # a diagonal
+                m = min(bx, by)
+                idx = rng.choice(m, size=min(k, m), replace=False)
+                lay[idx, idx] = 1
+            else:
+                lay.reshape(-1)[rng.choice(cells, size=min(k, cells), replace=False)] = 1
+            cont[:, :, 0] = lay
+            masks[mi] = lay.reshape(-1)
+            res[mi] = bool(tools.is_stable(np.array([bx, by, 1]), np.array([0, 0, 1]), cont))
+        shapes.append((bx, by))
+        out["m%d" % si] = np.packbits(masks, axis=1)
+        out["r%d" % si] = res
+    save("stable3d_wide.npz", shapes=np.asarray(shapes, np.int8), **out)
+
+
 def _ref_dataset(pack, D, n, count, seed, tmp):
     """pack.create_dataset -> (dir, raw text lines) for `count` validation samples."""
     cwd = os.getcwd()
@@ -255,6 +294,36 @@ def make_dataset(pack, D, tmp, count):
          decoder_static_shape=np.asarray(ds.decoder_static.shape),
          decoder_dynamic_shape=np.asarray(ds.decoder_dynamic.shape), **files)
     return torch.from_numpy(static.astype(np.float32)), torch.from_numpy(dynamic.astype(np.float32))
+
+
+WIDE_DATASETS = ((3, 10, 10, 40, 24), (2, 12, 70, 30, 24), (3, 12, 12, 40, 8))   # D, n, initial width, height, samples
+
+
+def make_dataset_wide(pack):
+    """pack.create_dataset with --initial_container_width beyond the lane-per-cell kernels (3D 10 x 10 and 12 x 12: 100
+    and 144 cells; 2D 70 columns): generate.generate_blocks packs into the initial container with
+    tools.calc_positions_lb_greedy in hard mode (generate.py:908) for any width.  Stored: the text files' blocks and
+    positions and the PACKDataset tensors (dataset_wide.npz, round 5)."""
+    out, cases = {}, []
+    for D, n, W, H, count in WIDE_DATASETS:
+        with tempfile.TemporaryDirectory() as tmp:
+            cwd = os.getcwd()
+            os.chdir(tmp)
+            try:
+                _, vdir = pack.create_dataset(n, 2, count, D, W, H, 1, [1, 5], seed=4321 + W)
+                vdir = os.path.abspath(vdir) + "/"
+            finally:
+                os.chdir(cwd)
+            ds = pack.PACKDataset(vdir, n, count, 4321 + W, "bot", "diff", True, 5, unit=1)
+            tag = "w%d_" % len(cases)
+            cases.append(repr(dict(D=D, n=n, W=W, H=H, count=count)))
+            out[tag + "txt_blocks"] = np.loadtxt(vdir + "blocks.txt").astype(np.int8)
+            out[tag + "txt_pos"] = np.loadtxt(vdir + "pos.txt").astype(np.int16)
+            out[tag + "static"] = ds.static.detach().numpy().astype(np.int8)
+            out[tag + "dynamic"] = ds.dynamic.detach().numpy().astype(np.int8)
+            assert np.array_equal(out[tag + "static"].astype(np.float32), ds.static.detach().numpy())
+    out["cases"] = np.asarray(cases)
+    save("dataset_wide.npz", **out)
 
 
 def make_ppsg(tools, pack, src=None):
@@ -546,7 +615,10 @@ ROLLING_SHAPES = ((2, 50, 10, [7, 250], 6), (3, 50, 10, [7, 7, 250], 4), (2, 24,
 # instances above 64 blocks (rolling.py:702 --total_blocks_num is free): node ids above 63 go through the CPython-set
 # iteration order with a non-zero perturb, two-word graphs on the device (rolling_big.npz, round 3)
 ROLLING_BIG_SHAPES = ((2, 100, 10, [7, 500], 2), (3, 100, 10, [7, 7, 500], 2), (2, 128, 16, [9, 600], 1), (3, 130, 12, [7, 7, 600], 1),
-                      (2, 70, 20, [7, 400], 1))
+                      (2, 70, 20, [7, 400], 1),
+                      # round 5: three- and four-word graphs (129 .. 256 blocks, one wavefront per instance) and the
+                      # thread-per-instance form above 256 blocks
+                      (3, 200, 10, [7, 7, 900], 1), (2, 300, 10, [9, 1400], 1))
 
 
 def make_rolling(tools, generate, shapes=ROLLING_SHAPES, name="rolling.npz", seed=77):
@@ -608,10 +680,12 @@ def main():
     if want("ppsg3d"): make_ppsg3d(pack, generate)
     if want("ppsg2d"): make_ppsg2d(generate)
     if want("stable3d"): make_stable3d(tools)
+    if want("stable3d_wide"): make_stable3d_wide(tools)
     if want("kat"): make_kat(tools)
     if want("rolling"): make_rolling(tools, generate)
     if want("rolling_big"): make_rolling(tools, generate, ROLLING_BIG_SHAPES, "rolling_big.npz", seed=78)
     if want("render"): make_render(pack)
+    if want("dataset_wide"): make_dataset_wide(pack)
     if want("data"):
         with tempfile.TemporaryDirectory() as tmp:
             statics, dynamics, tours = {}, {}, {}

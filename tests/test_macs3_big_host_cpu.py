@@ -17,7 +17,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # W, L, H, n, episodes, flags (1 hard, 2 P, 4 S, 8 zero ratio = 'mul', 16 tie-break = 'mcs'), block side bound, height bound, seed
 CASES = [(10, 10, 50, 12, 150, 22, 6, 6, 1), (12, 9, 40, 16, 120, 23, 7, 5, 2), (9, 16, 60, 20, 80, 22, 5, 7, 3),
          (3, 40, 30, 14, 80, 30, 9, 4, 4), (20, 20, 30, 30, 25, 22, 9, 5, 5), (10, 10, 14, 30, 80, 22, 6, 6, 6),   # the last one overflows
-         (16, 5, 200, 40, 40, 19, 5, 9, 7), (11, 11, 50, 12, 100, 14, 6, 6, 8)]
+         (16, 5, 200, 40, 40, 19, 5, 9, 7), (11, 11, 50, 12, 100, 14, 6, 6, 8),
+         # block sides of 9 .. 16 (round 5: tap_stable_wide.h beyond the 8 x 8 support masks)
+         (20, 20, 40, 14, 60, 22, 13, 5, 9), (24, 18, 40, 12, 40, 23, 17, 5, 10), (30, 12, 50, 16, 40, 30, 17, 6, 11)]
 
 
 @pytest.fixture(scope="module")
