@@ -114,8 +114,10 @@ int tap_env_reset(tap_ctx *ctx, const tap_env_desc *d, void *state, void *stream
  * 2027-2351, is_stable_2d 839-868, is_stable 710-765; with strategy TAP_MACS ->
  * calc_one_position_mcs_2d 2456-2749 / calc_one_position_mcs_3d 2751-3165 (2D: W <= 4096, H <= 4096 -- lane-per-column
  * kernels up to 16 columns, one wavefront per container above; 3D: W, L <= 64, H <= 4096 -- lane-per-cell kernel up to
- * 64 cells with sides <= 8, one wavefront per container above (block footprints <= 8 x 8 there); block sides <=
- * container sides, else error bit 4); model.py:451-465 is the loop it replaces).
+ * 64 cells with sides <= 8, one wavefront per container above; block sides <= container sides, else error bit 4);
+ * on the wave-per-container paths (LB_GREEDY and MACS 3D above 64 cells) tools.is_stable is evaluated for block
+ * footprints up to 16 x 16 (csrc/tap_stable_wide.h beyond the 8 x 8 support masks), larger ones raise error bit 4;
+ * model.py:451-465 is the loop it replaces).
  *   blocks      (B, D) TAP_DT_F32 | TAP_DT_I32, one block per env; f32 is truncated like
  *               block.astype(int) (tools.py:3689)
  *   active      (B,) uint8 or NULL: envs with 0 are not stepped and only report their feature
@@ -199,7 +201,10 @@ int tap_episode_scores(tap_ctx *ctx, const tap_env_desc *d, int B, int n, const 
  * int32 in placement order, one launch.  This is what generate.generate_blocks calls with
  * 'C+P+S-lb-hard' on the initial container (generate.py:908); an instance is accepted when every
  * stable_out flag is 1 (generate.py:909-910).  With strategy TAP_MACS: tools.calc_positions_mcs
- * (tools.py:3213-3315).  reward_out (B,) f32 = -(C+P+S), positions_out
+ * (tools.py:3213-3315).  LB_GREEDY containers of any size (generate.py:908 accepts any --initial_container_width):
+ * lane-per-cell groups up to 64 cells, above that one wavefront per container with the height-map in LDS across the n
+ * placements (big.hip: k_big_wave_episode; tap_episode_reward / tap_episode_scores take the same path); MACS / MUL
+ * above 64 cells: TAP_E_UNSUPPORTED, step them with tap_env_step_gather.  reward_out (B,) f32 = -(C+P+S), positions_out
  * (B, n, D) i32, stable_out (B, n) u8, score64_out (B,) f64 = C+P+S -- each nullable.
  * A block with a side < 1 is not part of its list (lists of different length in one batch: the
  * two-container reward of pack.py:451-466 packs the blocks of each target id separately); S is
@@ -274,14 +279,14 @@ int tap_ppsg_check(tap_ctx *ctx, int B, int n, int input_simple, const uint64_t 
 /* ---- rolling precedence windows (generate.py:1589-1839, rolling.py:589-637) ------------- */
 
 /* generate.InitialContainer.__init__: the five dependency graphs of B fully packed initial
- * containers with N <= 256 blocks each, as column masks of NW = ceil(N/64) uint64 words with bit a of a
+ * containers with N <= 4096 blocks each, as column masks of NW = ceil(N/64) uint64 words with bit a of a
  * node j's mask = "block a blocks block j": rel_out holds 5*N*NW words per instance -- first the N movement
  * masks, then one record of four masks (left, right, forward, backward) per node, so that a step reads the
  * window nodes' side masks as one piece of a cache line each; state_out holds 2*NW words (entered, window).
- * Up to 64 blocks an instance is handled by one wavefront (lane = node), up to 128 blocks with windows of at
- * most 32 nodes still by one wavefront (lane = two nodes, two-word masks); above that by one thread per instance
- * (tap_rolling_step then runs its two launches);
- * state_out is cleared. */
+ * Up to 64 blocks an instance is handled by one wavefront (lane = node), up to 256 blocks with windows of at
+ * most 64 / NW nodes still by one wavefront (lane = NW nodes, NW-word masks; tap_rolling_step is one launch up to
+ * 128 blocks and two above); wider windows and instances of 257 .. 4096 blocks by one thread per instance
+ * (rolling.py:831 leaves --total_blocks_num free).  state_out is cleared. */
 int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container_size, int arm_size,
                      const int32_t *blocks, const int32_t *positions, uint64_t *rel_out,
                      uint64_t *state_out, void *stream);
@@ -397,7 +402,10 @@ enum {
  * One kernel for LB_GREEDY (2D/3D, up to 64 cells) and MACS/MUL (2D up to 16 columns; 3D up to 8 x 8), as long as a workgroup's candidate lists fit the device's LDS (160 KiB per workgroup on gfx950); every other
  * shape and strategy tap_env_step takes (legacy 'LB', LB_GREEDY and MACS 3D above 64 cells, MACS 2D above 16 columns, a MACS
  * container whose candidate lists do not fit a fused workgroup's LDS) runs the same step as its two launches behind
- * this entry.  feature_out nullable; ratio_out (B,) f32 required with
+ * this entry -- except on the bit shadow (tap_transition_bits / _first, the stepper), where the wave-per-container
+ * shapes are one launch too since round 5: a container's wavefront runs its own precedence slab, then its placement
+ * (big.hip, macs_big.hip, macs3_big.hip; for MACS a fresh container and calc_ratio stay launches of their own at the
+ * two ends of an episode).  feature_out nullable; ratio_out (B,) f32 required with
  * TAP_T_RATIO. */
 int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                    int update_rows, const float *dyn_in, const float *static_, int static_rows,

@@ -71,12 +71,15 @@ def short_name(k):
     """bench.py's name of a kernel (the last template argument of k_transition* is the form of the precedence
     update: 0 fp32 copy, 1 bit shadow, 2 first step building the shadow)."""
     import re
-    m = re.match(r"(?:void )?k_transition(?:_macs3?)?<(.*)>", k)
+    m = re.match(r"(?:void )?k_(?:big_|macs2d_wave_|macs3d_wave_)?transition(?:_macs3?)?<(.*)>", k)
     if m:
-        mode = m.group(1).split(",")[-1].strip()
+        mode = m.group(1).split(",")[-1].strip()   # & 3: the form; 4 = TAP_MODE_MERGED (the run-of-rows expansion, round 5)
+        mode = str(int(mode) & 3) if mode.isdigit() else mode
         return {"0": "transition_copy", "1": "transition", "2": "transition_first"}.get(mode, "transition")
     for pat, name in (("k_mask_step", "mask_step"), ("k_env_step", "env_step"), ("k_rolling_window", "rolling_window"),
                       ("k_rolling_step", "rolling_step"), ("k_macs2d_step", "macs_step"), ("k_macs3d_step", "macs_step"),
+                      ("k_big_wave_episode", "episode"), ("k_big_wave_step", "env_step"), ("k_macs2d_wave_step", "macs_step"),
+                      ("k_macs3d_wave_step", "macs_step"),
                       ("k_episode", "episode"), ("k_dyn_bits", "dyn_bits")):
         if pat in k:
             return name

@@ -1,6 +1,7 @@
 """Randomised parity sweep of the rolling-window path on the GPU: random (D, N, window, container width) --
 windows of 2 .. 24 nodes over 4 .. 64 blocks (wave-per-instance kernels: closed-form, half-closed and emulated
-CPython-set orders; thread-level set order above 18 nodes) and up to 200 blocks (thread-per-instance path) --
+CPython-set orders; thread-level set order above 18 nodes) and up to 330 blocks (NW-word graphs on one wavefront up to
+256 blocks with windows of at most 64 / NW nodes, the thread-per-instance path otherwise) --
 every window tensor, node list, initial mask and the final packing of a slice of the instances against the
 CPU oracle (generate.InitialContainer + tools.Container restatements), fused and two-launch forms.
 
@@ -18,7 +19,7 @@ DEV = "cuda:0"
 
 def one(D, N, child, W, B, seed, fused):
     rs = np.random.RandomState(seed)
-    init = [W, 6 * N + 10] if D == 2 else [W, W, 6 * N + 10]
+    init = [W, min(6 * N + 10, 4000)] if D == 2 else [W, W, min(6 * N + 10, 4000)]
     hi = min(5, W + 1)
     blocks = torch.as_tensor(rs.randint(1, hi, size=(B, N, D)).astype(np.int32), device=DEV)
     positions, _, _ = gen.pack_blocks(blocks, init, 'C+P+S-lb-soft')
@@ -28,7 +29,7 @@ def one(D, N, child, W, B, seed, fused):
     def policy(step, static, dynamic, current_mask, **_):
         seen[step] = (static.cpu().numpy(), dynamic.cpu().numpy(), current_mask.cpu().numpy())
         return torch.multinomial(current_mask, 1, generator=g).squeeze(1)
-    H = 4 * N + 10
+    H = min(4 * N + 10, 4000)
     out = T.run_rolling_episode(blocks, positions, init, policy, 5, H, child_graph_size=child, fused=fused)
     out["env"].check(); out["windows"].check()
     tour = out["tour_idx"].cpu().numpy(); picked = out["nodes"].cpu().numpy()
@@ -63,7 +64,7 @@ for k in range(n_cfg):
     D = int(rs.choice([2, 3]))
     big = rs.rand() < 0.15
     child = int(rs.randint(2, 25)) if not big else int(rs.randint(2, 40))
-    N = int(rs.randint(child + 1, 65)) if not big else int(rs.randint(max(65, child + 1), 200))
+    N = int(rs.randint(child + 1, 65)) if not big else int(rs.randint(max(65, child + 1), 330))    # round 5: up to 256 on one wavefront, thread-per-instance above
     W = int(rs.randint(4, 9))
     B = 48 if not big else 16
     fused = bool(rs.rand() < 0.6)

@@ -459,23 +459,34 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
     big_wave_step_body<HARD>(a, env, lane, big_lds + (size_t)wave * a.d.W * a.d.L * (HARD ? 4 : 1), 0, nullptr);
 }
 
-// ---- the whole decoding step in ONE launch (round 5): a container's wavefront first runs update_dynamic + update_mask
-// of its own precedence slab on the bit shadow (tap_transition.h: trans_stream_wave; inputs in one round trip, the
-// write-through stores drain while the placement runs), then the placement above.  MODE 1: on the bit shadow; 2: the
-// episode's first step (shadow built in the launch).  Round 4 ran these shapes as a mask launch + a placement launch
-// (+ reset / calc_ratio launches at the ends of an episode).  Stream waves of their own beside the placement waves, as
-// in k_transition, were measured first: they occupy wave slots at this kernel's register count (141 VGPRs: 12 slots per
-// CU), so a CU held 8 placement waves instead of 12 -- 19.5 us per step at 10 x 10 x 50, B = 4 096.
+// ---- the whole decoding step in ONE launch (round 5): a workgroup = PW placement wavefronts (one container each, as
+// above) + ceil(PW / 2) stream waves running update_dynamic + update_mask of the same containers on the bit shadow
+// (tap_transition.h: trans_stream_wave), side by side as in k_transition -- the two kinds exchange nothing, so there is
+// no barrier.  MODE 1: on the bit shadow; 2: the episode's first step (shadow built in the launch).  Round 4 ran these
+// shapes as a mask launch + a placement launch (+ reset / calc_ratio launches at the ends of an episode): 10 x 10 x 50,
+// B = 4 096, graph-replayed step 19.5 us (c7).  Measured against it: the container's own wavefront running its slab
+// first and then the placement (no stream waves: 12 instead of 8 placement waves per CU at this kernel's 141 VGPRs)
+// -- 25.0 us: the placement is short enough here that the serial slab shows; the MACS forms (macs_big.hip,
+// macs3_big.hip), whose placements last 40 .. 150 us, are built that way.
 template <bool HARD, int NC, int MODE>
-__global__ void __launch_bounds__(TAP_BLOCK) k_big_transition(TransArgs a, int PW)
+__global__ void __launch_bounds__(384) k_big_transition(TransArgs a, int PW)
 {
     extern __shared__ int32_t big_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int cells = a.s.d.W * a.s.d.L, tile = cells * (HARD ? 4 : 1);
-    const int env = blockIdx.x * PW + wave;
-    if (env >= a.s.d.B) return;                                                   // wave-uniform
-    trans_stream_wave<1, NC, MODE>(a.m, env, lane, reinterpret_cast<float *>(big_lds + (size_t)PW * tile) + (size_t)wave * 3 * a.m.nR);
-    big_wave_step_body<HARD>(a.s, env, lane, big_lds + (size_t)wave * tile, a.flags, a.ratio_out);
+    const int base = blockIdx.x * PW;
+    if (wave < PW) {
+        const int env = base + wave;
+        if (env >= a.s.d.B) return;                                               // wave-uniform
+        __builtin_amdgcn_s_setprio(2);
+        big_wave_step_body<HARD>(a.s, env, lane, big_lds + (size_t)wave * tile, a.flags, a.ratio_out);
+        return;
+    }
+    const int sw = wave - PW;
+    MaskArgs m = a.m;
+    m.B = min(m.B, base + PW);                                                    // this workgroup's containers only
+    float *slds = reinterpret_cast<float *>(big_lds + (size_t)PW * tile) + (size_t)sw * 2 * 3 * m.nR;
+    trans_stream_wave<2, NC, MODE>(m, base + 2 * sw, lane, slds);
 }
 
 // ---- whole episodes (round 5): tools.calc_positions_lb_greedy (tools.py:2393-2449) for containers above 64 cells ----
@@ -630,7 +641,7 @@ static int big_transition_pw(const tap_ctx *ctx, const tap_env_desc *d, int nR)
     const bool hard = (d->flags & TAP_F_HARD) != 0;
     const size_t tile = (size_t)d->W * d->L * sizeof(int32_t) * (hard ? 4 : 1);
     for (int pw = 4; pw >= 1; pw >>= 1)
-        if ((size_t)pw * tile + (size_t)pw * 3 * nR * sizeof(float) <= tap_lds_limit(ctx)) return pw;
+        if ((size_t)pw * tile + (size_t)((pw + 1) / 2) * 2 * 3 * nR * sizeof(float) <= tap_lds_limit(ctx)) return pw;
     return 0;
 }
 
@@ -643,8 +654,9 @@ int tap_big_transition(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, 
     const int mode = a.m.bits_in ? 1 : 2;
     const bool hard = (d->flags & TAP_F_HARD) != 0;
     const size_t tile = (size_t)d->W * d->L * sizeof(int32_t) * (hard ? 4 : 1);
-    const size_t lds = (size_t)pw * tile + (size_t)pw * 3 * a.m.nR * sizeof(float);
-    const dim3 g((d->B + pw - 1) / pw), blk(64 * pw);
+    const int sw = (pw + 1) / 2;
+    const size_t lds = (size_t)pw * tile + (size_t)sw * 2 * 3 * a.m.nR * sizeof(float);
+    const dim3 g((d->B + pw - 1) / pw), blk(64 * (pw + sw));
     if (g.x == 0) return TAP_OK;
 #define TAP_BT(H_, NC_, M_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_big_transition<H_, NC_, M_>, lds)); \
         hipLaunchKernelGGL((k_big_transition<H_, NC_, M_>), g, blk, lds, st, a, pw); } while (0)
