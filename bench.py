@@ -1091,6 +1091,55 @@ def variants_rolling(cfg, hp, dev, use_graph, trace):
     return out
 
 
+class ActorShapedPolicy(torch.nn.Module):
+    """A stand-in policy with the op count and tensor shapes of the reference's actor at inference (model.py:141-515: 1x1
+    convolutions as encoders of `static`, of the per-step `dynamic` and of the decoder inputs, one GRU step, the
+    attention over the columns, the context read, the pointer energies, the mask added as a log, softmax) at the
+    reference's hidden size 128 -- random weights, written here from that description, not the reference's module.
+    It exists to answer one question: what share of a decoding step is the environment when a network of the actor's
+    size sits between the steps.  Sampling: the Gumbel-max draw of the masked softmax from pre-drawn uniform keys
+    (keys (steps, B, nR), refreshed outside the graph), so an episode with it can be captured in a hipGraph."""
+
+    def __init__(self, D, rows, nR, flen, keys, hidden=128):
+        super().__init__()
+        H = hidden
+        nn = torch.nn
+        self.static_enc = nn.Conv1d(1 + D, H, 1)
+        self.dynamic_enc = nn.Conv1d(rows, H, 1)
+        self.dec_static = nn.Conv1d(D, H // 2, 1)
+        self.dec_dynamic = nn.Linear(flen, H // 2)
+        self.gru = nn.GRUCell(H, H)
+        self.Wa = nn.Parameter(torch.randn(H, 3 * H) * 0.05)
+        self.va = nn.Parameter(torch.randn(1, H) * 0.05)
+        self.Wp = nn.Parameter(torch.randn(H, 4 * H) * 0.05)
+        self.vp = nn.Parameter(torch.randn(1, H) * 0.05)
+        self.keys = keys
+        self.hh = None
+        self.static_hidden = None
+        self.ops_per_step = 24
+
+    @torch.no_grad()
+    def begin(self, static, B):
+        self.static_hidden = self.static_enc(static)                       # once per episode (model.py:282)
+        self.hh = torch.zeros(B, self.gru.hidden_size, device=static.device)
+
+    @torch.no_grad()
+    def forward(self, step, dynamic, current_mask, decoder_static, decoder_dynamic, **_):
+        B = current_mask.shape[0]
+        dh = self.dynamic_enc(dynamic)                                     # (B, H, nR)
+        dec = torch.cat((self.dec_static(decoder_static).squeeze(2),
+                         self.dec_dynamic(decoder_dynamic.reshape(B, -1))), 1)      # (B, H)
+        self.hh = self.gru(dec, self.hh)
+        enc = torch.cat((self.static_hidden, dh), 1)                       # (B, 2H, nR)
+        hid = torch.cat((enc, self.hh.unsqueeze(2).expand(-1, -1, enc.shape[2])), 1)
+        attn = torch.softmax(torch.matmul(self.va, torch.tanh(torch.matmul(self.Wa, hid))), dim=2)    # (B, 1, nR)
+        ctx = torch.bmm(attn, enc.transpose(1, 2)).transpose(1, 2).expand_as(enc)                    # (B, 2H, nR)
+        logits = torch.matmul(self.vp, torch.tanh(torch.matmul(self.Wp, torch.cat((enc, ctx), 1)))).squeeze(1)
+        probs = torch.softmax(logits + current_mask.log(), dim=1)          # model.py:393-395
+        # Gumbel-max: argmax(log p - log(-log u)) is a draw from p; masked columns stay at -inf
+        return torch.argmax(probs.log() - torch.log(-torch.log(self.keys[step])), dim=1)
+
+
 def variants(cfg, args, hp, rank, world, dev, use_graph):
     """Two more readings of the same workload (single GPU, rank 0's line only)."""
     name, D, cs, n, B, reward, strategy = cfg
@@ -1222,6 +1271,62 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
                                                      "selectable columns (uniform over them), 2 torch ops per step")
     except Exception as ex:                                  # pragma: no cover
         out.setdefault("policy_in_loop_graph", dict(error=str(ex)[:300]))
+    # (c2) a network of the reference actor's size between the steps: how much of a decoding step is the environment?
+    try:
+        if "graph" in skip:
+            raise RuntimeError("skipped")
+        trace("actor_shaped_policy")
+        g3 = torch.Generator(device=dev)
+        g3.manual_seed(4244)
+        keys3 = torch.empty(hp.nw, B, st.shape[2], device=dev).uniform_(1e-7, 1.0 - 1e-7, generator=g3)
+        env_a = T.BatchedContainer(B, cs, hp.nw, reward, "diff", packing_strategy=strategy, device=dev)
+        spa = T.EpisodeStepper(st, dy, env_a, steps=hp.nw)
+        flen = int(np.prod(env_a._feature_shape()[1:]))
+        actor = ActorShapedPolicy(D, dy.shape[1], st.shape[2], flen, keys3).to(dev)
+
+        class _Pol(object):                                      # run_episode calls policy(step=..., ...): begin at step 0
+            def __call__(self, step, static, **kw):
+                if step == 0:
+                    actor.begin(static, B)
+                return actor(step, **kw)
+        val_a, rec_a = graphed(_Pol(), lambda: keys3.uniform_(1e-7, 1.0 - 1e-7, generator=g3), spa, steps=50)
+        ok_a = oracle_ok(rec_a)
+        # the same network ops alone, on the stepper's (frozen) views: what the loop costs without the environment
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+
+        def net_only():
+            actor.begin(st, B)
+            for k in range(hp.nw):
+                actor(k, dynamic=spa.dynamic, current_mask=spa._ones_mask, decoder_static=spa.decoder_static,
+                      decoder_dynamic=spa.decoder_dynamic)
+        spa._ones_mask = torch.ones(B, st.shape[2], device=dev)
+        with torch.cuda.stream(side):
+            net_only(); net_only()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        gn = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gn):
+            net_only()
+        for _ in range(3):
+            gn.replay()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(50):
+            gn.replay()
+        torch.cuda.synchronize(dev)
+        net_us = (time.perf_counter() - t0) / (50 * hp.nw) * 1e6
+        step_us = B / val_a * 1e6
+        out["actor_shaped_policy_graph"] = dict(
+            value=val_a, unit="env-steps/s", steps=50, verified=ok_a, us_per_decoding_step=step_us,
+            network_only_us_per_step=net_us, env_share=max(0.0, 1.0 - net_us / step_us),
+            what="rollout.run_episode captured in one hipGraph with ActorShapedPolicy between the fused steps: the op "
+                 "count and shapes of the reference's actor at inference (1x1-conv encoders, one GRU step, attention over "
+                 "the nR columns, context, pointer energies, masked softmax; hidden 128, random weights) and a Gumbel-max "
+                 "draw from pre-drawn keys; network_only = the same ops without the environment's launch; env_share = "
+                 "1 - network_only / step (BASELINE.md section 2 measured 38 % for the reference's CPU loop)")
+    except Exception as ex:                                  # pragma: no cover
+        out["actor_shaped_policy_graph"] = dict(error=str(ex)[:300])
     # (d) what the fp32 contract costs: the same graph-captured episode (recorded tour, no policy ops) on a stepper that
     #     writes update_dynamic's result as the fp32 tensor model.py:378 feeds the encoder, and on one that keeps it as
     #     its bit shadow only (tap_stepper_buffers.dyn = NULL) -- masks, placements, features and ratio are the same

@@ -461,12 +461,16 @@ typedef struct tap_stepper_buffers {
     int32_t *nonbinary;          /* device int32, nullable, caller zeroes it: see tap_mask_step_first */
     int32_t tour_stride;         /* 0 = steps */
     int32_t tour_col0;           /* first tour column this stepper writes (a rolling episode's last window: N - child) */
+    float *colsum[2];            /* (B, 3, nR), only for windows WITHOUT a bit shadow (nR % 4 != 0, nR > 256 or rows > 128;
+                                    NULL otherwise): the column-sum shadow of dyn[w]; the step is then tap_transition's
+                                    fp32-copy form, dyn[] is required and bits[] is unused */
 } tap_stepper_buffers;
 
 /* d / state: the containers (tap_env_desc_init, a blob of tap_env_state_bytes); n, R, rows, update_rows,
  * static_rows as in tap_transition_bits; steps = decoding steps per episode (model.py:342: blocks_num).
- * TAP_E_UNSUPPORTED when the window has no bit shadow (nR % 4 != 0, nR > 256, rows > 128): drive those shapes
- * with tap_transition. */
+ * Windows without a bit shadow (nR % 4 != 0, nR > 256, rows > 128) run tap_transition's fp32-copy form behind the same
+ * three calls (buf->colsum; tap_stepper_begin then always makes its two small launches; tap_stepper_begin_shadow is
+ * TAP_E_UNSUPPORTED there). */
 int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
                        int update_rows, int static_rows, int steps, const tap_stepper_buffers *buf,
                        tap_stepper **out);

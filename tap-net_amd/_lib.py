@@ -39,7 +39,7 @@ class StepperBuffers(C.Structure):
     """tapenv.h: tap_stepper_buffers"""
     _fields_ = [("bits", _vp_t * 2), ("dyn", _vp_t * 2), ("current", _vp_t * 2), ("mask", _vp_t * 2),
                 ("feature", _vp_t), ("decoder_static", _vp_t), ("ratio", _vp_t), ("tour", _vp_t), ("nonbinary", _vp_t),
-                ("tour_stride", C.c_int32), ("tour_col0", C.c_int32)]
+                ("tour_stride", C.c_int32), ("tour_col0", C.c_int32), ("colsum", _vp_t * 2)]
 
 
 class RollerBuffers(C.Structure):

@@ -22,11 +22,20 @@ struct BigCtx {
 __device__ static void big_scan(const BigCtx &c, int x, int y, int bx, int by, int &mx, u64 &eq, int &sum)
 {
     mx = -1; eq = 0; sum = 0;
+    if ((c.D == 2 && bx > 64) || (c.D == 3 && (bx > 8 || by > 8))) {             // beyond the support mask (the block's sides are the
+        for (int i = 0; i < bx; ++i)                                              // same on every lane): maximum and sum only, the
+            for (int j = 0; j < by; ++j) {                                        // stability test reads the map again (big_stable)
+                const int h = c.hm[(x + i) * c.L + y + j];
+                sum += h;
+                mx = max(mx, h);
+            }
+        return;
+    }
     for (int i = 0; i < bx; ++i)
         for (int j = 0; j < by; ++j) {
             const int h = c.hm[(x + i) * c.L + y + j];
             sum += h;
-            const u64 bit = c.D == 2 ? (i < 64 ? 1ull << i : 0ull) : ((i < 8 && j < 8) ? 1ull << (i * 8 + j) : 0ull);   // wider: big_stable
+            const u64 bit = 1ull << (c.D == 2 ? i : i * 8 + j);
             if (h > mx) { mx = h; eq = bit; }
             else if (h == mx) eq |= bit;
         }

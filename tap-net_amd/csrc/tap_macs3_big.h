@@ -291,7 +291,7 @@ M3B_HD inline M3BResult m3b_place(M3BState &s, int *cnt, int &err, int bx, int b
             }
         }
         if (t < H) {                                                               // :2909 on top
-            m3b_u64 tt[8];                                                         // footprint rows of the top level (yy <= 8)
+            m3b_u64 tt[TAP_WIDE_MAX_SIDE];                                         // footprint rows of the top level (yy <= 16)
             bool full = true;
             for (int j = 0; j < yy; ++j) { tt[j] = m3b_rowT(s, t, y + j); full = full && (tt[j] & spanx) == spanx; }
             if (full) {                                                            // :2911-2913

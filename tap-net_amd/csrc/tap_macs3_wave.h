@@ -283,7 +283,9 @@ __device__ inline M3BResult m3w_place(const M3WTile &s, int *cnt, int &err, int 
             }
         }
         if (t < H) {                                                               // :2909 on top
-            m3b_u64 tt[8];                                                         // footprint rows of the top level (yy <= 8)
+            m3b_u64 *tt = s.rows;                                                  // footprint rows of the top level (yy <= 16), in the wave's LDS
+                                                                                   // scratch (free in this phase; every lane writes the same words and
+                                                                                   // reads back what it wrote: 16 words in registers cost a wave per SIMD)
             bool full = true;
             for (int j = 0; j < yy; ++j) { tt[j] = m3w_rowT(s, t, y + j, lane); full = full && (tt[j] & spanx) == spanx; }
             if (full) {                                                            // :2911-2913

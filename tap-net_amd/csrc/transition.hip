@@ -248,17 +248,17 @@ static int transition_common(tap_ctx *ctx, const tap_env_desc *d, void *state, i
     return TAP_OK;
 }
 
-extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
-                              int update_rows, const float *dyn_in, const float *static_,
-                              int static_rows, const int64_t *ptr, const float *mask_in,
-                              const float *colsum_in, float *dyn_out, float *colsum_out,
-                              float *current_out, float *mask_out, float *feature_out,
-                              float *ratio_out, int flags, void *stream)
+static int transition_copy_impl(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                                int update_rows, const float *dyn_in, const float *static_,
+                                int static_rows, const int64_t *ptr, const float *mask_in,
+                                const float *colsum_in, float *dyn_out, float *colsum_out,
+                                float *current_out, float *mask_out, float *feature_out,
+                                float *ratio_out, int flags, void *stream, const StepAux *aux)
 {
     if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     TransArgs a = {};
     int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
-                               current_out, mask_out, feature_out, ratio_out, flags, a);
+                               current_out, mask_out, feature_out, ratio_out, flags, a, aux);
     if (rc) return rc;
     if (!dyn_in || !colsum_in || !dyn_out || !colsum_out)
         return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
@@ -272,6 +272,18 @@ extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, 
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, dyn_in, dyn_out, static_, ptr,
                    mask_in, colsum_in, colsum_out, current_out, mask_out, nullptr, nullptr});
     return transition_dispatch(ctx, d, a, stream);
+}
+
+extern "C" int tap_transition(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
+                              int update_rows, const float *dyn_in, const float *static_,
+                              int static_rows, const int64_t *ptr, const float *mask_in,
+                              const float *colsum_in, float *dyn_out, float *colsum_out,
+                              float *current_out, float *mask_out, float *feature_out,
+                              float *ratio_out, int flags, void *stream)
+{
+    if (d && d->B > 0 && !mask_in) return tap_fail(ctx, TAP_E_INVALID, "bad transition arguments");
+    return transition_copy_impl(ctx, d, state, n, R, rows, update_rows, dyn_in, static_, static_rows, ptr, mask_in, colsum_in,
+                                dyn_out, colsum_out, current_out, mask_out, feature_out, ratio_out, flags, stream, nullptr);
 }
 
 static int transition_bits_impl(tap_ctx *ctx, const tap_env_desc *d, void *state, int n, int R, int rows,
@@ -393,6 +405,7 @@ struct tap_stepper {
     const float *mask0;                 // the mask step 0 starts from (null = ones)
     int k;                              // index of the next step
     int keep;                           // TAP_SB_CONTINUE: step 0 does not start from a fresh container
+    int copy_form;                      // the window has no bit shadow: `dynamic` is carried as the fp32 tensor + column sums
 };
 
 struct DeviceGuard { // the launches must be issued with the context's device current (callers may sit on another one)
@@ -416,28 +429,34 @@ extern "C" int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *sta
         return tap_fail(ctx, TAP_E_INVALID, "bad stepper arguments");
     if (d->B > 0) {                                  // an empty batch has no buffers to check
         if (!state) return tap_fail(ctx, TAP_E_INVALID, "bad stepper arguments");
+        const bool shadow = n * R % 4 == 0 && n * R <= 256 && rows <= 128;
         for (int w = 0; w < 2; ++w)
-            if (!buf->bits[w] || !buf->current[w] || !buf->mask[w])
+            if ((shadow && !buf->bits[w]) || !buf->current[w] || !buf->mask[w])
                 return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of bits / current / mask");
+        if (!shadow) {
+            // a window beyond the bit shadow (nR % 4 != 0, nR > 256 or rows > 128): the step is tap_transition's fp32-copy
+            // form on the column-sum shadow -- both phases of dyn and of colsum (B, 3, nR) are required
+            if (!buf->dyn[0] || !buf->dyn[1] || !buf->colsum[0] || !buf->colsum[1] || buf->colsum[0] == buf->colsum[1])
+                return tap_fail(ctx, TAP_E_INVALID, "a stepper for a window without a bit shadow needs both phases of dyn and colsum");
+        }
         // dyn: both phases, or neither -- a caller whose encoder consumes the bit shadow skips the fp32 expansion of
         // update_dynamic's result (78 % of a c2 step's bytes); masks, placements and ratio do not depend on it
         if ((buf->dyn[0] == nullptr) != (buf->dyn[1] == nullptr))
             return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of dyn, or neither (no fp32 expansion)");
-        if (buf->bits[0] == buf->bits[1] || (buf->dyn[0] && buf->dyn[0] == buf->dyn[1]) || buf->current[0] == buf->current[1] ||
+        if ((shadow && buf->bits[0] == buf->bits[1]) || (buf->dyn[0] && buf->dyn[0] == buf->dyn[1]) || buf->current[0] == buf->current[1] ||
             buf->mask[0] == buf->mask[1] || !buf->ratio)
             return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers and ratio is required");
     }
     const int nR = n * R;
     if (buf->tour_stride < 0 || buf->tour_col0 < 0 || (buf->tour_stride > 0 && buf->tour_col0 + steps > buf->tour_stride))
         return tap_fail(ctx, TAP_E_INVALID, "stepper tour columns [col0, col0 + steps) must fit tour_stride");
-    if (nR % 4 != 0 || nR > 256 || rows > 128)
-        return tap_fail(ctx, TAP_E_UNSUPPORTED, "the stepper carries `dynamic` as its bit shadow: nR %% 4 == 0, nR <= 256, rows <= 128");
     tap_stepper *s = new (std::nothrow) tap_stepper();
     if (!s) return tap_fail(ctx, TAP_E_INVALID, "out of host memory");
     s->ctx = ctx; s->d = *d; s->state = state;
     s->n = n; s->R = R; s->rows = rows; s->update_rows = update_rows; s->static_rows = static_rows; s->steps = steps;
     s->b = *buf;
     s->static_ = nullptr; s->dyn_in = nullptr; s->bits0 = nullptr; s->mask0 = nullptr; s->k = 0; s->keep = 0;
+    s->copy_form = (nR % 4 != 0 || nR > 256 || rows > 128) ? 1 : 0;
     *out = s;
     return TAP_OK;
 }
@@ -455,6 +474,20 @@ extern "C" int tap_stepper_begin(tap_stepper *s, const float *static_, const flo
     s->mask0 = nullptr;
     s->k = 0;
     s->keep = (flags & TAP_SB_CONTINUE) != 0;
+    if (s->copy_form && s->d.B > 0) {
+        // no bit shadow: the column sums of the fresh tensor and the masks DRL.forward starts from (model.py:297-307;
+        // mask = ones) into phase 1, which step 0 reads -- two small launches, with or without TAP_SB_INITIAL_MASK
+        DeviceGuard g(s->ctx->device);
+        int rc = tap_dyn_colsum(s->ctx, s->d.B, s->n, s->n * s->R, s->rows, dyn_in, s->b.colsum[1], stream);
+        // the incremental column sums are exact for 0/1 tensors only: count the other elements like the shadow builders do
+        if (rc == TAP_OK && s->b.nonbinary)
+            rc = tap_dyn_bits(s->ctx, s->d.B, s->n * s->R, s->rows, dyn_in, nullptr, s->b.nonbinary, stream);
+        if (rc == TAP_OK)
+            rc = tap_update_mask(s->ctx, s->d.B, s->n, s->R, nullptr, s->b.colsum[1], nullptr, s->b.current[1], s->b.mask[1], stream);
+        if (rc != TAP_OK) { s->static_ = nullptr; return rc; }
+        s->mask0 = s->b.mask[1];
+        return TAP_OK;
+    }
     if (!(flags & TAP_SB_INITIAL_MASK) || s->d.B == 0) return TAP_OK;
     // shadow + the masks DRL.forward starts from (model.py:297-307) in one launch that reads the tensor once; they
     // land in phase 1, which step 0 (writing phase 0) reads
@@ -470,6 +503,7 @@ extern "C" int tap_stepper_begin(tap_stepper *s, const float *static_, const flo
 extern "C" int tap_stepper_begin_shadow(tap_stepper *s, const float *static_, const unsigned long long *bits, int flags)
 {
     if (!s) return TAP_E_INVALID;
+    if (s->copy_form) return tap_fail(s->ctx, TAP_E_UNSUPPORTED, "this window has no bit shadow: begin with tap_stepper_begin");
     if (s->d.B > 0 && (!static_ || !bits || bits == s->b.bits[0]))
         return tap_fail(s->ctx, TAP_E_INVALID, "stepper_begin_shadow needs static and a shadow that is not phase 0's buffer");
     if (s->d.B == 0) static_ = reinterpret_cast<const float *>(s);
@@ -493,7 +527,12 @@ extern "C" int tap_stepper_step(tap_stepper *s, const int64_t *ptr, void *stream
     const StepAux aux = {s->b.decoder_static, s->b.tour, s->b.tour_stride > 0 ? s->b.tour_stride : s->steps, s->b.tour_col0 + k};
     DeviceGuard g(s->ctx->device);
     int rc;
-    if (k == 0 && !s->bits0)
+    if (s->copy_form)
+        rc = transition_copy_impl(s->ctx, &s->d, s->state, s->n, s->R, s->rows, s->update_rows, k == 0 ? s->dyn_in : s->b.dyn[r],
+                                  s->static_, s->static_rows, ptr, k == 0 ? s->mask0 : s->b.mask[r], s->b.colsum[k == 0 ? 1 : r],
+                                  s->b.dyn[w], s->b.colsum[w], s->b.current[w], s->b.mask[w], s->b.feature, s->b.ratio, flags,
+                                  stream, &aux);
+    else if (k == 0 && !s->bits0)
         rc = transition_first_impl(s->ctx, &s->d, s->state, s->n, s->R, s->rows, s->update_rows, s->dyn_in, s->static_,
                                    s->static_rows, ptr, nullptr, s->b.bits[w], s->b.dyn[w], s->b.current[w], s->b.mask[w],
                                    s->b.feature, s->b.ratio, s->b.nonbinary, flags, stream, &aux);

@@ -491,8 +491,11 @@ class EpisodeStepper(object):
         self.static_rows = int(static.shape[1])
         self.update_rows = _UPDATE_ROWS[input_type]
         self.steps = self.n if steps is None else int(steps)
-        if not bits_supported(self.rows, self.nR):
-            raise ValueError("EpisodeStepper needs a window with a bit shadow (rows <= 128, nR % 4 == 0, nR <= 256)")
+        # windows without a bit shadow (rows > 128, nR % 4 != 0, nR > 256) run tap_transition's fp32-copy form on the
+        # column-sum shadow behind the same three calls
+        self._copy = not bits_supported(self.rows, self.nR)
+        if self._copy and not expand_dynamic:
+            raise ValueError("expand_dynamic=False needs a window with a bit shadow (rows <= 128, nR % 4 == 0, nR <= 256)")
         if env.batch_size != self.B or env.block_dim != self.block_dim:
             raise ValueError("container batch / dimension does not match the instance tensors")
         self.env = env
@@ -501,7 +504,8 @@ class EpisodeStepper(object):
         f32 = dict(dtype=torch.float32, device=dev)
         D = self.block_dim
         words = _bit_planes(self.rows) * self.nR
-        self._bits = [torch.empty(self.B, words, dtype=torch.int64, device=dev) for _ in range(2)]
+        self._bits = [torch.empty(self.B, words, dtype=torch.int64, device=dev) if not self._copy else None for _ in range(2)]
+        self._colsum = [torch.empty(self.B, 3, self.nR, **f32) if self._copy else None for _ in range(2)]
         # expand_dynamic=False: update_dynamic's result stays in its bit shadow (``dynamic_bits``) and the fp32 tensor
         # of model.py:378 is not written -- 78 % of a c2 step's bytes; ``dynamic`` is then None after a step
         self.expand_dynamic = bool(expand_dynamic)
@@ -530,7 +534,9 @@ class EpisodeStepper(object):
         _steppers.add(self)
         buf = _lib.StepperBuffers()
         for w in range(2):
-            buf.bits[w], buf.dyn[w] = self._bits[w].data_ptr(), (self._dyn[w].data_ptr() if expand_dynamic else None)
+            buf.bits[w] = self._bits[w].data_ptr() if not self._copy else None
+            buf.dyn[w] = self._dyn[w].data_ptr() if expand_dynamic else None
+            buf.colsum[w] = self._colsum[w].data_ptr() if self._copy else None
             buf.current[w], buf.mask[w] = self._cur[w].data_ptr(), self._mask[w].data_ptr()
         buf.feature, buf.decoder_static = self.decoder_dynamic.data_ptr(), self.decoder_static.data_ptr()
         buf.ratio = self.ratio.data_ptr()
@@ -550,6 +556,7 @@ class EpisodeStepper(object):
         self._ones = None
         self.static = self.dynamic = self.current_mask = self.mask = self.dynamic_bits = None
         self.k = 0
+        self._count_in_step0 = False
 
     def __del__(self):
         h, self._h = getattr(self, '_h', None), None
@@ -580,8 +587,13 @@ class EpisodeStepper(object):
         if rc:
             _lib.check(rc, self._ctx)
         self.static, self.dynamic, self.k = static, dynamic, 0
+        self._count_in_step0 = not initial_mask and not self._copy
         self._dec.zero_()
-        if initial_mask:
+        if self._copy:                                        # begin always makes its launches there: masks and the count exist
+            self.current_mask, self.mask = self._cur[1], self._mask[1]
+            if _binary_mode == 'check':
+                self._raise_nonbinary()
+        elif initial_mask:
             self.current_mask, self.mask = self._cur[1], self._mask[1]
             if _binary_mode == 'check':
                 self._raise_nonbinary()
@@ -593,6 +605,8 @@ class EpisodeStepper(object):
         """The same for a window whose bit shadow the caller holds (rolling windows emit it next to the tensor):
         no launch; ``dynamic`` / ``current_mask`` are only recorded as the values before step 0."""
         self._check_instances(static, "static", (self.B, self.static_rows, self.nR))
+        if self._copy:
+            raise ValueError("this window has no bit shadow: begin(static, dynamic)")
         if bits.dtype is not torch.int64 or not bits.is_contiguous() or bits.device != self._dev or \
                 bits.numel() != self._bits[0].numel():
             raise ValueError("bits must be the (B, %d) int64 shadow of the window" % (self._bits[0].shape[1],))
@@ -601,6 +615,7 @@ class EpisodeStepper(object):
             _lib.check(rc, self._ctx)
         if self._ones is None:
             self._ones = torch.ones(self.B, self.nR, dtype=torch.float32, device=self._dev)
+        self._count_in_step0 = False                      # the caller's shadow: nothing is counted
         self.static, self.dynamic, self.k, self._bits0 = static, dynamic, 0, bits
         self.current_mask, self.mask = current_mask, self._ones
         return self
@@ -620,6 +635,10 @@ class EpisodeStepper(object):
         self.k += 1
         self.dynamic, self.current_mask, self.mask = self._views[w]
         self.dynamic_bits = self._bits[w]
+        if self.k == 1 and self._count_in_step0 and _binary_mode == 'check':
+            # begin(initial_mask=False) made no launch: step 0 built the shadow and counted the elements that are neither
+            # 0 nor 1 -- under 'check' that count is read here (one host sync per episode, as begin() does otherwise)
+            self._raise_nonbinary()
         return w
 
     def _raise_nonbinary(self):

@@ -30,13 +30,19 @@ class RandomFeasiblePolicy(object):
     """Uniformly random selectable column of ``current_mask``: an exponential race -- the column with the smallest
     Exp(1) draw among the selectable ones, argmax(mask / q) -- which is what torch.multinomial(mask, 1) computes
     after its input checks (three torch ops on buffers the policy keeps, instead of ~85 us of host per
-    torch.multinomial call on this stack)."""
+    torch.multinomial call on this stack).  Where NO column is selectable argmax returns column 0 (torch.multinomial
+    raises there): ``strict=True`` checks for that, at one host sync per call; a recorded run checks the tour against
+    the masks afterwards (tests), a trainer's episodes end before the mask empties."""
 
-    def __init__(self, generator=None):
+    def __init__(self, generator=None, strict=False):
         self.generator = generator
+        self.strict = strict          # True: raise when an env has no selectable column, as torch.multinomial does (one host sync per call)
         self._q = self._r = None
 
     def __call__(self, step, current_mask, **_):
+        if self.strict and not bool((current_mask.sum(1) > 0).all()):
+            raise RuntimeError("RandomFeasiblePolicy: an env has no selectable column (current_mask is all zero there); "
+                               "argmax would return column 0")
         if self._q is None or self._q.shape != current_mask.shape or self._q.device != current_mask.device:
             self._q = torch.empty_like(current_mask)
             self._r = torch.empty_like(current_mask)
@@ -119,7 +125,7 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     tour_idx (B, steps), reward = -scores (B,) fp32 (model.py:515), env, and with ``record`` the per-step features /
     masks.  ``bits``: carry ``dynamic`` as its bit shadow between the steps, None = when possible.
 
-    The fused loop runs on a ``pack.EpisodeStepper`` whenever the window has a bit shadow: between two calls of the
+    The fused loop runs on a ``pack.EpisodeStepper`` (windows without a bit shadow: on its fp32-copy form): between two calls of the
     policy the host makes ONE C call and issues no torch op (the step's launch also writes ``decoder_static`` and
     the tour column).  ``stepper``: a stepper to re-use across episodes (a trainer builds one per run: nothing is
     allocated per episode; the returned tensors are then views of its buffers, valid until its next ``begin``);
@@ -134,8 +140,10 @@ def run_episode(static, dynamic, policy, container_width, container_height,
     B, D = int(static.shape[0]), block_dim
     nsteps = n if steps is None else steps
     dev = _lib.resolve_device(static.device)
+    # (windows without a bit shadow -- rows > 128, nR % 4 != 0, nR > 256 -- run on the stepper too since round 5: its
+    #  fp32-copy form; ``bits=True`` still asks for the shadow and fails there)
     if stepper is not None or (fused and bits is not False and not isinstance(bits, torch.Tensor) and
-                               bits_supported(int(dynamic.shape[1]), int(dynamic.shape[2]))):
+                               (bits is None or bits_supported(int(dynamic.shape[1]), int(dynamic.shape[2])))):
         try:
             return _run_episode_stepper(static, dynamic, policy, container_width, container_height, reward_type,
                                         heightmap_type, packing_strategy, input_type, allow_rot, env, record, nsteps,
