@@ -41,6 +41,13 @@ __device__ static void big_scan(const BigCtx &c, int x, int y, int bx, int by, i
         }
 }
 
+// the wide form out of line: inlined into the candidate loops it would sit in every wave's instruction stream although
+// block sides above 8 are rare
+__device__ __attribute__((noinline)) static int big_stable_wide(const int32_t *hm, int L, int x, int y, int bx, int by, int mx)
+{
+    return tap_stable3d_wide([&](int i, int j) { return hm[(x + i) * L + y + j]; }, bx, by, mx);
+}
+
 // tools.is_stable_2d / is_stable of a footprint resting at level z = mx > 0 (eq: big_scan's support mask).  Beyond the
 // masks' reach -- 2D blocks wider than 64, 3D sides of 9 .. 16 -- the height-map is read again (tap_stable_wide.h)
 __device__ static int big_stable(const BigCtx &c, int x, int y, int bx, int by, int mx, u64 eq)
@@ -52,7 +59,9 @@ __device__ static int big_stable(const BigCtx &c, int x, int y, int bx, int by, 
         while (trail < bx && c.hm[(x + bx - 1 - trail) * c.L + y] != mx) ++trail;
         return (2 * lead < bx) && (2 * trail < bx);
     }
-    if (bx > 8 || by > 8) return tap_stable3d_wide([&](int i, int j) { return c.hm[(x + i) * c.L + y + j]; }, bx, by, mx);
+#ifndef TAP_AB_NO_WIDE_STABLE
+    if (bx > 8 || by > 8) return big_stable_wide(c.hm, c.L, x, y, bx, by, mx);
+#endif
     return tap_stable3d_any(c.lut, bx, by, eq);
 }
 
