@@ -11,6 +11,16 @@
 #include "tap_masks.h"
 #include "tap_transition.h"
 
+// Register budget of the wave-per-container kernels.  The common placement (footprints within the support masks) needs
+// 67 .. 83 VGPRs; the instantiation for wide footprints (tap_stable_wide.h: per-row extremes in 64-bit words inside the
+// candidate loop) 131 .. 149 -- and a kernel is allocated the maximum over its paths, whether a wave takes them or not:
+// with the wide code compiled in, the 10 x 10 step ran at 3 instead of 6 waves per SIMD, 22.9 against 19.8 us (c7,
+// same-source A/B, round 5).  Holding the kernels to 5 waves per SIMD (96 VGPRs) leaves the common path unspilled and
+// makes the rare wide path spill instead.
+#ifndef TAP_BIG_REGS
+#define TAP_BIG_REGS __attribute__((amdgpu_waves_per_eu(5, 8)))
+#endif
+
 struct BigCtx {
     int D, W, L, H, flags;
     const uint32_t *lut;
@@ -19,12 +29,26 @@ struct BigCtx {
 };
 
 // max / support mask / sum over a footprint
+// WIDE: the footprint is beyond the support mask (2D: wider than 64; 3D: a side above 8) -- maximum and sum only, the
+// stability test reads the map again (big_stable).  A block's sides are the same on every lane of its container's
+// wavefront, so the callers pick the instantiation once per placement: compiled into the common path (even out of line)
+// the wide form cost the 10 x 10 step 15 % (c7: 23.1 against 20.1 us, round 5).
+__device__ __forceinline__ bool big_is_wide(int D, int bx, int by)
+{
+#ifdef TAP_AB_NO_WIDE_STABLE      // A/B builds: the wide instantiation compiled out (wide blocks then get wrong stability flags)
+    return false;
+#else
+    return D == 2 ? bx > 64 : (bx > 8 || by > 8);
+#endif
+}
+
+template <bool WIDE>
 __device__ static void big_scan(const BigCtx &c, int x, int y, int bx, int by, int &mx, u64 &eq, int &sum)
 {
     mx = -1; eq = 0; sum = 0;
-    if ((c.D == 2 && bx > 64) || (c.D == 3 && (bx > 8 || by > 8))) {             // beyond the support mask (the block's sides are the
-        for (int i = 0; i < bx; ++i)                                              // same on every lane): maximum and sum only, the
-            for (int j = 0; j < by; ++j) {                                        // stability test reads the map again (big_stable)
+    if constexpr (WIDE) {
+        for (int i = 0; i < bx; ++i)
+            for (int j = 0; j < by; ++j) {
                 const int h = c.hm[(x + i) * c.L + y + j];
                 sum += h;
                 mx = max(mx, h);
@@ -41,28 +65,28 @@ __device__ static void big_scan(const BigCtx &c, int x, int y, int bx, int by, i
         }
 }
 
-// the wide form out of line: inlined into the candidate loops it would sit in every wave's instruction stream although
-// block sides above 8 are rare
-__device__ __attribute__((noinline)) static int big_stable_wide(const int32_t *hm, int L, int x, int y, int bx, int by, int mx)
+// the wide form out of line
+__device__ __forceinline__ int big_stable_wide(const int32_t *hm, int L, int x, int y, int bx, int by, int mx)
 {
     return tap_stable3d_wide([&](int i, int j) { return hm[(x + i) * L + y + j]; }, bx, by, mx);
 }
 
 // tools.is_stable_2d / is_stable of a footprint resting at level z = mx > 0 (eq: big_scan's support mask).  Beyond the
 // masks' reach -- 2D blocks wider than 64, 3D sides of 9 .. 16 -- the height-map is read again (tap_stable_wide.h)
-__device__ static int big_stable(const BigCtx &c, int x, int y, int bx, int by, int mx, u64 eq)
+template <bool WIDE>
+__device__ __forceinline__ int big_stable(const BigCtx &c, int x, int y, int bx, int by, int mx, u64 eq)
 {
-    if (c.D == 2) {
-        if (bx <= 64) return tap_stable2d(bx, eq);
-        int lead = 0, trail = 0;                                                 // tools.py:839-868: leading / trailing unsupported columns
-        while (lead < bx && c.hm[(x + lead) * c.L + y] != mx) ++lead;
-        while (trail < bx && c.hm[(x + bx - 1 - trail) * c.L + y] != mx) ++trail;
-        return (2 * lead < bx) && (2 * trail < bx);
+    if constexpr (WIDE) {
+        if (c.D == 2) {
+            int lead = 0, trail = 0;                                             // tools.py:839-868: leading / trailing unsupported columns
+            while (lead < bx && c.hm[(x + lead) * c.L + y] != mx) ++lead;
+            while (trail < bx && c.hm[(x + bx - 1 - trail) * c.L + y] != mx) ++trail;
+            return (2 * lead < bx) && (2 * trail < bx);
+        }
+        return big_stable_wide(c.hm, c.L, x, y, bx, by, mx);
+    } else {
+        return c.D == 2 ? tap_stable2d(bx, eq) : tap_stable3d_any(c.lut, bx, by, eq);
     }
-#ifndef TAP_AB_NO_WIDE_STABLE
-    if (bx > 8 || by > 8) return big_stable_wide(c.hm, c.L, x, y, bx, by, mx);
-#endif
-    return tap_stable3d_any(c.lut, bx, by, eq);
 }
 
 // is cell (x, y) a left-bottom corner, and of which class (tools.py:2067-2078 2D; 2219-2246 3D, appendix B)
@@ -93,7 +117,8 @@ __device__ static long big_key(const BigCtx &c, int x, int y, int z, int cls)
 }
 
 // one placement; the caller advances the step counter.  -> placed?
-__device__ static Placement big_place(const BigCtx &c, Counters &cnt, int &err, int bx, int by, int bz)
+template <bool WIDE>
+__device__ static Placement big_place_t(const BigCtx &c, Counters &cnt, int &err, int bx, int by, int bz)
 {
     const int W = c.W, L = c.L, cells = W * L;
     const bool hard = (c.flags & TAP_F_HARD) != 0;
@@ -114,10 +139,10 @@ __device__ static Placement big_place(const BigCtx &c, Counters &cnt, int &err, 
                 if (c.D == 2 && x + bx > W) { stop2d = true; break; }          // :2076 stops at the first overflow
                 if (x + bx > W || y + by > L) continue;                          // :2255-2256
                 int mx, sum; u64 eq;
-                big_scan(c, x, y, bx, by, mx, eq, sum);
+                big_scan<WIDE>(c, x, y, bx, by, mx, eq, sum);
                 const int z = mx;
                 if (z >= c.H) err |= 1;                                          // :2109 would raise IndexError
-                const int stab = z == 0 ? 1 : big_stable(c, x, y, bx, by, z, eq);
+                const int stab = z == 0 ? 1 : big_stable<WIDE>(c, x, y, bx, by, z, eq);
                 const int emp = cnt.empty + bx * by * z - sum;
                 const double r = tap_score(cfg, cnt, vol, gmax, z, bz, emp, stab);
                 const long key = big_key(c, x, y, z, cls);
@@ -135,7 +160,7 @@ __device__ static Placement big_place(const BigCtx &c, Counters &cnt, int &err, 
                 long k = LONG_MAX;
                 if (!stop2d && big_corner(c, x, y, cls)) {
                     if (c.D == 2 && x + bx > W) stop2d = true;
-                    else if (x + bx <= W && y + by <= L) { int mx, sum; u64 eq; big_scan(c, x, y, bx, by, mx, eq, sum); k = big_key(c, x, y, mx, cls); }
+                    else if (x + bx <= W && y + by <= L) { int mx, sum; u64 eq; big_scan<WIDE>(c, x, y, bx, by, mx, eq, sum); k = big_key(c, x, y, mx, cls); }
                 }
                 c.keys[x * L + y] = k > INT_MAX ? INT_MAX : (int)k;
             }
@@ -159,12 +184,12 @@ __device__ static Placement big_place(const BigCtx &c, Counters &cnt, int &err, 
                     const int sp = _x * L + _y;
                     if ((visited[sp >> 6] >> (sp & 63)) & 1ull) continue;        // :2105
                     int mx, sum; u64 eq;
-                    big_scan(c, _x, _y, bx, by, mx, eq, sum);
+                    big_scan<WIDE>(c, _x, _y, bx, by, mx, eq, sum);
                     if (z > 0 && mx < z) continue;                               // :2106 nothing underneath
                     visited[sp >> 6] |= 1ull << (sp & 63);                       // :2107
                     if (z >= c.H) { err |= 1; continue; }                        // :2109 IndexError
                     if (mx > z) continue;                                        // :2109 not free
-                    const int st = z == 0 ? 1 : big_stable(c, _x, _y, bx, by, z, eq);
+                    const int st = z == 0 ? 1 : big_stable<WIDE>(c, _x, _y, bx, by, z, eq);
                     if (!st) continue;                                           // :2112-2114
                     ok = true; sx = _x; sy = _y; sstab = st; semp = cnt.empty + bx * by * z - sum;
                 }
@@ -184,6 +209,11 @@ __device__ static Placement big_place(const BigCtx &c, Counters &cnt, int &err, 
         res.x = res.y = res.z = res.stab = 0;
     }
     return res;
+}
+
+__device__ static Placement big_place(const BigCtx &c, Counters &cnt, int &err, int bx, int by, int bz)
+{
+    return big_is_wide(c.D, bx, by) ? big_place_t<true>(c, cnt, err, bx, by, bz) : big_place_t<false>(c, cnt, err, bx, by, bz);
 }
 
 __device__ static void big_feature(int feature, int D, int W, int L, const int32_t *hm, float *out)
@@ -260,9 +290,9 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_step(StepArgs a, int32_t *scr
 // k_big_wave_step): every lane of the wavefront calls this.  Updates the tile (and the global copy `ghm` when given),
 // valid / empty / stable in `cnt` and the error bits; the caller advances cnt.count and files the result.  The returned
 // placement is the same on every lane.
-template <bool HARD>
-__device__ __forceinline__ Placement big_wave_place(const tap_env_desc &d, const uint32_t *lut, int32_t *hm, int32_t *ghm, int lane,
-                                                    int gmax, Counters &cnt, int &err, int bx, int by, int bz)
+template <bool HARD, bool WIDE>
+__device__ __forceinline__ Placement big_wave_place_t(const tap_env_desc &d, const uint32_t *lut, int32_t *hm, int32_t *ghm, int lane,
+                                                      int gmax, Counters &cnt, int &err, int bx, int by, int bz)
 {
     const int D = d.D, W = d.W, L = d.L, cells = W * L;
     const BigCtx c = {D, W, L, d.H, d.flags, lut, hm, nullptr};
@@ -280,10 +310,10 @@ __device__ __forceinline__ Placement big_wave_place(const tap_env_desc &d, const
         if (!big_corner(c, x, y, cls)) continue;
         if (x + bx > W || y + by > L) continue;                              // :2076 (2D: every later corner overflows too), :2255-2256
         int mx, sum; u64 eq;
-        big_scan(c, x, y, bx, by, mx, eq, sum);
+        big_scan<WIDE>(c, x, y, bx, by, mx, eq, sum);
         const int z = mx;
         if (z >= d.H) err |= 1;                                            // :2109 would raise IndexError
-        const int stab = z == 0 ? 1 : big_stable(c, x, y, bx, by, z, eq);
+        const int stab = z == 0 ? 1 : big_stable<WIDE>(c, x, y, bx, by, z, eq);
         const int emp = cnt.empty + bx * by * z - sum;
         const double r = tap_score(cfg, cnt, vol, gmax, z, bz, emp, stab);
         const long key = big_key(c, x, y, z, cls);
@@ -311,8 +341,8 @@ __device__ __forceinline__ Placement big_wave_place(const tap_env_desc &d, const
             int cls, k = INT_MAX, ms = -1, sm = 0;
             if (x + bx <= W && y + by <= L) {
                 int mx; u64 eq;
-                big_scan(c, x, y, bx, by, mx, eq, sm);
-                const int st = mx == 0 ? 1 : big_stable(c, x, y, bx, by, mx, eq);
+                big_scan<WIDE>(c, x, y, bx, by, mx, eq, sm);
+                const int st = mx == 0 ? 1 : big_stable<WIDE>(c, x, y, bx, by, mx, eq);
                 ms = (mx << 1) | st;
                 if (big_corner(c, x, y, cls)) { const long kk = big_key(c, x, y, mx, cls); k = kk > INT_MAX ? INT_MAX : (int)kk; }
             }
@@ -371,6 +401,15 @@ __device__ __forceinline__ Placement big_wave_place(const tap_env_desc &d, const
     Placement res = {0, 0, 0, 0, 0};
     if (placed) { res.placed = 1; res.x = px; res.y = py; res.z = pz; res.stab = pstab; }
     return res;
+}
+
+template <bool HARD>
+__device__ __forceinline__ Placement big_wave_place(const tap_env_desc &d, const uint32_t *lut, int32_t *hm, int32_t *ghm, int lane,
+                                                    int gmax, Counters &cnt, int &err, int bx, int by, int bz)
+{
+    if (__builtin_expect(big_is_wide(d.D, bx, by), 0))                            // wave-uniform, rare
+        return big_wave_place_t<HARD, true>(d, lut, hm, ghm, lane, gmax, cnt, err, bx, by, bz);
+    return big_wave_place_t<HARD, false>(d, lut, hm, ghm, lane, gmax, cnt, err, bx, by, bz);
 }
 
 // One lock-step of one container by one wavefront (every lane calls): gather / block, placement, state and results out,
@@ -468,7 +507,7 @@ __device__ __forceinline__ void big_wave_step_body(const StepArgs &a, int env, i
 }
 
 template <bool HARD>
-__global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
+__global__ void __launch_bounds__(TAP_BLOCK) TAP_BIG_REGS k_big_wave_step(StepArgs a)
 {
     extern __shared__ int32_t big_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -487,7 +526,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_step(StepArgs a)
 // -- 25.0 us: the placement is short enough here that the serial slab shows; the MACS forms (macs_big.hip,
 // macs3_big.hip), whose placements last 40 .. 150 us, are built that way.
 template <bool HARD, int NC, int MODE>
-__global__ void __launch_bounds__(384) k_big_transition(TransArgs a, int PW)
+__global__ void __launch_bounds__(384) TAP_BIG_REGS k_big_transition(TransArgs a, int PW)
 {
     extern __shared__ int32_t big_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -515,7 +554,7 @@ __global__ void __launch_bounds__(384) k_big_transition(TransArgs a, int PW)
 // refused them).  A tour entry's block is fetched by lane t % 64 for 64 steps at a time (two dependent loads once per
 // 64 placements instead of once per placement).
 template <bool HARD>
-__global__ void __launch_bounds__(TAP_BLOCK) k_big_wave_episode(EpisodeArgs a)
+__global__ void __launch_bounds__(TAP_BLOCK) TAP_BIG_REGS k_big_wave_episode(EpisodeArgs a)
 {
     extern __shared__ int32_t big_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

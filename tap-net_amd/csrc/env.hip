@@ -139,6 +139,9 @@ extern "C" int tap_env_desc_init(tap_env_desc *d, int B, int D, const int32_t *c
     if (strchr(reward, 'S')) d->flags |= TAP_F_USE_S;              // tools.py:2138
     if (!strncmp(reward, "mcs", 3)) d->flags |= TAP_F_MCS_ZERO;    // tools.py:2709
     if (strstr(reward, "mcs")) d->flags |= TAP_F_MCS_TIE;          // tools.py:2718
+    // TAP_AB_NO_TIE=1 (timing experiments only -- the placements then differ from the reference's): 'mcs' without its
+    // usable-space tie-break, to bound what that phase costs inside a launch
+    if (getenv("TAP_AB_NO_TIE")) d->flags &= ~TAP_F_MCS_TIE;
     // tools.py:3919-3964
     struct { const char *name; int mode; } table[] = {
         {"comp", TAP_R_C}, {"soft", TAP_R_CxS}, {"hard", TAP_R_CxS}, {"pyrm", TAP_R_CP},
