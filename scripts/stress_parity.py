@@ -66,7 +66,7 @@ for seed in range(int(sys.argv[1])):
             r2 = np.random.RandomState(8000 + seed)          # one thread per container, rows as 64-bit masks)
             W, L = int(r2.randint(2, 24)), int(r2.randint(9, 24))
             if r2.rand() < 0.5: W, L = L, W
-            cs = [W, L, int(r2.choice([30, 60, 100]))]; n = int(r2.randint(8, 40)); hi = int(min(W, L, r2.randint(3, 9))) + 1
+            cs = [W, L, int(r2.choice([30, 60, 100]))]; n = int(r2.randint(8, 40)); hi = int(min(W, L, r2.randint(3, 17))) + 1   # round 5: sides up to 16 (tap_stable_wide.h)
     elif kind == 1:  # MACS 2D
         W = int(rs.randint(2, 14)); cs = [W, int(rs.choice([60, 100, 200]))]; n = int(rs.randint(6, 24)); hi = min(W, 6) + 1
         reward = str(rs.choice(["C+P+S-mcs-soft", "C+P+S-mcs-hard", "C+P+S-mul-soft", "mcs-soft", "C+P-mcs-hard"])); strat = "MACS"
@@ -82,7 +82,7 @@ for seed in range(int(sys.argv[1])):
             r2 = np.random.RandomState(9000 + seed)          # per container, soft and hard)
             W, L = int(r2.randint(2, 26)), int(r2.randint(9, 26))
             if r2.rand() < 0.5: W, L = L, W
-            cs = [W, L, int(r2.choice([40, 80, 160]))]; n = int(r2.randint(6, 40)); hi = int(min(W, L, r2.randint(3, 9))) + 1
+            cs = [W, L, int(r2.choice([40, 80, 160]))]; n = int(r2.randint(6, 40)); hi = int(min(W, L, r2.randint(3, 17))) + 1   # round 5: sides up to 16
     else:            # LB 2D
         W = int(rs.randint(1, 40)); cs = [W, int(rs.choice([60, 120, 250]))]; n = int(rs.randint(4, 30)); hi = int(rs.randint(2, 10))
         reward = str(rs.choice(["C+P+S-lb-soft", "C+P+S-lb-hard", "C+P-lb-soft", "C+P-lb-hard"])); strat = "LB_GREEDY"
