@@ -643,117 +643,12 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     }
 }
 
-// ---- the same step for launches whose output no longer fits the caches (nontemporal stores, B >= 32 k at c2) ----------
-// There a CU's wave slots are all taken (8 per SIMD) and a stream wave lives one load round trip plus the drain of its
-// stores: bytes in flight per CU = resident stream waves x 4.8 KB, and the sweep stands at 4.6 TB/s against a 6.3 TB/s
-// fill ceiling.  This form lets ONE wave walk `iters` consecutive slab pairs and puts the NEXT pair's inputs in flight
-// right after the current pair's stores have been issued: the load latency of pair i + 1 and the drain of pair i overlap
-// inside the wave (one s_waitcnt vmcnt(0) per pair; gfx9 counts loads and stores together, so no finer wait is safe).
-// Two slabs per wave, one-word shadow, 32-bit column words (rows <= 32), every input present (the fused step on the bit
-// shadow); round 4's per-slab loops.  env0 = the wave's first slab of pair 0, pair i starts at env0 + i * pair_stride.
-template <int NC>
-__device__ __forceinline__ void stream_wave_bits_pipelined(const MaskArgs &a, int env0, int pair_stride, int iters, int lane)
-{
-    typedef unsigned long long u64;
-    const int nR = a.nR, C4 = nR >> 2, rows = a.rows, n = a.n, B = a.B;
-    const int RP = a.rp;
-    const bool lane_on = lane < RP * C4;
-    const int rsub = (int)(((unsigned)lane * (unsigned)a.c4_magic) >> 16), c4 = lane - rsub * C4;
-    const u64 nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    int jm[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) jm[c] = tap_mod_small(min(lane + 64 * c, nR - 1), n);
-    long praw[2];
-    float row0[2][NC], keep[2][NC];
-    u64 bj[2][NC];
-    ulonglong2 w[2][2];
-    auto request = [&](int senv0) {                       // every input of both slabs, unconditionally, on clamped addresses
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int env = min(senv0 + k, B - 1);
-            praw[k] = a.ptr[env];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int j = min(lane + 64 * c, nR - 1);
-                row0[k][c] = a.static_[(size_t)env * a.static_rows * nR + j];
-                keep[k][c] = a.mask_in[(size_t)env * nR + j];
-                bj[k][c] = a.bits_in[(size_t)env * nR + j];
-            }
-            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + c4 * 4);
-            w[k][0] = src[0];
-            w[k][1] = src[1];
-        }
-    };
-    if (env0 < B) request(env0);
-    for (int it = 0; it < iters; ++it) {
-        const int senv0 = env0 + it * pair_stride;
-        if (senv0 >= B) break;                                                    // wave-uniform
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): this pair's inputs are here (and the previous pair's stores gone)
-        u64 clr[2];
-        int pm[2];
-        unsigned nw32[2][4];
-        u64 nw64[2][4];
-        u64 nb[2][NC];
-        float kp[2][NC];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const bool valid = praw[k] >= 0 && praw[k] < nR;
-            const int p = valid ? (int)praw[k] : 0;
-            float r0 = -1.f;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float t = __shfl(row0[k][c], p & 63);
-                if (valid && (p >> 6) == c) r0 = t;
-            }
-            const int real = (r0 > -1.f && r0 < (float)rows) ? (int)r0 : -1;
-            u64 m = 0;
-            for (int i = 0; i < a.update_rows; ++i) {
-                const int r = real + n * i;
-                if (real >= 0 && r < rows) m |= 1ull << r;
-            }
-            clr[k] = m;
-            pm[k] = valid ? tap_mod_small(p, n) : -1;
-            nw64[k][0] = w[k][0].x & ~m; nw64[k][1] = w[k][0].y & ~m; nw64[k][2] = w[k][1].x & ~m; nw64[k][3] = w[k][1].y & ~m;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) nw32[k][q] = (unsigned)nw64[k][q];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) { nb[k][c] = bj[k][c] & ~m; kp[k][c] = (jm[c] == pm[k]) ? 0.f : keep[k][c]; }
-        }
-        // stores of this pair: the fp32 tensor first (the bulk), then the shadow words and the masks
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int env = senv0 + k;
-            if (env >= B) continue;
-            if (lane_on) {
-                if (a.dyn_out) {
-                    float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)env * rows * nR) + c4;
-                    for (int r = rsub; r < rows; r += RP) {
-                        const float4 v = make_float4((float)((nw32[k][0] >> r) & 1u), (float)((nw32[k][1] >> r) & 1u),
-                                                     (float)((nw32[k][2] >> r) & 1u), (float)((nw32[k][3] >> r) & 1u));
-                        store_stream(&dst[(size_t)r * C4], v, 0);
-                    }
-                }
-                if (rsub == 0 && a.bits_out) {
-                    ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + (size_t)env * nR + c4 * 4);
-                    dst[0] = make_ulonglong2(nw64[k][0], nw64[k][1]);
-                    dst[1] = make_ulonglong2(nw64[k][2], nw64[k][3]);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const int j = lane + 64 * c;
-                if (j >= nR) continue;
-                const int move = __popcll(nb[k][c] & nmask), small = n >= 64 ? 0 : __popcll((nb[k][c] >> n) & nmask);
-                const int large = n >= 32 ? 0 : __popcll((nb[k][c] >> (2 * n)) & nmask);
-                if (a.mask_out) a.mask_out[(size_t)env * nR + j] = kp[k][c];
-                if (a.cur_out) a.cur_out[(size_t)env * nR + j] = (small * large + move) != 0 ? 0.f : kp[k][c];
-            }
-        }
-        // the next pair's inputs go out behind these stores: their round trip overlaps the drain
-        if (it + 1 < iters && senv0 + pair_stride < B) request(senv0 + pair_stride);
-    }
-}
-
+// (Round 5, measured and removed: a stream wave walking 2 or 4 consecutive slab pairs with the NEXT pair's inputs put in
+//  flight right behind the current pair's stores, for launches beyond the write-through limit -- the load round trip of
+//  pair i + 1 overlapping the drain of pair i inside the wave, one vmcnt(0) per pair.  c2's shape: 1 628 / 1 612 against
+//  1 653 M env-steps/s at B = 128 k, 1 353 against 1 471 M at 512 k, 1 357 / 1 361 against 1 478 M at 1 M; c3's at 256 k
+//  514 / 500 against 558 M.  With every wave slot of the CU taken, the hardware's interleaving of many short-lived waves
+//  already overlaps loads and drains; fewer, longer-lived waves only lose.  git: "pipelined stream wave ... TAP_PIPE_ITERS".)
 // -DTAP_STREAM_R3: the round-3 form of the step (scripts/ab_transition.sh A/B builds only)
 #ifdef TAP_STREAM_R3
 template <int NS, int NC, bool BUILD = false>

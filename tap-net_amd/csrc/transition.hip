@@ -63,36 +63,6 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TAP_
     TL_STAMP(3);
 }
 
-// The same step for launches beyond the write-through limit (the output no longer fits the caches): a workgroup walks
-// `iters` consecutive groups of EPB envs; its stream waves overlap the next group's input round trip with the drain of
-// the current group's stores (tap_masks.h: stream_wave_bits_pipelined), its placement waves loop beside them.
-template <int D, int G, int NC>
-__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_pipe(TAP_MASK_HOT_PARAMS, TransArgs a, int iters)
-{
-    using Geo = TransGeom<G, 4>;
-    constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
-    static_assert(SPW == 2, "two slabs per stream wave");
-    __shared__ int s_old[64 * ENV_WAVES];
-    __shared__ int s_new[64 * ENV_WAVES];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int env_base = blockIdx.x * iters * EPB;
-    if (wave >= ENV_WAVES) {
-        const MaskArgs m = tap_mask_hot(a.m, true, TAP_MASK_HOT_NAMES);
-        stream_wave_bits_pipelined<NC>(m, env_base + (wave - ENV_WAVES) * SPW, EPB, iters, lane);
-        return;
-    }
-    __builtin_amdgcn_s_setprio(2);
-    const int cell = tid % G;
-    StepArgs sa = a.s;
-    sa.ptr = h_ptr; sa.static_ = h_static; sa.nR = h_nR; sa.static_rows = h_static_rows; sa.d.B = h_B;
-    for (int it = 0; it < iters; ++it) {
-        const int base = env_base + it * EPB;
-        if (base >= h_B) break;                                                   // uniform over the workgroup
-        tap_lb_place_wave<D, G>(sa, a.flags, a.ratio_out, base + tid / G, cell, lane, s_old + (tid - cell), s_new + (tid - cell));
-        tap_wave_lds_sync();
-    }
-}
-
 #ifdef TAP_PROF
 extern "C" int tap_prof_read_timeline(unsigned long long *out, int clear)
 {
@@ -154,18 +124,6 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-    if constexpr (G < 64) {   // nontemporal launches on the bit shadow: the pipelined form (TAP_PIPE_ITERS groups per workgroup; 0 = off)
-        static const int pipe = [] { const char *e = getenv("TAP_PIPE_ITERS"); return e ? atoi(e) : 0; }();
-        const int nc = mask_fast_path_cols(a.m);
-        if (SW == 4 && pipe > 1 && mode == 1 && !a.m.wt && a.m.rows <= 32 && a.m.ptr && a.m.static_ && a.m.mask_in && (nc == 1 || nc == 2) &&
-            grid >= 4096 * pipe) {
-            const int g2 = (grid + pipe - 1) / pipe;
-            if (nc == 1) hipLaunchKernelGGL((k_transition_pipe<D, G, 1>), dim3(g2), dim3(THREADS), 0, st, TAP_MASK_HOT_ARGS(a.m), a, pipe);
-            else hipLaunchKernelGGL((k_transition_pipe<D, G, 2>), dim3(g2), dim3(THREADS), 0, st, TAP_MASK_HOT_ARGS(a.m), a, pipe);
-            TAP_LAUNCH_CHECK(ctx, "k_transition_pipe");
-            return TAP_OK;
-        }
-    }
 #define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, TAP_MASK_HOT_ARGS(a.m), a)
     // 2D windows (nR = 2n columns: five store instructions per run at c2) take the run-of-rows expansion while the stores
     // are write-through; 3D windows and every launch beyond the write-through limit keep the slab-by-slab loops
