@@ -541,7 +541,11 @@ int tap_roller_steps_done(const tap_roller *r);
  * 8(d) asks for the HBM peak to be confirmed on the box.  kind 0: dst = src (plain stores), 1: the same with
  * nontemporal stores, 2: fill dst (plain), 3: fill dst (nontemporal), 4: read src only, 5: fill with write-through
  * (sc0 sc1) stores, 6 / 7: the same in the bit-shadow expansion's store shape at c2 and as 4 800 linear bytes per wave
- * (bytes % 19200 == 0).  bytes % 16 == 0, 16-byte aligned buffers.  scripts/calibrate_bw.py times these; nothing on the hot path calls them. */
+ * (bytes % 19200 == 0), 8: the same bytes as 960-byte store instructions that start on 64 bytes.  bytes % 16 == 0,
+ * 16-byte aligned buffers.  scripts/calibrate_bw.py times these.  kinds 9 .. 13: SPARSE reads of src (256-byte aligned,
+ * bytes % 256 == 0), one record per stride, every record once -- 9: 8 bytes of every 128, 10: 32 of 128, 11: 32 of 64,
+ * 12: 64 of 128, 13: 32 of 256 -- for scripts/calibrate_fetch.py, which reads rocprofv3's FETCH_SIZE against them.
+ * Nothing on the hot path calls these. */
 int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, size_t bytes, void *stream);
 
 #ifdef __cplusplus

@@ -87,9 +87,55 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_wt(v4f *__restrict__ dst
     }
 }
 
+// kinds 9 .. 13 (round 5): SPARSE reads, to calibrate what rocprofv3's FETCH_SIZE tallies for the rolling step's
+// scattered records (the guide's "x 2" holds for wide coalesced reads only).  Record r of the region starts at
+// r * STRIDE bytes and TOUCH of its bytes are read (8: one lane's u64; 16 k: k lanes' 16 bytes each), every record once.
+//   9: 8 of 128    10: 32 of 128    11: 32 of 64    12: 64 of 128    13: 32 of 256
+template <int TOUCH, int STRIDE>
+__global__ void __launch_bounds__(TAP_BLOCK) k_fetch_probe(const char *__restrict__ src, size_t records, float *sink)
+{
+    constexpr int LPR = TOUCH >= 16 ? TOUCH / 16 : 1;                 // lanes per record
+    const size_t t = (size_t)blockIdx.x * TAP_BLOCK + threadIdx.x;
+    const size_t r = t / LPR;
+    if (r >= records) return;
+    const char *p = src + r * STRIDE + (t % LPR) * 16;
+    float acc;
+    if (TOUCH == 8) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(p);
+        acc = __uint_as_float((unsigned)(w ^ (w >> 32)));
+    } else {
+        const v4f v = *reinterpret_cast<const v4f *>(p);
+        acc = v.x + v.y + v.z + v.w;
+    }
+    if (acc == 123456.75f) *sink = acc;                               // never true for the calibration data
+}
+template <int TOUCH, int STRIDE>
+static void fetch_probe_launch(const void *src, size_t bytes, float *sink, hipStream_t st)
+{
+    const size_t records = bytes / STRIDE, lanes = records * (TOUCH >= 16 ? TOUCH / 16 : 1);
+    hipLaunchKernelGGL((k_fetch_probe<TOUCH, STRIDE>), dim3((unsigned)((lanes + TAP_BLOCK - 1) / TAP_BLOCK)), dim3(TAP_BLOCK), 0, st,
+                       static_cast<const char *>(src), records, sink);
+}
+
 extern "C" int tap_bw_probe(tap_ctx *ctx, int kind, void *dst, const void *src, size_t bytes, void *stream)
 {
     if (!ctx) return TAP_E_INVALID;
+    if (kind >= 9 && kind <= 13) {
+        if (!src || bytes % 256 || (uintptr_t)src % 256) return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kinds 9 .. 13 read a 256-byte aligned region");
+        if (bytes / 64 > 0x7fffffffull * 64) return tap_fail(ctx, TAP_E_INVALID, "bw_probe: region too large");
+        float *snk = reinterpret_cast<float *>(ctx->chk);
+        hipStream_t s_ = (hipStream_t)stream;
+        if (bytes == 0) return TAP_OK;
+        switch (kind) {
+        case 9: fetch_probe_launch<8, 128>(src, bytes, snk, s_); break;
+        case 10: fetch_probe_launch<32, 128>(src, bytes, snk, s_); break;
+        case 11: fetch_probe_launch<32, 64>(src, bytes, snk, s_); break;
+        case 12: fetch_probe_launch<64, 128>(src, bytes, snk, s_); break;
+        default: fetch_probe_launch<32, 256>(src, bytes, snk, s_); break;
+        }
+        TAP_LAUNCH_CHECK(ctx, "k_fetch_probe");
+        return TAP_OK;
+    }
     if (kind < 0 || kind > 8 || bytes % 16 || ((uintptr_t)dst | (uintptr_t)src) % 16)
         return tap_fail(ctx, TAP_E_INVALID, "bw_probe: kind 0..8, 16-byte aligned buffers and sizes");
     if (kind >= 6 && bytes % 19200)
