@@ -45,7 +45,14 @@ def episode_case(name, B, n, D, cs, reward, strategy, variants):
     out = []
     ref = None
     for label, kw in variants:
-        def run():
+        kw = dict(kw)
+        if kw.pop("reuse", False):                        # what a trainer does: ONE container batch + step object per run
+            env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=DEV)
+            kw["stepper"] = T.pack.EpisodeStepper(st, dy, env, "bot", True, steps=n)
+            if D == 3:
+                kw["container_length"] = cs[1]
+
+        def run(kw=kw):
             return T.run_episode(st, dy, T.TapePolicy(tape), cs[0], cs[-1], reward_type=reward,
                                  packing_strategy=strategy, **kw)
         r = run()
@@ -90,14 +97,14 @@ def rolling_case(name, B, N, child, D, init):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
-    ap.add_argument("--only", default=None, help="substring of the case names to run")
+    ap.add_argument("--only", default=None, help="substrings (comma-separated) of the case names to run")
     a = ap.parse_args()
     rows = []
     global episode_case, rolling_case
     if a.only:                                            # skip the other cases without touching the list below
         ep0, ro0 = episode_case, rolling_case
-        episode_case = lambda name, *x, **k: ep0(name, *x, **k) if a.only in name else []     # noqa: E731
-        rolling_case = lambda name, *x, **k: ro0(name, *x, **k) if a.only in name else []     # noqa: E731
+        episode_case = lambda name, *x, **k: ep0(name, *x, **k) if any(o in name for o in a.only.split(',')) else []     # noqa: E731
+        rolling_case = lambda name, *x, **k: ro0(name, *x, **k) if any(o in name for o in a.only.split(',')) else []     # noqa: E731
     bits_vs_copy = [("fused step, bit shadow", dict(fused=True)), ("fused step, fp32 copy", dict(fused=True, bits=False)),
                     ("two launches, bit shadow", dict(fused=False)), ("two launches, fp32 copy", dict(fused=False, bits=False))]
     rows += episode_case("2D n=30 W=5 LB_GREEDY (90 rows: two-word shadow)", 8192, 30, 2, [5, 150], "C+P+S-lb-soft", "LB_GREEDY", bits_vs_copy)
@@ -114,7 +121,7 @@ def main():
     rows += rolling_case("3D rolling N=300 child=10 (one thread per instance, 16-word masks)", 1024, 300, 10, 3, [7, 7, 1300])
     # round 4: the one-thread-per-container paths (correctness paths for unusual --container_width values), next to the
     # lane-per-cell kernels at the nearest shapes they cover
-    one = bits_vs_copy[:1]
+    one = bits_vs_copy[:1] + [("fused step, bit shadow, step object re-used across episodes", dict(fused=True, reuse=True))]
     rows += episode_case("3D n=10 8x8 LB_GREEDY (lane per cell, for scale)", 4096, 10, 3, [8, 8, 50], "C+P+S-lb-soft", "LB_GREEDY", one)
     rows += episode_case("3D n=10 10x10 LB_GREEDY (big.hip: one wavefront per container)", 4096, 10, 3, [10, 10, 50], "C+P+S-lb-soft", "LB_GREEDY", one)
     rows += episode_case("3D n=10 10x10 LB_GREEDY hard rewards (big.hip)", 4096, 10, 3, [10, 10, 50], "C+P+S-lb-hard", "LB_GREEDY", one)
