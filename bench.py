@@ -1357,11 +1357,11 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
     return out
 
 
-def run_sweep(cfg, hp, dev, use_graph, path):
+def run_sweep(cfg, hp, dev, use_graph, path, batches=None):
     name, D, cs, n, B, reward, strategy = cfg
     env_b, mask_b = algorithmic_bytes(D, cs, hp.nw)
     lines = []
-    for b in (8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304):
+    for b in (batches or (8192, 16384, 32768, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304)):
         if b % hp.B:
             continue
         try:
@@ -1604,6 +1604,7 @@ def main():
                     help="precedence update as an fp32 copy (tap_transition) instead of on the bit shadow (tap_transition_bits)")
     ap.add_argument("--sweep", action="store_true", help="also run a batch sweep (stderr; --sweep-out appends JSON lines)")
     ap.add_argument("--sweep-out", default=None)
+    ap.add_argument("--sweep-batches", default=None, help="comma-separated batch sizes (multiples of --batch) instead of the powers of two")
     ap.add_argument("--two-launch-rolling", action="store_true",
                     help="c5: tap_env_step_gather + tap_rolling_window per step instead of the fused tap_rolling_step")
     ap.add_argument("--overlap", action="store_true",
@@ -1782,7 +1783,8 @@ def main():
         if not args.no_variants and world == 1:
             out["variants"] = variants(cfg, args, hp, rank, world, dev, use_graph)
         if args.sweep and hp.kind == "transition":
-            run_sweep(cfg, hp, dev, use_graph, args.sweep_out)
+            run_sweep(cfg, hp, dev, use_graph, args.sweep_out,
+                      [int(x) for x in args.sweep_batches.split(",")] if args.sweep_batches else None)
         print(json.dumps(out), flush=True)
     tdist.barrier()
     if world > 1:

@@ -154,13 +154,13 @@ template <int G, bool WIDE> static int launch_episode_macs2(tap_ctx *ctx, const 
 }
 
 // ---- MACS / MUL 3D ---------------------------------------------------------------------------------------------
-template <int G>
+template <int G, int WL = 0>                            // WL: compile-time sides (tap_macs3_place), the reference's 5 x 5
 __global__ void __launch_bounds__(TAP_BLOCK) k_episode_macs3(EpisodeArgs a)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x, cell = tid % G;
     const int env = blockIdx.x * ((int)blockDim.x / G) + tid / G;
-    const int W = a.d.W, Ld = a.d.L, cells = W * Ld, n = a.n;
+    const int W = WL ? WL : a.d.W, Ld = WL ? WL : a.d.L, cells = W * Ld, n = a.n;
     const bool ev = env < a.B, incell = cell < cells;
     const int gl0 = (tid & 63) - cell;
     const int HW = macs3_hw(a.d.H);
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_episode_macs3(EpisodeArgs a)
         S.hm[cell] = hm;
         tap_wave_lds_sync();
         const int step = cnt.count;
-        const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, cnt, err, bx, by, bz, do_step);
+        const Placement pl = tap_macs3_place<G, WL>(cfg, S, cell, gl0, hm, cnt, err, bx, by, bz, do_step);
         tap_wave_lds_sync();
         if (do_step && cell == 0) {                           // tools.py:2843-2846: failures too
             S.hist[step * MACS3_HIST] = (pl.x & 15) | ((pl.y & 15) << 4) | ((bx & 15) << 8) | ((by & 15) << 12) | ((pl.placed & 1) << 16);
@@ -218,6 +218,14 @@ template <int G> static int launch_episode_macs3(tap_ctx *ctx, const EpisodeArgs
     const int epb = threads / G, grid = (a.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
+    if constexpr (G == 32) {
+        if (d.W == 5 && d.L == 5) {
+            TAP_HIP_CHECK(ctx, tap_allow_lds(k_episode_macs3<G, 5>, lds));
+            hipLaunchKernelGGL((k_episode_macs3<G, 5>), dim3(grid), dim3(threads), lds, st, a);
+            TAP_LAUNCH_CHECK(ctx, "k_episode_macs3");
+            return TAP_OK;
+        }
+    }
     TAP_HIP_CHECK(ctx, tap_allow_lds(k_episode_macs3<G>, lds));
     hipLaunchKernelGGL(k_episode_macs3<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_episode_macs3");

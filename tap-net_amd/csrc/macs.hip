@@ -124,12 +124,12 @@ template <int G> static int launch_macs_wide(tap_ctx *ctx, const StepArgs &a, hi
 }
 
 // ---- 3D ------------------------------------------------------------------------------------------
-template <int G>
+template <int G, int WL = 0>                            // WL: compile-time sides (tap_macs3_place), the reference's 5 x 5
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_step(StepArgs a)
 {
     extern __shared__ int lds[];
     const int tid = threadIdx.x;
-    tap_macs3_wave<G>(a, 0, nullptr, blockIdx.x * ((int)blockDim.x / G) + tid / G, tid % G, tid & 63,
+    tap_macs3_wave<G, WL>(a, 0, nullptr, blockIdx.x * ((int)blockDim.x / G) + tid / G, tid % G, tid & 63,
                       lds + (tid / G) * macs3_group_words(G, a.d.n_max, a.d.H));
 }
 
@@ -143,6 +143,14 @@ template <int G> static int launch_macs3(tap_ctx *ctx, const StepArgs &a, hipStr
     const int epb = threads / G, grid = (d.B + epb - 1) / epb;
     if (grid == 0) return TAP_OK;
     const size_t lds = epb * per_env;
+    if constexpr (G == 32) {
+        if (d.W == 5 && d.L == 5) {
+            TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_step<G, 5>, lds));
+            hipLaunchKernelGGL((k_macs3d_step<G, 5>), dim3(grid), dim3(threads), lds, st, a);
+            TAP_LAUNCH_CHECK(ctx, "k_macs3d_step");
+            return TAP_OK;
+        }
+    }
     TAP_HIP_CHECK(ctx, tap_allow_lds(k_macs3d_step<G>, lds));
     hipLaunchKernelGGL(k_macs3d_step<G>, dim3(grid), dim3(threads), lds, st, a);
     TAP_LAUNCH_CHECK(ctx, "k_macs3d_step");

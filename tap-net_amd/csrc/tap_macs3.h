@@ -170,11 +170,13 @@ static __device__ unsigned int tap_prof_m3[8192 * 16];
 // S.hist[0..8*cnt.count) filled, visible to the group (wave-level sync by the caller).  do_step is
 // group-uniform.  On return hm/cnt and the cell's words in S.occ are updated and res describes the
 // placement.
-template <int G>
+template <int G, int WL = 0>
 __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S, int cell, int gl0, int &hm,
                                             Counters &cnt, int &err, int bx, int by, int bz, bool do_step)
 {
-    const int W = c.W, L = c.L, H = c.H, cells = W * L;
+    // WL != 0: a WL x WL container with the sides known at compile time (the row / level loops unroll, `y * W` shifts
+    // and the divisions by W fold): 33.4 -> 31.1 us per fused step at c6 (5 x 5, the reference's own 3D container)
+    const int W = WL ? WL : c.W, L = WL ? WL : c.L, H = c.H, cells = W * L;
     Placement res = {0, 0, 0, 0, 0};
     if (!do_step) return res;
     M3_PROF_BEGIN;
@@ -778,11 +780,11 @@ __device__ inline Placement tap_macs3_place(const PlaceCfg &c, const Macs3Lds &S
 // One env's whole step as executed by its lane group (stand-alone step in macs.hip, placement waves
 // of the fused transition in transition.hip): load state + history, place, store state, feature,
 // and -- for the fused form -- the fresh-container start and calc_ratio (flags: TAP_T_*).
-template <int G>
+template <int G, int WL = 0>
 __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio_out, int env, int cell, int lane,
                                       int *lds_group)
 {
-    const int B = a.d.B, W = a.d.W, Ld = a.d.L, cells = W * Ld;
+    const int B = a.d.B, W = WL ? WL : a.d.W, Ld = WL ? WL : a.d.L, cells = W * Ld;
     const bool ev = env < B, incell = cell < cells, fresh = flags & TAP_T_FRESH;
     const int gl0 = lane - cell;
     const int HW = macs3_hw(a.d.H);
@@ -840,7 +842,7 @@ __device__ inline void tap_macs3_wave(const StepArgs &a, int flags, float *ratio
     tap_wave_lds_sync();
     const int step = cnt.count;
     const PlaceCfg cfg = {W, Ld, a.d.H, a.d.flags, a.lut};
-    const Placement pl = tap_macs3_place<G>(cfg, S, cell, gl0, hm, cnt, err, bx, by, bz, do_step);
+    const Placement pl = tap_macs3_place<G, WL>(cfg, S, cell, gl0, hm, cnt, err, bx, by, bz, do_step);
     err = group_or<G>(err);
 
     tap_wave_lds_sync();

@@ -129,7 +129,8 @@ template <int G> struct M3Geo {
 #else
 #define M3_OCC
 #endif
-template <int G, int NC, int MODE>
+// WL: 0, or the side of a WL x WL container known at compile time (tap_macs3_place; instantiated for the reference's 5 x 5)
+template <int G, int NC, int MODE, int WL = 0>
 __global__ void __launch_bounds__((M3Geo<G>::THREADS)) M3_OCC k_transition_macs3(TransArgs a)
 {
     using Geo = M3Geo<G>;
@@ -146,8 +147,8 @@ __global__ void __launch_bounds__((M3Geo<G>::THREADS)) M3_OCC k_transition_macs3
     int *macs_base = reinterpret_cast<int *>(trans_lds + (size_t)EPB * 3 * a.m.nR);
     const int grp = tid / G;
     const int env = Geo::SPREAD ? ((grp & 1) ? a.s.d.B : env_base + (grp >> 1)) : env_base + grp;
-    tap_macs3_wave<G>(a.s, a.flags, a.ratio_out, env, tid % G, lane,
-                      macs_base + grp * macs3_group_words(G, a.s.d.n_max, a.s.d.H));
+    tap_macs3_wave<G, WL>(a.s, a.flags, a.ratio_out, env, tid % G, lane,
+                          macs_base + grp * macs3_group_words(G, a.s.d.n_max, a.s.d.H));
 }
 
 template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
@@ -159,8 +160,12 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
                        (size_t)M3Geo<G>::GROUPS * macs3_group_words(G, a.s.d.n_max, a.s.d.H) * sizeof(int);
     if (lds > tap_lds_limit(ctx)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS 3D): %zu bytes of LDS needed", lds);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs3<G, NC_, M_>, LDS_)); \
-        hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
+    // the reference's own 3D container (5 x 5, BASELINE c6; a 32-lane group) runs the instantiation with compile-time sides
+    const bool wl5 = G == 32 && a.s.d.W == 5 && a.s.d.L == 5;
+#define TAP_LAUNCH_W(NC_, M_, LDS_, WL_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs3<G, NC_, M_, WL_>, LDS_)); \
+        hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_, WL_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
+#define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr (G == 32) { if (wl5) TAP_LAUNCH_W(NC_, M_, LDS_, 5); else TAP_LAUNCH_W(NC_, M_, LDS_, 0); } \
+        else TAP_LAUNCH_W(NC_, M_, LDS_, 0); } while (0)
 #define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 5, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 6, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)   /* 5 / 6: TAP_MODE_MERGED, the run-of-rows expansion (c4: 504 against 490 M env-steps/s) */
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
@@ -170,6 +175,8 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
     }
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
+#undef TAP_LAUNCH_W
+    (void)wl5;
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs3");
     return TAP_OK;
 }
