@@ -452,15 +452,19 @@ __device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v 
 //  cache-resident buffer, 6.14 against 4.02 us on fresh ones, profiles/r04_bw_store_shapes.json); the kernel did not
 //  agree: c2 1 295 -> 1 268 M env-steps/s, c3 520 -> 478 M, cold passes 1 009 -> 992 M, and 10-15 % slower from
 //  B = 128 k up -- the LDS read and the index arithmetic in front of every store cost more than the half lines.)
-template <int NS, int NC, bool BUILD = false, bool MERGED = true>
+// C4S != 0: the reference's own window -- n = 10 nodes, rows = 30, nR = 4 C4S columns (C4S = 5: 2D, 15: 3D) -- with its
+// shape known at compile time: the expansion's loop unrolls, the row / column arithmetic folds.  Same session, same
+// tree: c2 1 280 -> 1 337-1 346 M env-steps/s, c3 500 -> 506 M.
+template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0>
 __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
                                                  float *lds = nullptr)
 {
     typedef unsigned long long u64;
     static_assert(NS <= 2, "a stream wave expands one or two slabs");
     if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
-    const int nR = a.nR, C4 = nR >> 2, rows = a.rows, n = a.n;
-    const int RP = a.rp;
+    const int nR = C4S ? 4 * C4S : a.nR, C4 = C4S ? C4S : nR >> 2, rows = C4S ? 30 : a.rows, n = C4S ? 10 : a.n;
+    const int RP = C4S ? 64 / C4S : a.rp;
+    const int c4_magic = C4S ? 65536 / C4S + 1 : a.c4_magic;
     const bool lane_on = lane < RP * C4;
     // ONE role per wave: the wave's slabs are contiguous, so their rows form one run of NS * rows rows of nR floats; the
     // lane keeps column quad c4 of EVERY slab and walks the rows r0, r0 + RP, ... of the whole run (stream_lane_role:
@@ -468,9 +472,9 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     // mapping of round 4 -- per-slab roles cost six more and a wave per SIMD (68 VGPRs, measured: 1 264 against
     // 1 450 M env-steps/s at B = 1 M).
 #ifdef TAP_STREAM_UNALIGNED   // A/B builds: round 4's fixed roles (store instructions start wherever the slab does)
-    const LaneRole role = stream_lane_role(lane, 0, C4, RP, a.c4_magic, 0, 0, 0);
+    const LaneRole role = stream_lane_role(lane, 0, C4, RP, c4_magic, 0, 0, 0);
 #else
-    const LaneRole role = stream_lane_role(lane, senv0, C4, RP, a.c4_magic, a.sb_mul, a.sb_add, 0);
+    const LaneRole role = stream_lane_role(lane, senv0, C4, RP, c4_magic, a.sb_mul, a.sb_add, 0);
 #endif
     const bool first_row = role.rsub == 0;               // these lanes also write the slab's new shadow words
     u64 *tile = reinterpret_cast<u64 *>(lds);
@@ -563,7 +567,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             // lanes skip i = 0); rows >= `rows` belong to the second slab
             const int non = (NS > 1 && on[NS - 1]) ? 2 : 1;
             const int total = non * rows;
-            const int nq = (non > 1 ? a.nq2 : a.nq) + role.nq;                // role.nq: one more instruction when rotated
+            const int nq = (C4S ? (non * rows + RP - 1) / RP : (non > 1 ? a.nq2 : a.nq)) + role.nq;   // role.nq: one more instruction when rotated
             float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)senv0 * rows * nR) + role.c4;
             int rr = role.r0;
             // MERGED = false (two-slab waves only): round 4's loops, one per slab on the lane's own rows.  Which form a
@@ -767,13 +771,13 @@ __device__ __forceinline__ void stream_wave_bits_r3(const MaskArgs &a, int senv0
 }
 
 #endif
-template <int NS, int NC, bool BUILD = false, bool MERGED = true>
+template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0>
 __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS], float *lds = nullptr)
 {
 #ifdef TAP_STREAM_R3
     stream_wave_bits_r3<NS, NC, BUILD>(a, senv0, lane, on, lds);
 #else
-    stream_wave_bits_r4<NS, NC, BUILD, MERGED>(a, senv0, lane, on, lds);
+    stream_wave_bits_r4<NS, NC, BUILD, MERGED, C4S>(a, senv0, lane, on, lds);
 #endif
 }
 

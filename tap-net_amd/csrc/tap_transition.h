@@ -22,19 +22,25 @@ struct TransArgs {
 // MODE & 3: 0 = fp32 copy with the column-sum shadow, 1 = on the bit shadow, 2 = first step (shadow built in the launch);
 // MODE & 4 (TAP_MODE_MERGED): the fp32 expansion walks the wave's two slabs as one run of rows (tap_masks.h:
 // stream_wave_bits, where the A/B figures are) instead of slab by slab
-constexpr int TAP_MODE_MERGED = 4;
+// MODE & 8 / & 16 (TAP_MODE_C4_5 / _15): the window is the reference's own -- n = 10, rows = 30, nR = 20 (2D) / 60 (3D) --
+// and its shape is compiled in (stream_wave_bits_r4: C4S); the launcher checks the shape
+constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16;
+__host__ __device__ constexpr int tap_mode_shape(int D) { return D == 2 ? TAP_MODE_C4_5 : TAP_MODE_C4_15; }
+inline bool tap_mode_shape_ok(const MaskArgs &m, int D) { return m.n == 10 && m.rows == 30 && m.nR == (D == 2 ? 20 : 60); }
 template <int SPW, int NC, int MODE_>
 __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
 {
     constexpr int MODE = MODE_ & 3;
     constexpr bool MERGED = (MODE_ & TAP_MODE_MERGED) != 0;
+    constexpr int C4S = (MODE_ & TAP_MODE_C4_5) ? 5 : (MODE_ & TAP_MODE_C4_15) ? 15 : 0;
+    static_assert(C4S == 0 || NC == 1, "the compiled-in window shapes have one column per lane");
     bool on[SPW];
 #pragma unroll
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
     TL_STAMP(0);
     if (NC > 0) {
-        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED>(m, senv0, lane, on, lds);
-        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true, MERGED>(m, senv0, lane, on, lds);
+        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED, C4S>(m, senv0, lane, on, lds);
+        else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true, MERGED, C4S>(m, senv0, lane, on, lds);
         else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         TL_STAMP(2);
         TL_WAIT_VM();

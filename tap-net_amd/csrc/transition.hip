@@ -124,7 +124,12 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, TAP_MASK_HOT_ARGS(a.m), a)
+#define TAP_LAUNCH_K(NC_, M_, LDS_) hipLaunchKernelGGL((k_transition<D, G, NC_, SW, M_>), dim3(grid), dim3(THREADS), LDS_, st, TAP_MASK_HOT_ARGS(a.m), a)
+    // the reference's own window (n = 10: rows = 30, nR = 20 / 60) on the bit shadow runs the instantiation with its shape
+    // compiled in (tap_transition.h: TAP_MODE_C4_*)
+    const bool shaped = tap_mode_shape_ok(a.m, D);
+#define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr ((NC_) == 1 && ((M_) & 3) != 0) { if (shaped) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D)), LDS_); else TAP_LAUNCH_K(NC_, M_, LDS_); } \
+        else TAP_LAUNCH_K(NC_, M_, LDS_); } while (0)
     // 2D windows (nR = 2n columns: five store instructions per run at c2) take the run-of-rows expansion while the stores
     // are write-through; 3D windows and every launch beyond the write-through limit keep the slab-by-slab loops
     const bool merged = D == 2 && a.m.wt != 0;
@@ -138,6 +143,8 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     }
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
+#undef TAP_LAUNCH_K
+    (void)shaped;
     TAP_LAUNCH_CHECK(ctx, "k_transition");
     return TAP_OK;
 }
