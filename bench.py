@@ -1088,6 +1088,42 @@ def variants_rolling(cfg, hp, dev, use_graph, trace):
                                           "torch ops) between the steps, eager launches")
     except Exception as ex:                                  # pragma: no cover
         out["policy_in_loop"] = dict(error=str(ex)[:300])
+    trace("no_fp32_expand")
+    try:
+        if "eager" in skip:
+            raise RuntimeError("skipped")
+        # the windows' fp32 precedence tensor (7 200 of the 9 937 bytes a c5 step moves) left out: the same episodes,
+        # this run's recorded tour replayed, on step objects with and without the expansion (tapenv.h: dynamic = NULL)
+        blocks = hp.rw.blocks
+        positions = torch.as_tensor(hp.positions_h, device=dev)
+        tape = T.TapePolicy(hp.tape.t().contiguous())                 # (B, n): the recorded tour
+        pairs = {True: None, False: None}
+
+        def run2(expand):
+            r = T.run_rolling_episode(blocks, positions, hp.init, tape, cs[0], cs[-1], child_graph_size=hp.nw,
+                                      reward_type=reward, steppers=pairs[expand], expand_dynamic=expand)
+            pairs[expand] = r["steppers"]
+            return r
+
+        def timed2(expand, steps):
+            run2(expand)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                r = run2(expand)
+            torch.cuda.synchronize(dev)
+            return B * n * steps / (time.perf_counter() - t0), r
+        v_on, r_on = timed2(True, 5)
+        keep = [r_on[k].clone() for k in ("reward", "tour_idx", "nodes")]
+        v_off, r_off = timed2(False, 5)
+        same = all(torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) for a, b in zip(keep, [r_off[k] for k in ("reward", "tour_idx", "nodes")]))
+        out["no_fp32_expand"] = dict(value=v_off, unit="env-steps/s", with_expansion=v_on, steps=5, identical_outputs=bool(same),
+                                     dynamic_is_none=pairs[False][0].dynamic is None,
+                                     what="rolling.run_rolling_episode(expand_dynamic=False) against expand_dynamic=True on persistent "
+                                          "step objects, this run's tour replayed (TapePolicy), eager launches: the windows' fp32 "
+                                          "precedence tensors are never written, a policy reads their bit shadows")
+    except Exception as ex:                                  # pragma: no cover
+        out["no_fp32_expand"] = dict(error=str(ex)[:300])
     return out
 
 

@@ -297,7 +297,10 @@ int tap_rolling_init(tap_ctx *ctx, int B, int D, int N, const int32_t *container
  * (B, 3*child, child*R) f32.  Optional by-products: colsum_out (B, 3, child*R) (the column sums
  * update_mask needs), bits_out (B, child*R) uint64 (the bit shadow of dynamic_out for
  * tap_transition_bits / tap_mask_step_bits; needs 3*child <= 64, child*R % 4 == 0), current_mask_out (B, child*R) (model.py:297-307), nodes_out (B, child) i32
- * (sorted global block ids = static's columns), err_out (B,) i32 (1 = window could not be filled). */
+ * (sorted global block ids = static's columns), err_out (B,) i32 (1 = window could not be filled).
+ * dynamic_out may be NULL when bits_out is given: the window's precedence tensor then only exists as its bit shadow
+ * (no fp32 expansion -- 7 200 of the 9 937 bytes a c5 step moves; for policies that read the shadow, as
+ * tap_stepper_buffers.dyn = NULL for the decoding step).  tap_rolling_step and tap_roller_buffers.dynamic alike. */
 int tap_rolling_window(tap_ctx *ctx, int B, int D, int N, int child, const int32_t *blocks,
                        const uint64_t *rel, uint64_t *state, const int64_t *remove_ptr,
                        float *static_out, float *dynamic_out, float *colsum_out, uint64_t *bits_out,
@@ -513,7 +516,7 @@ typedef struct tap_roller tap_roller;
 typedef struct tap_roller_buffers {
     float *static_[2];              /* (B, 1+D, child*R) */
     int32_t *nodes[2];              /* (B, child): sorted global block ids = static's columns */
-    float *dynamic;                 /* (B, 3*child, child*R) */
+    float *dynamic;                 /* (B, 3*child, child*R); nullable when bits is given: no fp32 expansion */
     unsigned long long *bits;       /* (B, child*R) nullable: dynamic's bit shadow (needs 3*child <= 64) */
     float *colsum;                  /* (B, 3, child*R) nullable */
     float *current_mask;            /* (B, child*R) nullable (model.py:297-307) */

@@ -374,7 +374,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
-    float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
+    float *dy = a.dynamic_out ? a.dynamic_out + (size_t)inst * 3 * child * nRc : nullptr;   // NULL: no fp32 expansion (tapenv.h)
     // which side pair guards rotation r (:1808-1821): the axis that becomes vertical
     auto side_of = [&](int r, int sec) -> int {
         const int *p = D == 2 ? perm2[r] : perm3[r];
@@ -467,7 +467,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
                 const int node = S.ord[rm];
 #pragma unroll
                 for (int sec = 0; sec < 3; ++sec)
-                    dy[(size_t)(sec * child + rm) * nRc + col] = (float)((m[sec] >> node) & 1ull);
+                    if (dy) dy[(size_t)(sec * child + rm) * nRc + col] = (float)((m[sec] >> node) & 1ull);
             }
         }
     }
@@ -476,7 +476,7 @@ __device__ inline void rolling_emit_wave(const RollArgs &a, int inst, int v, LDS
     tap_wave_lds_sync();
     PROF(6);
     const int C4 = nRc >> 2, RP = 64 / C4;
-    if (v < RP * C4) {
+    if (dy && v < RP * C4) {
         // lane roles rotated so that every store instruction starts on a 64-byte granule (tap_masks.h: stream_lane_role)
         const LaneRole role = roll_lane_role(v, dy, C4, RP, rows);
         const int c4 = role.c4;
@@ -515,7 +515,7 @@ __device__ __forceinline__ void rolling_emit_fast_tail(const RollArgs &a, int in
     long long tp = clock64();
 #endif
     float *st = a.static_out + (size_t)inst * (1 + D) * NRC;
-    float *dy = a.dynamic_out + (size_t)inst * ROWS * NRC;
+    float *dy = a.dynamic_out ? a.dynamic_out + (size_t)inst * ROWS * NRC : nullptr;   // NULL: no fp32 expansion (tapenv.h)
     if (v < NRC) {
         const int col = v, r = v / CH, cm = v - r * CH;
         // which side pair guards rotation r (:1808-1821): the axis that becomes vertical, p[D-1] of the rotation's
@@ -563,7 +563,7 @@ __device__ __forceinline__ void rolling_emit_fast_tail(const RollArgs &a, int in
 #else
         const int sb = AL ? __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<uintptr_t>(dy) >> 4) & 3)) : 0;
 #endif
-        if (v < K) {
+        if (dy && v < K) {
             int role = v - sb;
             const int late = role < 0 ? 1 : 0;
             role += late ? K : 0;
@@ -886,7 +886,7 @@ __device__ inline void rolling_window_waveN(const RollArgs &a, int inst, int v, 
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
-    float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
+    float *dy = a.dynamic_out ? a.dynamic_out + (size_t)inst * 3 * child * nRc : nullptr;   // NULL: no fp32 expansion (tapenv.h)
     const int rows = 3 * child;
     const bool packed = rows <= 64 && (nRc & 3) == 0 && nRc <= 128;
     for (int col = v; col < nRc; col += 64) {
@@ -912,13 +912,13 @@ __device__ inline void rolling_window_waveN(const RollArgs &a, int inst, int v, 
             for (int rm = 0; rm < child; ++rm)
 #pragma unroll
                 for (int sec = 0; sec < 3; ++sec)
-                    dy[(size_t)(sec * child + rm) * nRc + col] = (float)((ws[sec] >> rm) & 1u);
+                    if (dy) dy[(size_t)(sec * child + rm) * nRc + col] = (float)((ws[sec] >> rm) & 1u);
         }
     }
     if (!packed) return;
     tap_wave_lds_sync();
     const int C4 = nRc >> 2, RP = 64 / C4;
-    if (v < RP * C4) {
+    if (dy && v < RP * C4) {
         const LaneRole role = roll_lane_role(v, dy, C4, RP, rows);       // store instructions start on 64-byte granules
         const int c4 = role.c4;
         const u64 c0 = S.cw[c4 * 4], c1 = S.cw[c4 * 4 + 1], c2 = S.cw[c4 * 4 + 2], c3 = S.cw[c4 * 4 + 3];
@@ -1248,7 +1248,7 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
     const int perm2[2][3] = {{0, 1, 0}, {1, 0, 0}};
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     float *st = a.static_out + (size_t)inst * (1 + D) * nRc;
-    float *dy = a.dynamic_out + (size_t)inst * 3 * child * nRc;
+    float *dy = a.dynamic_out ? a.dynamic_out + (size_t)inst * 3 * child * nRc : nullptr;   // NULL: no fp32 expansion (tapenv.h)
     const int rows = 3 * child;
     int srt_i = 0;
     for (int v = 0; v < N; ++v) {                                     // sorted position -> node: static's columns
@@ -1285,7 +1285,7 @@ __global__ void __launch_bounds__(64) k_rolling_window_big(RollArgs a)
                             bit = out;
                         }
                     }
-                    dy[(size_t)(sec * child + rm) * nRc + col] = bit ? 1.f : 0.f;
+                    if (dy) dy[(size_t)(sec * child + rm) * nRc + col] = bit ? 1.f : 0.f;
                     sum[sec] += bit;
                     if (bit && sec * child + rm < 64) word |= 1ull << (sec * child + rm);
                 }
@@ -1367,7 +1367,9 @@ static int rolling_window_impl(tap_ctx *ctx, int B, int D, int N, int child, con
 {
     int rc = roll_check(ctx, B, D, N, child);
     if (rc) return rc;
-    if (!blocks || !rel || !state || !static_out || !dynamic_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    if (!blocks || !rel || !state || !static_out) return tap_fail(ctx, TAP_E_INVALID, "null pointer");
+    if (!dynamic_out && !bits_out)
+        return tap_fail(ctx, TAP_E_INVALID, "dynamic_out may only be left out when bits_out takes the window's bit shadow");
     RollArgs a = {};
     a.err_sticky = err_sticky;
     a.wt = tap_write_through((size_t)B * 3 * child * child * (D == 2 ? 2 : 6) * sizeof(float));
@@ -1458,9 +1460,10 @@ static int rolling_step_impl(tap_ctx *ctx, const tap_env_desc *d, void *env_stat
     if (d->B == 0) return TAP_OK; // an empty batch has no buffers to check
     rc = roll_check(ctx, d->B, d->D, N, child);
     if (rc) return rc;
-    if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || !dynamic_out ||
-        static_cur == static_next)
+    if (!env_state || !blocks || !rel || !state || !ptr || !static_cur || !static_next || static_cur == static_next)
         return tap_fail(ctx, TAP_E_INVALID, "bad rolling_step arguments (static_cur and static_next must differ)");
+    if (!dynamic_out && !bits_out)
+        return tap_fail(ctx, TAP_E_INVALID, "dynamic_out may only be left out when bits_out takes the window's bit shadow");
     if (d->strategy != TAP_LB_GREEDY || tap_is_big(d) || (N > 64 && roll_wide_nw(N, child) != 2)) {
         // no single kernel for these (MACS / legacy LB placements, thread-per-container shapes, instances above 128
         // blocks: their window wave keeps up to 16 mask words per lane, the fused kernels are held to 72 registers):
@@ -1563,9 +1566,9 @@ extern "C" int tap_roller_create(tap_ctx *ctx, const tap_env_desc *d, void *env_
     if (rc) return rc;
     rc = roll_check(ctx, d->B, d->D, N, child);
     if (rc) return rc;
-    if (d->B > 0 && (!env_state || !buf->static_[0] || !buf->static_[1] || buf->static_[0] == buf->static_[1] || !buf->dynamic ||
-                     !buf->nodes[0] || !buf->nodes[1] || buf->nodes[0] == buf->nodes[1]))
-        return tap_fail(ctx, TAP_E_INVALID, "roller needs both phases of static / nodes (distinct) and dynamic");
+    if (d->B > 0 && (!env_state || !buf->static_[0] || !buf->static_[1] || buf->static_[0] == buf->static_[1] ||
+                     (!buf->dynamic && !buf->bits) || !buf->nodes[0] || !buf->nodes[1] || buf->nodes[0] == buf->nodes[1]))
+        return tap_fail(ctx, TAP_E_INVALID, "roller needs both phases of static / nodes (distinct) and dynamic (or, without the fp32 expansion, bits)");
     if ((buf->tour || buf->picked) && buf->tour_stride < N - child)
         return tap_fail(ctx, TAP_E_INVALID, "roller tour_stride must hold the N - child single-step windows");
     tap_roller *r = new (std::nothrow) tap_roller();

@@ -486,7 +486,8 @@ class EpisodeStepper(object):
         import ctypes as C
         self.block_dim = _block_dim(static, input_type)
         self.R = _rotate_types(self.block_dim, allow_rot)
-        self.B, self.rows, self.nR = (int(v) for v in dynamic.shape)
+        # (``dynamic`` may be the tensor's SHAPE (B, rows, nR) when none exists: windows carried as their bit shadow only)
+        self.B, self.rows, self.nR = (int(v) for v in (dynamic if isinstance(dynamic, (tuple, list)) else dynamic.shape))
         self.n = self.nR // self.R
         self.static_rows = int(static.shape[1])
         self.update_rows = _UPDATE_ROWS[input_type]

@@ -48,7 +48,7 @@ class RollingWindows(object):
         instances run in lock-step, so this is a host-side count, not a device read."""
         return self.steps_done >= self.windows_total
 
-    def next(self, remove_ptr=None, want_masks=True):
+    def next(self, remove_ptr=None, want_masks=True, expand_dynamic=True):
         """convert_to_input() after remove_block(sub_graph_nodes[ptr % child]).
         -> dict(static, dynamic, nodes, colsum, bits, current_mask): ``bits`` is the window tensor's bit
         shadow (pack.dynamic_bits layout) when its shape has one, else ``colsum`` holds the column sums."""
@@ -57,9 +57,9 @@ class RollingWindows(object):
         f32 = dict(dtype=torch.float32, device=self.device)
         nRc = self.child * self.R
         static = torch.empty(self.B, 1 + self.D, nRc, **f32)
-        dynamic = torch.empty(self.B, 3 * self.child, nRc, **f32)
         nodes = torch.empty(self.B, self.child, dtype=torch.int32, device=self.device)
         bits = self._new_bits(nRc) if want_masks else None
+        dynamic = self._new_dynamic(nRc, bits, expand_dynamic)
         colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks and bits is None else None
         cur = torch.empty(self.B, nRc, **f32) if want_masks else None
         err = torch.zeros(self.B, dtype=torch.int32, device=self.device)
@@ -73,6 +73,16 @@ class RollingWindows(object):
         self._err = err
         return dict(static=static, dynamic=dynamic, nodes=nodes, colsum=colsum, bits=bits, current_mask=cur)
 
+    def _new_dynamic(self, nRc, bits, expand_dynamic):
+        """The window's fp32 precedence tensor, or None with ``expand_dynamic=False`` (tapenv.h: dynamic_out = NULL --
+        the window then only exists as its bit shadow, which its shape must have)."""
+        if expand_dynamic:
+            return torch.empty(self.B, 3 * self.child, nRc, dtype=torch.float32, device=self.device)
+        if bits is None:
+            raise ValueError("expand_dynamic=False needs the window's bit shadow (want_masks=True and 3 * child <= 64, "
+                             "child * R a multiple of 4)")
+        return None
+
     def _new_bits(self, nRc):
         """Buffer for the window tensor's bit shadow (pack.dynamic_bits layout), None if the shape has none."""
         from .pack import bits_supported
@@ -80,16 +90,16 @@ class RollingWindows(object):
             return None
         return torch.empty(self.B, nRc, dtype=torch.int64, device=self.device)
 
-    def step(self, ptr, env, static_cur, want_masks=True, want_feature=True):
+    def step(self, ptr, env, static_cur, want_masks=True, want_feature=True, expand_dynamic=True):
         """One decoding step in ONE launch (tap_rolling_step): place the block picked in the current
         window (column ``ptr`` of ``static_cur``) into ``env`` and build the next window.
         -> (feature, next-window dict)."""
         f32 = dict(dtype=torch.float32, device=self.device)
         nRc = self.child * self.R
         static = torch.empty(self.B, 1 + self.D, nRc, **f32)
-        dynamic = torch.empty(self.B, 3 * self.child, nRc, **f32)
         nodes = torch.empty(self.B, self.child, dtype=torch.int32, device=self.device)
         bits = self._new_bits(nRc) if want_masks else None
+        dynamic = self._new_dynamic(nRc, bits, expand_dynamic)
         colsum = torch.empty(self.B, 3, nRc, **f32) if want_masks and bits is None else None
         cur = torch.empty(self.B, nRc, **f32) if want_masks else None
         err = torch.zeros(self.B, dtype=torch.int32, device=self.device)
@@ -122,7 +132,7 @@ class RollingStepper(object):
     ``bits`` / ``colsum``, ``current_mask``, ``decoder_dynamic``, ``decoder_static`` describe the CURRENT window --
     views of the stepper's buffers, overwritten by later steps."""
 
-    def __init__(self, windows, env, want_masks=True):
+    def __init__(self, windows, env, want_masks=True, expand_dynamic=True):
         rw = self.windows = windows
         self.env = env
         dev = self._dev = rw.device
@@ -135,8 +145,9 @@ class RollingStepper(object):
         f32 = dict(dtype=torch.float32, device=dev)
         self._static = [torch.empty(B, 1 + D, nRc, **f32) for _ in range(2)]
         self._nodes = [torch.empty(B, child, dtype=torch.int32, device=dev) for _ in range(2)]
-        self.dynamic = torch.empty(B, 3 * child, nRc, **f32)
         self.bits = rw._new_bits(nRc) if want_masks else None
+        # expand_dynamic=False: no fp32 precedence tensor (``dynamic`` is None, the windows exist as ``bits`` only)
+        self.dynamic = rw._new_dynamic(nRc, self.bits, expand_dynamic)
         self.colsum = torch.empty(B, 3, nRc, **f32) if want_masks and self.bits is None else None
         self.current_mask = torch.empty(B, nRc, **f32) if want_masks else None
         self._err = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -153,7 +164,7 @@ class RollingStepper(object):
         buf = _lib.RollerBuffers()
         for w in range(2):
             buf.static_[w], buf.nodes[w] = self._static[w].data_ptr(), self._nodes[w].data_ptr()
-        buf.dynamic = self.dynamic.data_ptr()
+        buf.dynamic = self.dynamic.data_ptr() if self.dynamic is not None else None
         buf.bits = self.bits.data_ptr() if self.bits is not None else None
         buf.colsum = self.colsum.data_ptr() if self.colsum is not None else None
         buf.current_mask = self.current_mask.data_ptr() if self.current_mask is not None else None
@@ -274,7 +285,8 @@ class RollingDataset(object):
 
 def run_rolling_episode(blocks, positions, initial_container_size, policy, container_width, container_height,
                         child_graph_size=10, reward_type='C+P+S-lb-soft', heightmap_type='diff',
-                        packing_strategy='LB_GREEDY', record=False, fused=True, steppers=None, check='nan'):
+                        packing_strategy='LB_GREEDY', record=False, fused=True, steppers=None, check='nan',
+                        expand_dynamic=True):
     """rolling.validate's loop for a batch (rolling.py:589-637 around DRL.forward(one_step),
     rolling.py:294-460): N - child windows of ONE decoding step each, then a full episode on the
     last window; one long-lived target container per instance.
@@ -287,24 +299,31 @@ def run_rolling_episode(blocks, positions, initial_container_size, policy, conta
     ``fused`` runs on a RollingStepper + pack.EpisodeStepper pair: per decoding step the policy's call and one C
     call (decoder_static, the tour and the picked ids are written by the step's own launch).  ``steppers``: the
     pair returned by an earlier call (``out['steppers']``) to re-use across episodes -- nothing but the relation
-    masks is then allocated per episode, and the returned tensors are views of the pair's buffers."""
+    masks is then allocated per episode, and the returned tensors are views of the pair's buffers.
+
+    ``expand_dynamic=False`` (the step objects only; windows of at most 21 nodes): the windows' precedence tensors are
+    never written as fp32 -- the policy gets ``dynamic=None`` and reads the pair's ``bits`` / ``dynamic_bits`` instead
+    (7 200 of the 9 937 bytes a c5 step moves are that tensor)."""
     rw = RollingWindows(blocks, positions, initial_container_size, child_graph_size)
+    if not expand_dynamic and not (fused and rw._new_bits(rw.child * rw.R) is not None):
+        raise ValueError("expand_dynamic=False runs on the step objects (fused=True) and needs windows with a one-word bit shadow")
     if fused and bits_supported(3 * rw.child, rw.child * rw.R):
         return _run_rolling_steppers(rw, policy, container_width, container_height, reward_type, heightmap_type,
-                                     packing_strategy, record, steppers, check)
+                                     packing_strategy, record, steppers, check, expand_dynamic)
     return _run_rolling_eager(rw, policy, container_width, container_height, reward_type, heightmap_type,
                               packing_strategy, record, fused, check)
 
 
 def _run_rolling_steppers(rw, policy, container_width, container_height, reward_type, heightmap_type, packing_strategy,
-                          record, steppers, check='nan'):
+                          record, steppers, check='nan', expand_dynamic=True):
     B, N, D, child = rw.B, rw.N, rw.D, rw.child
     dev = rw.device
     if steppers is None:
         cs = [container_width, container_height] if D == 2 else [container_width, container_width, container_height]
         env = BatchedContainer(B, cs, N, reward_type, heightmap_type, packing_strategy=packing_strategy, device=dev)
-        roll = RollingStepper(rw, env)
-        last = EpisodeStepper(roll._static[0], roll.dynamic, env, steps=child, tour=roll.tour, tour_col0=N - child)
+        roll = RollingStepper(rw, env, expand_dynamic=expand_dynamic)
+        last = EpisodeStepper(roll._static[0], (B, 3 * child, child * rw.R), env, steps=child, tour=roll.tour,
+                              tour_col0=N - child, expand_dynamic=expand_dynamic)
     else:
         roll, last = steppers
         env = roll.env
