@@ -151,10 +151,16 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 
 template <int D, int G> static int launch_transition(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-#ifndef TAP_TRANS_SW
-#define TAP_TRANS_SW 4   // 4 stream waves: best of 1/2/4/8 for both forms of the update (re-measured in round 4, scripts/ab_transition.sh)
-#endif
+    // Stream waves per workgroup of 8 envs.  2D windows (2 400-byte slabs at n = 10): 4, two slabs per wave (8: c2 1 349 ->
+    // 1 216 M env-steps/s, 1 903 -> 1 753 M at B = 65 536).  3D windows (7 200-byte slabs): 8, one slab per wave -- c3
+    // 507 -> 543 M at B = 4 096, 556 -> 598 M at 8 192, 549 -> 574 M at 16 384, 605 -> 620 M at 65 536, equal from 262 144
+    // (round 5, on the kernels with the compiled-in window shape; round 4 had measured 4 as the best for both at c2's
+    // shape only).  -DTAP_TRANS_SW=n forces one value (scripts/ab_transition.sh).
+#ifdef TAP_TRANS_SW
     return launch_transition_v<D, G, TAP_TRANS_SW>(ctx, a, st);
+#else
+    return launch_transition_v<D, G, (D == 3 ? 8 : 4)>(ctx, a, st);
+#endif
 }
 
 static int transition_dispatch(tap_ctx *ctx, const tap_env_desc *d, const TransArgs &a, void *stream);
