@@ -19,10 +19,14 @@
 //  them perfectly -- 23.6 us.  A window-maximum form of macs_adj (80 instead of 590 instructions, tie-break 5.1 k -> 2.6 k
 //  cycles stand-alone) crossed that line and was dropped; amdgpu_waves_per_eu(7, 8) brings either form to 72 VGPRs but
 //  costs 3 % by itself.)
+#ifndef TAP_MACS_SW
+#define TAP_MACS_SW 4   // stream waves per workgroup of the MACS fused steps (-DTAP_MACS_SW=8, measured in round 5: c4 503 -> 330 M
+                        // env-steps/s, c6 140 -> 129 M -- the wave slots are worth more to the placement waves)
+#endif
 template <int G, int NC, int MODE>
-__global__ void __launch_bounds__((TransGeom<G, 4>::THREADS)) k_transition_macs(TransArgs a)
+__global__ void __launch_bounds__((TransGeom<G, TAP_MACS_SW>::THREADS)) k_transition_macs(TransArgs a)
 {
-    using Geo = TransGeom<G, 4>;
+    using Geo = TransGeom<G, TAP_MACS_SW>;
     constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
     extern __shared__ float trans_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -117,7 +121,7 @@ template <int G> struct M3Spread { static constexpr bool on = G == 32; };
 template <int G> struct M3Spread { static constexpr bool on = false; };
 #endif
 template <int G> struct M3Geo {
-    using Geo = TransGeom<G, 4>;
+    using Geo = TransGeom<G, TAP_MACS_SW>;
     static constexpr bool SPREAD = M3Spread<G>::on;
     static constexpr int EPB = SPREAD ? 4 : Geo::EPB, SPW = SPREAD ? 2 : Geo::SPW, ENV_WAVES = SPREAD ? 4 : Geo::ENV_WAVES;
     static constexpr int GROUPS = SPREAD ? 8 : Geo::EPB;                      // LDS regions (the idle halves get one too)
@@ -185,7 +189,7 @@ int tap_macs_validate(tap_ctx *ctx, const tap_env_desc &d); // macs.hip
 
 template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 {
-    constexpr int EPB = TransGeom<G, 4>::EPB, THREADS = TransGeom<G, 4>::THREADS;
+    constexpr int EPB = TransGeom<G, TAP_MACS_SW>::EPB, THREADS = TransGeom<G, TAP_MACS_SW>::THREADS;
     const int grid = (a.s.d.B + EPB - 1) / EPB;
     if (grid == 0) return TAP_OK;
     const size_t lds = (size_t)EPB * 3 * a.m.nR * sizeof(float) +
