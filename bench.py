@@ -676,15 +676,18 @@ def time_passes(hps, steps, warmup, use_graph, world, repeats=1):
     drain()
     dts, local_dts = [], []
     for _ in range(max(1, repeats)):
-        # one bracket = EXACTLY `steps` passes between barrier + synchronize on both sides, MAX over ranks
+        # one bracket = EXACTLY `steps` passes between barrier + synchronize on both sides, MAX over ranks.  A rank's clock
+        # stops when ITS work (exchange included) is complete, the closing barrier follows and the job's time is the MAX
+        # over the ranks: the barrier's own latency (an RCCL all-reduce) is not part of any rank's `steps` passes, and the
+        # per-rank figures in `ranks.per_rank` stay each rank's own.
         tdist.barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         run(steps)
         drain()
         torch.cuda.synchronize(dev)
-        tdist.barrier()
         local_dt = time.perf_counter() - t0
+        tdist.barrier()
         local_dts.append(local_dt)
         dts.append(tdist.max_over_ranks(local_dt, dev))
     hp.bracket_times = dts
