@@ -74,8 +74,8 @@ def short_name(k):
     m = re.match(r"(?:void )?k_(?:big_|macs2d_wave_|macs3d_wave_)?transition(?:_macs3?)?<(.*)>", k)
     if m:
         targs = [x.strip() for x in m.group(1).split(",")]
-        # the form is the last template argument, except k_transition_macs3<G, NC, MODE, WL> (compile-time sides last)
-        mode = targs[2] if ("transition_macs3<" in k and len(targs) == 4) else targs[-1]
+        # the form is the last template argument, except k_transition_macs[3]<G, NC, MODE, WC | WL> (compile-time width / sides last)
+        mode = targs[2] if ("transition_macs" in k and len(targs) == 4) else targs[-1]
         # & 3: the form; 4 = TAP_MODE_MERGED (the run-of-rows expansion, round 5)
         mode = str(int(mode) & 3) if mode.isdigit() else mode
         return {"0": "transition_copy", "1": "transition", "2": "transition_first"}.get(mode, "transition")

@@ -128,12 +128,13 @@ static __device__ unsigned int tap_prof_m2[8192 * 8];
 // Every lane keeps the whole height-map in registers and derives per-level column bitmasks
 // (free: hm <= z, on: hm == z) from it, so runs, supports, footprint tests and stability are bit
 // operations; LDS only holds the EMS list, the slot list and the per-level `taken` masks.
-template <int G>
+// WC != 0: the container's width known at compile time (instantiated for c4's W = 7: 15.85 -> 15.46 us per fused step).
+template <int G, int WC = 0>
 __device__ inline Placement tap_macs_place(const PlaceCfg &c, const MacsLds &L, int cell, int gl0,
                                            int &hm, Counters &cnt, int &err, int bx, int bz,
                                            bool do_step)
 {
-    const int W = c.W, H = c.H, ems_cap = L.ems_cap;
+    const int W = WC ? WC : c.W, H = c.H, ems_cap = L.ems_cap;
     const bool incell = cell < W;
     Placement res = {0, 0, 0, 0, 0};
     if (!do_step) return res;

@@ -452,9 +452,9 @@ __device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v 
 //  cache-resident buffer, 6.14 against 4.02 us on fresh ones, profiles/r04_bw_store_shapes.json); the kernel did not
 //  agree: c2 1 295 -> 1 268 M env-steps/s, c3 520 -> 478 M, cold passes 1 009 -> 992 M, and 10-15 % slower from
 //  B = 128 k up -- the LDS read and the index arithmetic in front of every store cost more than the half lines.)
-// C4S != 0: the reference's own window -- n = 10 nodes, rows = 30, nR = 4 C4S columns (C4S = 5: 2D, 15: 3D) -- with its
-// shape known at compile time: the expansion's loop unrolls, the row / column arithmetic folds.  Same session, same
-// tree: c2 1 280 -> 1 337-1 346 M env-steps/s, c3 500 -> 506 M.
+// C4S != 0: a BASELINE window with its shape known at compile time -- C4S = 5 / 15: n = 10 nodes, rows = 30, nR = 20 (2D) /
+// 60 (3D) columns; C4S = 10: n = 20, rows = 60, nR = 40 (c4's 2D window) --: the expansion's loop unrolls, the row / column
+// arithmetic folds.  Same session, same tree: c2 1 280 -> 1 337-1 346 M env-steps/s, c3 500 -> 506 M, c4 496 -> 504 M.
 template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0>
 __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
                                                  float *lds = nullptr)
@@ -462,7 +462,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     typedef unsigned long long u64;
     static_assert(NS <= 2, "a stream wave expands one or two slabs");
     if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
-    const int nR = C4S ? 4 * C4S : a.nR, C4 = C4S ? C4S : nR >> 2, rows = C4S ? 30 : a.rows, n = C4S ? 10 : a.n;
+    const int nR = C4S ? 4 * C4S : a.nR, C4 = C4S ? C4S : nR >> 2, rows = C4S ? (C4S == 10 ? 60 : 30) : a.rows, n = C4S ? (C4S == 10 ? 20 : 10) : a.n;
     const int RP = C4S ? 64 / C4S : a.rp;
     const int c4_magic = C4S ? 65536 / C4S + 1 : a.c4_magic;
     const bool lane_on = lane < RP * C4;

@@ -24,15 +24,17 @@ struct TransArgs {
 // stream_wave_bits, where the A/B figures are) instead of slab by slab
 // MODE & 8 / & 16 (TAP_MODE_C4_5 / _15): the window is the reference's own -- n = 10, rows = 30, nR = 20 (2D) / 60 (3D) --
 // and its shape is compiled in (stream_wave_bits_r4: C4S); the launcher checks the shape
-constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16;
+// (both bits, TAP_MODE_C4_10: c4's window, n = 20, rows = 60, nR = 40 -- the MACS 2D step, transition_macs.hip)
+constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16, TAP_MODE_C4_10 = 24;
 __host__ __device__ constexpr int tap_mode_shape(int D) { return D == 2 ? TAP_MODE_C4_5 : TAP_MODE_C4_15; }
 inline bool tap_mode_shape_ok(const MaskArgs &m, int D) { return m.n == 10 && m.rows == 30 && m.nR == (D == 2 ? 20 : 60); }
+inline bool tap_mode_shape20_ok(const MaskArgs &m) { return m.n == 20 && m.rows == 60 && m.nR == 40; }
 template <int SPW, int NC, int MODE_>
 __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
 {
     constexpr int MODE = MODE_ & 3;
     constexpr bool MERGED = (MODE_ & TAP_MODE_MERGED) != 0;
-    constexpr int C4S = (MODE_ & TAP_MODE_C4_5) ? 5 : (MODE_ & TAP_MODE_C4_15) ? 15 : 0;
+    constexpr int C4S = (MODE_ & TAP_MODE_C4_10) == TAP_MODE_C4_10 ? 10 : (MODE_ & TAP_MODE_C4_5) ? 5 : (MODE_ & TAP_MODE_C4_15) ? 15 : 0;
     static_assert(C4S == 0 || NC == 1, "the compiled-in window shapes have one column per lane");
     bool on[SPW];
 #pragma unroll

@@ -23,7 +23,8 @@
 #define TAP_MACS_SW 4   // stream waves per workgroup of the MACS fused steps (-DTAP_MACS_SW=8, measured in round 5: c4 503 -> 330 M
                         // env-steps/s, c6 140 -> 129 M -- the wave slots are worth more to the placement waves)
 #endif
-template <int G, int NC, int MODE>
+// WC: 0, or the container's width known at compile time (tap_macs_place; BASELINE configs[3]'s W = 7 with its n = 20 window)
+template <int G, int NC, int MODE, int WC = 0>
 __global__ void __launch_bounds__((TransGeom<G, TAP_MACS_SW>::THREADS)) k_transition_macs(TransArgs a)
 {
     using Geo = TransGeom<G, TAP_MACS_SW>;
@@ -31,7 +32,7 @@ __global__ void __launch_bounds__((TransGeom<G, TAP_MACS_SW>::THREADS)) k_transi
     extern __shared__ float trans_lds[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
-    const int B = a.s.d.B, W = a.s.d.W, H = a.s.d.H;
+    const int B = a.s.d.B, W = WC ? WC : a.s.d.W, H = a.s.d.H;
     if (wave >= ENV_WAVES) {
         trans_stream_wave<SPW, NC, MODE>(a.m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * a.m.nR);
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__((TransGeom<G, TAP_MACS_SW>::THREADS)) k_transi
     tap_wave_lds_sync();
     const int step = cnt.count;
     const PlaceCfg cfg = {W, 1, H, a.s.d.flags, nullptr};
-    const Placement pl = tap_macs_place<G>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
+    const Placement pl = tap_macs_place<G, WC>(cfg, L, cell, gl0, hm, cnt, err, bx, bz, do_step);
     err = group_or<G>(err);
     tap_wave_lds_sync();
     L.hm[cell] = hm;
@@ -196,8 +197,14 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
                        (size_t)EPB * macs_group_words(G, a.s.d.H, a.s.d.n_max, a.s.d.W) * sizeof(int);
     if (lds > tap_lds_limit(ctx)) return tap_fail(ctx, TAP_E_UNSUPPORTED, "transition(MACS): %zu bytes of LDS needed", lds);
     const int mode = a.m.bits_in ? 1 : mask_builds_bits(a.m) ? 2 : 0;
-#define TAP_LAUNCH_T(NC_, M_, LDS_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs<G, NC_, M_>, LDS_)); \
-        hipLaunchKernelGGL((k_transition_macs<G, NC_, M_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
+    // BASELINE configs[3] (c4: W = 7, windows of 20 nodes) on the bit shadow runs the instantiation with the width and
+    // the window's shape compiled in
+    const bool c4shape = G == 8 && a.s.d.W == 7 && tap_mode_shape20_ok(a.m);
+#define TAP_LAUNCH_K(NC_, M_, LDS_, WC_) do { TAP_HIP_CHECK(ctx, tap_allow_lds(k_transition_macs<G, NC_, M_, WC_>, LDS_)); \
+        hipLaunchKernelGGL((k_transition_macs<G, NC_, M_, WC_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
+#define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr (G == 8 && (NC_) == 1 && ((M_) & 3) != 0) { \
+            if (c4shape) TAP_LAUNCH_K(NC_, ((M_) | TAP_MODE_C4_10), LDS_, 7); else TAP_LAUNCH_K(NC_, M_, LDS_, 0); } \
+        else TAP_LAUNCH_K(NC_, M_, LDS_, 0); } while (0)
 #define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 5, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 6, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)   /* 5 / 6: TAP_MODE_MERGED, the run-of-rows expansion (c4: 504 against 490 M env-steps/s) */
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
@@ -207,6 +214,8 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
     }
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
+#undef TAP_LAUNCH_K
+    (void)c4shape;
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs");
     return TAP_OK;
 }
