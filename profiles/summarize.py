@@ -24,47 +24,6 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag, cfg = sys.argv[1], sys.argv[2]
-src = os.path.join(ROOT, "gpurun_out")
-# the --stats summary, our kernels row by row, everything else (torch / rocprim / runtime copy and fill kernels of the
-# set-up code) summed in one line
-rows = list(csv.DictReader(open(os.path.join(src, "prof_%s" % tag, "%s_kernel_stats.csv" % cfg))))
-import re
-ours = [r for r in rows if re.match(r"^(void )?k_", r["Name"])]
-rest = [r for r in rows if r not in ours]
-with open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)), "w") as f:
-    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
-    w.writeheader()
-    for r in ours:
-        w.writerow(r)
-    if rest:
-        tot = sum(float(r["TotalDurationNs"]) for r in rest)
-        calls = sum(int(r["Calls"]) for r in rest)
-        w.writerow({"Name": "(other: %d torch / rocprim / runtime kernels of the set-up code)" % len(rest), "Calls": calls,
-                    "TotalDurationNs": int(tot), "AverageNs": tot / max(calls, 1),
-                    "Percentage": round(sum(float(r["Percentage"]) for r in rest), 4), "MinNs": "", "MaxNs": "", "StdDev": ""})
-means = collections.defaultdict(dict)
-for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    path = os.path.join(src, "prof_%s_%s" % (tag, kind), "%s_counter_collection.csv" % cfg)
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter:
-            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        means[k][counter] = sum(v) / len(v)
-        means[k]["calls_" + counter] = len(v)
-with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.csv" % (tag, cfg)), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["Kernel_Name", "calls", "FETCH_SIZE_KiB_mean_raw", "WRITE_SIZE_KiB_mean", "HBM_bytes_per_launch=(2*FETCH+WRITE)*1024"])
-    for k, m in sorted(means.items()):
-        fs, ws = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
-        w.writerow([k, m.get("calls_FETCH_SIZE", 0), "%.3f" % fs, "%.3f" % ws, int((2 * fs + ws) * 1024)])
-tpath = os.path.join(ROOT, "profiles", "traffic.json")
-traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
-# per-kernel average duration from the --stats pass of the same command
-avg_ns = {}
-for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))):
-    avg_ns[r["Name"]] = float(r["AverageNs"])
 
 
 def short_name(k):
@@ -89,21 +48,70 @@ def short_name(k):
     return None
 
 
-for k, m in means.items():
-    name = short_name(k)
-    if name is None:
-        continue
-    traffic["%s:%s" % (cfg, name)] = dict(
-        bytes=int((2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024), profile=tag,
-        kernel_us=round(avg_ns.get(k, 0.0) / 1e3, 3) or None, kernel=k[:80])
-traffic["_note"] = ("per-launch HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes and the "
-                    "kernel's average duration from the --kernel-trace --stats pass of the same bench.py command; "
-                    "`profile` names the profile set (profiles/<profile>_<config>_*.csv) the entry comes from")
-traffic["_source"] = "profiles/summarize.py"
-json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
-# bench lines under profiles/ come from clean runs (gpurun_out/bench_<tag>/<cfg>.json), never from the
-# profiled run, whose timings the tracer perturbs
-bj = os.path.join(src, "bench_%s" % tag, "%s.json" % cfg)
-if os.path.exists(bj) and os.path.getsize(bj):
-    shutil.copy(bj, os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, cfg)))
-print(json.dumps({k: v for k, v in traffic.items() if k.startswith(cfg + ":")}, indent=1))
+def main():
+    global tag, cfg
+    tag, cfg = sys.argv[1], sys.argv[2]
+    src = os.path.join(ROOT, "gpurun_out")
+    # the --stats summary, our kernels row by row, everything else (torch / rocprim / runtime copy and fill kernels of the
+    # set-up code) summed in one line
+    rows = list(csv.DictReader(open(os.path.join(src, "prof_%s" % tag, "%s_kernel_stats.csv" % cfg))))
+    import re
+    ours = [r for r in rows if re.match(r"^(void )?k_", r["Name"])]
+    rest = [r for r in rows if r not in ours]
+    with open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)), "w") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()), quoting=csv.QUOTE_NONNUMERIC)
+        w.writeheader()
+        for r in ours:
+            w.writerow(r)
+        if rest:
+            tot = sum(float(r["TotalDurationNs"]) for r in rest)
+            calls = sum(int(r["Calls"]) for r in rest)
+            w.writerow({"Name": "(other: %d torch / rocprim / runtime kernels of the set-up code)" % len(rest), "Calls": calls,
+                        "TotalDurationNs": int(tot), "AverageNs": tot / max(calls, 1),
+                        "Percentage": round(sum(float(r["Percentage"]) for r in rest), 4), "MinNs": "", "MaxNs": "", "StdDev": ""})
+    means = collections.defaultdict(dict)
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        path = os.path.join(src, "prof_%s_%s" % (tag, kind), "%s_counter_collection.csv" % cfg)
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] == counter:
+                acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        for k, v in acc.items():
+            means[k][counter] = sum(v) / len(v)
+            means[k]["calls_" + counter] = len(v)
+    with open(os.path.join(ROOT, "profiles", "%s_%s_pmc_summary.csv" % (tag, cfg)), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "calls", "FETCH_SIZE_KiB_mean_raw", "WRITE_SIZE_KiB_mean", "HBM_bytes_per_launch=(2*FETCH+WRITE)*1024"])
+        for k, m in sorted(means.items()):
+            fs, ws = m.get("FETCH_SIZE", 0.0), m.get("WRITE_SIZE", 0.0)
+            w.writerow([k, m.get("calls_FETCH_SIZE", 0), "%.3f" % fs, "%.3f" % ws, int((2 * fs + ws) * 1024)])
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    # per-kernel average duration from the --stats pass of the same command
+    avg_ns = {}
+    for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (tag, cfg)))):
+        avg_ns[r["Name"]] = float(r["AverageNs"])
+
+
+    for k, m in means.items():
+        name = short_name(k)
+        if name is None:
+            continue
+        traffic["%s:%s" % (cfg, name)] = dict(
+            bytes=int((2 * m.get("FETCH_SIZE", 0.0) + m.get("WRITE_SIZE", 0.0)) * 1024), profile=tag,
+            kernel_us=round(avg_ns.get(k, 0.0) / 1e3, 3) or None, kernel=k[:80])
+    traffic["_note"] = ("per-launch HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes and the "
+                        "kernel's average duration from the --kernel-trace --stats pass of the same bench.py command; "
+                        "`profile` names the profile set (profiles/<profile>_<config>_*.csv) the entry comes from")
+    traffic["_source"] = "profiles/summarize.py"
+    json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
+    # bench lines under profiles/ come from clean runs (gpurun_out/bench_<tag>/<cfg>.json), never from the
+    # profiled run, whose timings the tracer perturbs
+    bj = os.path.join(src, "bench_%s" % tag, "%s.json" % cfg)
+    if os.path.exists(bj) and os.path.getsize(bj):
+        shutil.copy(bj, os.path.join(ROOT, "profiles", "%s_%s_bench.json" % (tag, cfg)))
+    print(json.dumps({k: v for k, v in traffic.items() if k.startswith(cfg + ":")}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
