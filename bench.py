@@ -1668,6 +1668,14 @@ def main():
         mp.spawn(_spawned_rank, args=(sys.argv[1:], args.gpus, _free_port()), nprocs=args.gpus, join=True)
         return
 
+    # THE line must be alone on stdout, and libraries write there too: RCCL prints a five-line version banner on stdout
+    # (C stdio) from its first collective in a process -- seen on this stack with a 1-rank "nccl" group --, HIP and torch
+    # may warn there.  From here on file descriptor 1 of this rank IS stderr; rank 0 writes the one JSON line to the
+    # original descriptor at the end.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank, world, local = tdist.init_from_env()
     if world != args.gpus:
         if rank == 0:
@@ -1824,10 +1832,11 @@ def main():
         if args.sweep and hp.kind == "transition":
             run_sweep(cfg, hp, dev, use_graph, args.sweep_out,
                       [int(x) for x in args.sweep_batches.split(",")] if args.sweep_batches else None)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     tdist.barrier()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
     if not ok_all:
         sys.exit(1)
