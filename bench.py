@@ -1393,7 +1393,71 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
         out["no_fp32_expand"] = dict(error=str(ex)[:300])
     finally:
         T.pack.set_binary_check('check')
+    # (e) TAP_BENCH_TWO_CHAINS=1: the same batch as TWO half-batch chains on two streams of one graph.  Measured in round 6
+    #     (profiles/r06_two_chains.json): 1.02 G env-steps/s against the lock-step 1.35 G -- the chains' kernels do not
+    #     overlap (4.0 us per 4 096-env launch, one after the other), so splitting the batch only doubles the launches
+    if os.environ.get("TAP_BENCH_TWO_CHAINS") == "1" and use_graph:
+        try:
+            trace("two_chains")
+            out["two_chains"] = two_chain_reading(cfg, hp, dev)
+        except Exception as ex:                              # pragma: no cover
+            out["two_chains"] = dict(error=str(ex)[:300])
     return out
+
+
+def two_chain_reading(cfg, hp, dev, chains=2, steps=200):
+    """The headline's batch stepped as `chains` independent sub-batch chains, each on its own stream inside ONE hipGraph
+    (fork at the graph's head, join at its tail): a chain's step t + 1 waits for ITS step t only, so one chain's kernel
+    boundary (drain, cache write-back, the next dispatch: ~1.8 us of a ~6 us step) is covered by the other chain's
+    kernel.  This is NOT the reference's loop shape -- model.py:342-496 runs one policy call per decoding step for the
+    whole batch, which joins the chains at every step -- it is what a trainer that pipelines two micro-batches through
+    the policy would see, and it bounds what the launch boundaries cost the lock-step headline.  Result (round 6, MI355X,
+    ROCm 7.2): the two branches' kernels run one after the other -- 80.4 us per pass of 2 x 10 launches against 60.5 us for
+    the 10 lock-step launches -- so the variant is off by default (TAP_BENCH_TWO_CHAINS=1)."""
+    name, D, cs, n, B, reward, strategy = cfg
+    per = B // chains
+    hs = [HotPath(cfg, per, k * per, dev, fused=hp.fused, window=hp.nw, bits=hp.bits, instances=hp.instances) for k in range(chains)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(chains - 1)]
+    warm = torch.cuda.Stream(device=dev)
+    warm.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(warm):
+        for h in hs:
+            h.episode()
+    torch.cuda.current_stream(dev).wait_stream(warm)
+    torch.cuda.synchronize(dev)
+    ge = getattr(hp, "passes_per_graph", GATHER_EVERY)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream(dev)
+        for s in streams:
+            s.wait_stream(main)                                # fork
+        for k, h in enumerate(hs):
+            with torch.cuda.stream(main if k == 0 else streams[k - 1]):
+                for _ in range(ge):
+                    h.episode()
+        for s in streams:
+            main.wait_stream(s)                                # join
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize(dev)
+    reps = max(1, steps // ge)
+    dts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize(dev)
+        dts.append(time.perf_counter() - t0)
+    dt = statistics.median(dts)
+    ver = [h.verify() for h in hs]
+    pass_us = dt / (reps * ge) * 1e6
+    return dict(value=per * chains * n * reps * ge / dt, unit="env-steps/s", chains=chains, batch_per_chain=per,
+                pass_us=pass_us, passes=reps * ge, verified=all(v.get("verified") for v in ver),
+                what="the same B envs as %d independent chains of %d envs, one stream each inside one hipGraph (fork / "
+                     "join once per %d passes): a chain's next step waits for its own previous step only, so kernel "
+                     "boundaries overlap the other chain's kernels.  Not the reference's loop (one policy call per "
+                     "step for the whole batch joins the chains every step); the headline is the lock-step figure"
+                     % (chains, per, ge))
 
 
 def run_sweep(cfg, hp, dev, use_graph, path, batches=None):

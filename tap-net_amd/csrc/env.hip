@@ -139,9 +139,16 @@ extern "C" int tap_env_desc_init(tap_env_desc *d, int B, int D, const int32_t *c
     if (strchr(reward, 'S')) d->flags |= TAP_F_USE_S;              // tools.py:2138
     if (!strncmp(reward, "mcs", 3)) d->flags |= TAP_F_MCS_ZERO;    // tools.py:2709
     if (strstr(reward, "mcs")) d->flags |= TAP_F_MCS_TIE;          // tools.py:2718
-    // TAP_AB_NO_TIE=1 (timing experiments only -- the placements then differ from the reference's): 'mcs' without its
-    // usable-space tie-break, to bound what that phase costs inside a launch
-    if (getenv("TAP_AB_NO_TIE")) d->flags &= ~TAP_F_MCS_TIE;
+#ifdef TAP_AB_BUILD
+    // A/B builds only (-DTAP_AB_BUILD, scripts/ab_transition.sh; never in the product library, whose results no
+    // environment variable can change): TAP_AB_NO_TIE=1 runs 'mcs' without its usable-space tie-break -- the placements
+    // then differ from the reference's -- to bound what that phase costs inside a launch
+    if (getenv("TAP_AB_NO_TIE")) {
+        static bool warned = false;
+        if (!warned) { fprintf(stderr, "libtapenv (A/B build): TAP_AB_NO_TIE is set -- 'mcs' placements differ from the reference's\n"); warned = true; }
+        d->flags &= ~TAP_F_MCS_TIE;
+    }
+#endif
     // tools.py:3919-3964
     struct { const char *name; int mode; } table[] = {
         {"comp", TAP_R_C}, {"soft", TAP_R_CxS}, {"hard", TAP_R_CxS}, {"pyrm", TAP_R_CP},

@@ -116,6 +116,30 @@ __global__ void __launch_bounds__((TransGeom<G, TAP_MACS_SW>::THREADS)) k_transi
 // -DTAP_M3_SPREAD (A/B builds): ONE container per placement wave at G = 32 -- the wave's second lane group idles on an
 // out-of-range env -- so that B = 4096 puts four placement waves on a SIMD instead of two, each running only its own
 // container's loop trips.
+// Loop form of the fp32 expansion in the MACS steps' stream waves: 5 / 6 = shadow (given / built) | TAP_MODE_MERGED, the
+// run-of-rows loop; 1 / 2 = slab by slab.  Round 6, same session, two runs each (profiles/r06_macs_merge_ab.txt), M env-steps/s,
+// run-of-rows against slab-by-slab: MACS 2D (c4's shape) 518.6 / 518.0 against 508.7 / 511.8 at B = 8 192, 461.8 / 482.5
+// against 467.7 / 482.8 at 32 768 (nontemporal stores from here on), 533.4 / 526.0 against 518.8 / 519.6 at 131 072 -- the
+// run-of-rows loop at every batch, unlike the LB_GREEDY step (transition.hip), whose 2D windows lose 15-20 % with it once
+// the stores are nontemporal; MACS 3D (c6's shape, nR = 60) 139.8 / 139.7 against 139.9 / 140.1 at B = 4 096, 195.2 / 195.6
+// against 197.2 / 197.8 at 32 768, 222.9 / 222.9 against 225.8 / 225.8 at 131 072 -- slab by slab, as for the LB_GREEDY
+// step's 3D windows.  -DTAP_MACS_NOMERGE / -DTAP_MACS_MERGE_ALL force one form everywhere (A/B builds).
+#if defined(TAP_MACS_NOMERGE)
+#define TAP_MACS_M1 1
+#define TAP_MACS_M2 2
+#define TAP_MACS3_M1 1
+#define TAP_MACS3_M2 2
+#elif defined(TAP_MACS_MERGE_ALL)
+#define TAP_MACS_M1 5
+#define TAP_MACS_M2 6
+#define TAP_MACS3_M1 5
+#define TAP_MACS3_M2 6
+#else
+#define TAP_MACS_M1 5
+#define TAP_MACS_M2 6
+#define TAP_MACS3_M1 1
+#define TAP_MACS3_M2 2
+#endif
 #ifdef TAP_M3_SPREAD
 template <int G> struct M3Spread { static constexpr bool on = G == 32; };
 #else
@@ -171,7 +195,7 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
         hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_, WL_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr (G == 32) { if (wl5) TAP_LAUNCH_W(NC_, M_, LDS_, 5); else TAP_LAUNCH_W(NC_, M_, LDS_, 0); } \
         else TAP_LAUNCH_W(NC_, M_, LDS_, 0); } while (0)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 5, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 6, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)   /* 5 / 6: TAP_MODE_MERGED, the run-of-rows expansion (c4: 504 against 490 M env-steps/s) */
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, TAP_MACS3_M1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, TAP_MACS3_M2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;
@@ -205,7 +229,7 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr (G == 8 && (NC_) == 1 && ((M_) & 3) != 0) { \
             if (c4shape) TAP_LAUNCH_K(NC_, ((M_) | TAP_MODE_C4_10), LDS_, 7); else TAP_LAUNCH_K(NC_, M_, LDS_, 0); } \
         else TAP_LAUNCH_K(NC_, M_, LDS_, 0); } while (0)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, 5, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, 6, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)   /* 5 / 6: TAP_MODE_MERGED, the run-of-rows expansion (c4: 504 against 490 M env-steps/s) */
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, TAP_MACS_M1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, TAP_MACS_M2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;

@@ -239,7 +239,7 @@ class BatchedContainer(object):
 # use, at the end of a lockstep_scope, or at the next lockstep_containers call).  A Container that was collected before
 # the pool's first use is not waited for; one that is alive but never called (a probe built with the same arguments
 # outside a scope) makes the first "second call" raise LockstepError and is dropped -- rows are handed out holding a
-# sentinel (int64 min), never stale memory.  The 'mul' input types pool containers_a and containers_b together
+# sentinel (int64 min), never stale memory; the raising call is recorded in the new round first (its row: err.row).  The 'mul' input types pool containers_a and containers_b together
 # (model.py:290-292 builds them alternately with the same arguments): every env calls exactly one method on each of
 # its two Containers per step (model.py:419-427), so a round is 2 * batch_size calls.
 import os as _os
@@ -332,12 +332,22 @@ class _Pool(object):
             self.flush()
             if phantom.any():
                 self.live &= ~phantom
-                raise LockstepError(
+                # the call that found the phantoms is the first call of the NEXT round: it is recorded there before the
+                # error leaves (a caller that catches the error and goes on must not end up with this container one
+                # step behind the others); its result row rides on the exception
+                err = LockstepError(
                     "%d of the %d Containers of this lock-step pool were never called: the round could not complete on "
                     "its last call and its rows were filled late.  Build the pooled Containers inside "
                     "`with tools.lockstep_scope():` (or call tools.lockstep_containers(True) right before model.py:294 "
                     "builds them) so that no other Container with the same arguments joins the pool.  The phantom "
-                    "members have been dropped; the next rounds are complete." % (int(phantom.sum()), self.members))
+                    "members have been dropped and the next rounds are complete; THIS call was recorded as the first of "
+                    "the next round -- do not re-issue it, its result row is the exception's `.row` (filled when that "
+                    "round completes)." % (int(phantom.sum()), self.members))
+                err.row = self._record(i, block)
+                raise err
+        return self._record(i, block)
+
+    def _record(self, i, block):
         if self.out is None:
             self.out = np.full((self.members,) + self._fshape, _UNFILLED, np.int64)
         if block is not None:

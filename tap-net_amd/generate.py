@@ -73,13 +73,19 @@ def _pack_blocks_stepped(blocks, container_size, reward_type, dev):
     from .env import BatchedContainer
     B, n, D = blocks.shape
     env = BatchedContainer(B, container_size, n, reward_type, 'full', packing_strategy='LB_GREEDY', device=dev)
+    active = (blocks >= 1).all(dim=2)                                               # (B, n): is list entry t a block
     for t in range(n):
-        blk = blocks[:, t].contiguous()
-        env.add_new_blocks(blk, active=(blk >= 1).all(dim=1), want_feature=False)
+        env.add_new_blocks(blocks[:, t].contiguous(), active=active[:, t].contiguous(), want_feature=False)
     cps = env.calc_CPS()
     score = torch.where(env.counters[:, 3] > 0, (cps[:, 0] + cps[:, 1]) + cps[:, 2], torch.zeros_like(cps[:, 0]))
     rew = torch.where(env.errors != 0, torch.full_like(score, float('nan')), -score).to(torch.float32)
-    return env.positions, env.stable, rew
+    # the container files its placements by placement count; tap_pack_blocks writes list index t (zeros for the entries
+    # that are not blocks): the k-th active entry of a list takes slot k - 1
+    slot = (active.long().cumsum(dim=1) - 1).clamp_(min=0)
+    pos = torch.gather(env.positions, 1, slot.unsqueeze(2).expand(B, n, D))
+    pos = torch.where(active.unsqueeze(2), pos, torch.zeros_like(pos))
+    st = torch.gather(env.stable.to(torch.uint8), 1, slot).bool() & active
+    return pos, st, rew
 
 
 def precedence_tensors(blocks, positions, container_size, arm_size=1):
@@ -180,7 +186,7 @@ def gauss_split_table(max_len, size_range=(1, 5), device='cuda'):
 def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7, initial_container_height=50,
                                target_container_width=7, size_range=(1, 5), seed=12345, start=0, heights=None,
                                device='cuda', max_generations=4000, return_stats=False, input_type='bot',
-                               mean_block_area=(4.9, 8.4)):
+                               mean_block_area=(4.9, 8.4), arm_size=1):
     """B perfect-packing instances (2D) as generate.generate_blocks_with_GT builds them for block_dim 2
     (generate.py:57-161 with BPP_Generator_2D_easy, :392-484): a guillotine-cut perfect packing of a
     target_width x H box, a random take-apart order with random rotations, packed in that order into the initial
@@ -194,7 +200,11 @@ def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7
     20 .. 24; from H = 27 the cut generator itself accepts fewer than 1e-3 of its draws) -- the reference's own loop
     simply runs that long.  When the heights are drawn here, the distribution is therefore restricted to those
     with ``mean_block_area[0] <= W*H/n <= mean_block_area[1]`` (H = 14 .. 24 at 20 blocks: 90 % of the reference's
-    distribution) and re-normalised; pass ``mean_block_area=None`` for all of it."""
+    distribution) and re-normalised; pass ``mean_block_area=None`` for all of it.
+
+    ``arm_size`` (generate.py:623-641, 2D only): columns the arm needs beside a block; it enters the take-apart test
+    through the left / right relations (the take-apart ORDER of the perfect packing uses movement dependences only,
+    generate.py:77, which do not depend on it)."""
     dev = _lib.resolve_device(device)
     n, B, W = int(blocks_num), int(batch_size), int(target_container_width)
     if n > 64:
@@ -258,7 +268,7 @@ def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7
                 _lib.check(L.tap_ppsg_order2d(c, k, n, _lib.ptr(sb), _lib.ptr(sp), int(seed), _lib.ptr(si), 0, gen, trial,
                                               _lib.ptr(blocks), _lib.stream_of(dev)), c)
             pos, stable, rew = pack_blocks(blocks, cs)                               # generate.py:108
-            rw = RollingWindows(blocks, pos, cs, child_graph_size=1)                # the relations (:111-112)
+            rw = RollingWindows(blocks, pos, cs, child_graph_size=1, arm_size=int(arm_size))   # the relations (:111-112)
             ok = torch.empty(k, dtype=torch.uint8, device=dev)
             st8 = stable.to(torch.uint8).contiguous()
             with torch.cuda.device(dev):
@@ -279,7 +289,8 @@ def generate_ppsg_instances_2d(batch_size, blocks_num, initial_container_width=7
 
 def generate_ppsg_instances(batch_size, blocks_num, initial_container_width=7, initial_container_height=50,
                             target_container_width=5, size_range=(1, 5), seed=12345, start=0, slab_blocks=10,
-                            heights=None, device='cuda', max_generations=50, return_stats=False, input_type='bot'):
+                            heights=None, device='cuda', max_generations=50, return_stats=False, input_type='bot',
+                            arm_size=1):
     """B perfect-packing instances (3D) as generate.generate_blocks_with_GT builds them (generate.py:57-161):
     a guillotine-cut perfect packing of a target_width^2 x H box (BPP_Generator_3D + its acceptance test), a
     random take-apart order with random rotations, the blocks packed in that order into the initial container
@@ -358,7 +369,8 @@ def generate_ppsg_instances(batch_size, blocks_num, initial_container_width=7, i
                 _lib.check(L.tap_ppsg_order(c, k, n, _lib.ptr(sb), _lib.ptr(sp), int(seed), _lib.ptr(si), 0, gen, trial,
                                             _lib.ptr(blocks), _lib.stream_of(dev)), c)
             pos, stable, rew = pack_blocks(blocks, cs)                               # generate.py:108
-            rw = RollingWindows(blocks, pos, cs, child_graph_size=1)                # the five relations (:111-112)
+            # (arm_size is read by calc_dependent's 2D rule only, generate.py:623-641; passed on for symmetry)
+            rw = RollingWindows(blocks, pos, cs, child_graph_size=1, arm_size=int(arm_size))   # the five relations (:111-112)
             ok = torch.empty(k, dtype=torch.uint8, device=dev)
             st8 = stable.to(torch.uint8).contiguous()
             with torch.cuda.device(dev):

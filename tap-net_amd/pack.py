@@ -1038,8 +1038,8 @@ def create_dataset_gt(blocks_num, train_size, valid_size, obj_dim, target_contai
     (pack.py:516-518)."""
     from . import generate, datafiles
     blocks_num = int(blocks_num)
-    if int(arm_size) != 1:
-        raise NotImplementedError("perfect-packing instances are generated for arm_size 1 (the reference's default)")
+    if int(arm_size) < 1:
+        raise ValueError("arm_size >= 1")
     if seed is None:
         seed = np.random.randint(123456789)
     np.random.seed(seed)                                                          # pack.py:486
@@ -1051,7 +1051,7 @@ def create_dataset_gt(blocks_num, train_size, valid_size, obj_dim, target_contai
         rs.shuffle(ids)
         if _have(data_dir):
             continue
-        kw = dict(seed=(int(seed) + 7919 * k) % (2 ** 31), device=device, input_type=input_type)
+        kw = dict(seed=(int(seed) + 7919 * k) % (2 ** 31), device=device, input_type=input_type, arm_size=int(arm_size))
         if obj_dim == 2:
             # the height restriction of generate_ppsg_instances_2d's default is tuned for size_range (1, 5) at 20 blocks;
             # any other request draws from the reference's whole height distribution

@@ -14,7 +14,7 @@ from .rollout import _flagged_reward
 
 
 class RollingWindows(object):
-    """B instances of N <= 256 packed blocks each; ``next(ptr)`` drops the block picked in the
+    """B instances of N <= 4096 packed blocks each; ``next(ptr)`` drops the block picked in the
     previous window and returns the next window's network input.  Up to 64 blocks an instance is one
     wavefront (lane = node, graphs = 64-bit masks), up to 128 blocks with windows of at most 32 nodes still one
     wavefront (lane = two nodes, two-word masks), and ``step`` fuses the placement with the next window; above that
@@ -327,6 +327,12 @@ def _run_rolling_steppers(rw, policy, container_width, container_height, reward_
     else:
         roll, last = steppers
         env = roll.env
+        # the pair's buffers fix whether the fp32 tensors exist: a call that asks for the other mode would hand the
+        # policy a tensor it did not ask for (or None where it expects one)
+        pair_expands = roll.dynamic is not None
+        if pair_expands != bool(expand_dynamic) or bool(last.expand_dynamic) != bool(expand_dynamic):
+            raise ValueError("steppers were built with expand_dynamic=%s, this call asks for expand_dynamic=%s: "
+                             "build a new pair (steppers=None) for the other mode" % (pair_expands, bool(expand_dynamic)))
     env.reset()
     roll.begin(rw)
     feats = []

@@ -22,6 +22,7 @@ Fixtures:
   render.npz                         pack.render's eight metric files (LB_GREEDY / MACS / MUL, 2D / 3D, two-container types)
   ppsg3d.npz                         generate.BPP_Generator_3D / generate_blocks_with_GT (3D) under recorded seeds
   ppsg2d.npz                         generate.BPP_Generator_2D_easy / generate_blocks_with_GT (2D) under recorded seeds
+  ppsg2d_arm.npz                     generate_blocks_with_GT / generate_blocks (2D) with arm_size 2 .. 4 under recorded seeds
   ppsg_2d.npz                        (--only ppsg) 64 instances of the reference's PPSG generator + MACS traces over them
 """
 import argparse
@@ -458,6 +459,56 @@ def make_ppsg2d(generate):
     save("ppsg2d.npz", **out)
 
 
+def make_ppsg2d_arm(pack, generate):
+    """generate.generate_blocks_with_GT (2D) and generate.generate_blocks with an arm wider than one column
+    (`--arm_size`, generate.py:623-641): `arm_*` = whole generate_blocks_with_GT(n, [7, H], [W0, 50], arm, [1, 5], 'bot', 0)
+    runs and `rnd_*` = generate_blocks(n, [W0, 50], arm, [1, 5]) runs after np.random.seed(seed), for arm_size 2 and 3 --
+    the return values written as pack.create_dataset(_gt) writes them and read back through the reference's
+    PACKDataset (static, dynamic), plus blocks / positions in layout order (rotation 0)."""
+    out = {}
+    tmp = tempfile.mkdtemp()
+
+    def through_dataset(tag, n, rb, pos, dm, small, large):
+        d = os.path.join(tmp, tag) + "/"
+        os.makedirs(d)
+        with open(d + "blocks.txt", "w") as fb, open(d + "dep_small.txt", "w") as fs, open(d + "dep_large.txt", "w") as fl:
+            for r in range(len(rb)):                           # pack.py:536-539
+                fb.write(" ".join(str(int(v)) for v in rb[r]) + "\n")
+                fs.write(" ".join(str(int(v)) for v in small[r]) + "\n")
+                fl.write(" ".join(str(int(v)) for v in large[r]) + "\n")
+        open(d + "pos.txt", "w").write(" ".join(str(int(v)) for v in pos) + "\n")
+        open(d + "dep_move.txt", "w").write(" ".join(str(int(v)) for v in dm) + "\n")
+        open(d + "container.txt", "w").write(" ".join("0" for _ in range(n)) + "\n")
+        ds = pack.PACKDataset(d, n, 1, 12345, "bot", "diff", True, 5, unit=1)
+        out[tag + "_static"] = ds.static.detach().numpy()[0].astype(np.int8)
+        out[tag + "_dynamic"] = ds.dynamic.detach().numpy()[0].astype(np.int8)
+        out[tag + "_blocks"] = np.asarray(rb[0]).reshape(2, n).T.astype(np.int16)       # rotation 0, layout order
+        out[tag + "_positions"] = np.asarray(pos).reshape(2, n).T.astype(np.int16)
+
+    arm_cases, k = [], 0
+    for n, gt, w0, arm in ((6, [7, 5], 7, 2), (8, [7, 7], 7, 2), (10, [7, 9], 9, 2), (10, [7, 9], 9, 3), (12, [7, 10], 10, 3)):
+        for seed in range(4):
+            sd = 99000 + 100 * n + 10 * arm + seed
+            np.random.seed(sd)
+            rb, pos, dm, small, large = generate.generate_blocks_with_GT(n, list(gt), [w0, 50], arm, [1, 5], "bot", 0)
+            through_dataset("arm%d" % k, n, rb, pos, dm, small, large)
+            arm_cases.append((n, gt[0], gt[1], w0, arm, sd))
+            k += 1
+            print("ppsg2d_arm gt case", k, n, gt, arm, flush=True)
+    out["arm_cases"] = np.asarray(arm_cases, dtype=np.int64)
+    rnd_cases, k = [], 0
+    for n, w0, arm in ((10, 7, 2), (10, 9, 3), (20, 9, 2), (14, 12, 4)):
+        for seed in range(6):
+            sd = 66000 + 100 * n + 10 * arm + seed
+            np.random.seed(sd)
+            rb, pos, dm, small, large = generate.generate_blocks(n, [w0, 50 if n <= 14 else 90], arm, [1, 5])
+            through_dataset("rnd%d" % k, n, rb, pos, dm, small, large)
+            rnd_cases.append((n, w0, 50 if n <= 14 else 90, arm, sd))
+            k += 1
+    out["rnd_cases"] = np.asarray(rnd_cases, dtype=np.int64)
+    save("ppsg2d_arm.npz", **out)
+
+
 def make_masks(pack, D, static, dynamic):
     """Random feasible action tapes through the reference's update_dynamic / update_mask."""
     import torch
@@ -679,6 +730,7 @@ def main():
     if args.only and "ppsg" in args.only: make_ppsg(tools, pack, args.ppsg_dir)   # slow: only on request
     if want("ppsg3d"): make_ppsg3d(pack, generate)
     if want("ppsg2d"): make_ppsg2d(generate)
+    if want("ppsg2d_arm"): make_ppsg2d_arm(pack, generate)
     if want("stable3d"): make_stable3d(tools)
     if want("stable3d_wide"): make_stable3d_wide(tools)
     if want("kat"): make_kat(tools)

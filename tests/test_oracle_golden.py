@@ -295,3 +295,33 @@ def test_generate_blocks_with_gt_2d_draw_for_draw():
         # the function's own deps_move (row = blocked block); PACKDataset's tensor holds it transposed
         assert np.array_equal(dyn[:n, :n].T.reshape(-1), z["gt%d_dep_move" % k].astype(np.float32))
     assert len(z["gt_cases"]) == 20
+
+
+def test_arm_sizes_above_one_2d():
+    """`--arm_size` above one column (generate.py:623-641; 2D only): whole generate_blocks_with_GT runs with arm_size 2 / 3
+    draw for draw, and the PACKDataset tensors of generate_blocks_with_GT / generate_blocks instances with arm_size 2 .. 4
+    (the left / right access rules over `arm_size` columns, the wall rule at x < arm_size) through instance_from_blocks."""
+    z = G.load("ppsg2d_arm.npz")
+    for k, (n, gx, gz, w0, arm, seed) in enumerate(z["arm_cases"]):
+        n, init = int(n), [int(w0), 50]
+        if k < 17:                                           # the last three need > 4 M words (10^4 rejected packings)
+            rng = O.Rng(words=O.numpy_mt_words(int(seed), 4_000_000))
+            rc, blocks, pos, stats = O.generate_blocks_with_gt_2d(rng, n, [int(gx), int(gz)], init, arm_size=int(arm))
+            assert rc == 1 and not rng.exhausted, (k, rc)
+            assert np.array_equal(blocks, z["arm%d_blocks" % k]) and np.array_equal(pos, z["arm%d_positions" % k]), (k, stats)
+        ok, pos2, st, dyn = O.instance_from_blocks(z["arm%d_blocks" % k], init, int(arm))
+        assert ok == 1 and np.array_equal(pos2, z["arm%d_positions" % k]), k
+        assert np.array_equal(st, z["arm%d_static" % k].astype(np.float32)), k
+        assert np.array_equal(dyn, z["arm%d_dynamic" % k].astype(np.float32)), k
+    for k, (n, w0, h0, arm, seed) in enumerate(z["rnd_cases"]):
+        ok, pos2, st, dyn = O.instance_from_blocks(z["rnd%d_blocks" % k], [int(w0), int(h0)], int(arm))
+        assert ok == 1 and np.array_equal(pos2, z["rnd%d_positions" % k]), k
+        assert np.array_equal(st, z["rnd%d_static" % k].astype(np.float32)), k
+        assert np.array_equal(dyn, z["rnd%d_dynamic" % k].astype(np.float32)), k
+    assert len(z["arm_cases"]) == 20 and len(z["rnd_cases"]) == 24
+    # the wider arm is live in the fixture: some instance's tensors differ from the arm_size 1 ones
+    differs = 0
+    for k, (n, w0, h0, arm, seed) in enumerate(z["rnd_cases"]):
+        _, _, _, dyn1 = O.instance_from_blocks(z["rnd%d_blocks" % k], [int(w0), int(h0)], 1)
+        differs += int(not np.array_equal(dyn1, z["rnd%d_dynamic" % k].astype(np.float32)))
+    assert differs >= 12
