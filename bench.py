@@ -1391,6 +1391,31 @@ def variants(cfg, args, hp, rank, world, dev, use_graph):
                                           "positions of the two runs are compared bit for bit")
     except Exception as ex:                                  # pragma: no cover
         out["no_fp32_expand"] = dict(error=str(ex)[:300])
+    # (d2) the fp32 tensor kept, but ONE of it: tap_stepper_buffers.dyn[0] == dyn[1] -- step 0 writes the tensor, later
+    #      steps only the rows they clear (update_dynamic's result differs from its input in 3 of 3n rows)
+    try:
+        if "graph" in skip:
+            raise RuntimeError("skipped")
+        trace("in_place_dynamic")
+        tape_pol = T.TapePolicy(hp.tape[0].t())
+        vals, same = {}, None
+        for inplace in (False, True):
+            env_x = T.BatchedContainer(B, cs, hp.nw, reward, "diff", packing_strategy=strategy, device=dev)
+            spx = T.EpisodeStepper(st, dy, env_x, steps=hp.nw, inplace_dynamic=inplace)
+            vals[inplace], rec = graphed(tape_pol, lambda: None, spx, steps=200)
+            got = (rec["reward"].clone(), spx.dynamic.clone(), spx.current_mask.clone(), spx.mask.clone(),
+                   spx.decoder_dynamic.clone(), env_x.positions.clone())
+            same = got if same is None else all(bool(torch.equal(a, b)) for a, b in zip(same, got))
+        out["in_place_dynamic"] = dict(value=vals[True], unit="env-steps/s", two_buffers=vals[False], steps=200,
+                                       outputs_identical=bool(same), verified=oracle_ok(rec),
+                                       what="rollout.run_episode on a recorded tour captured in one hipGraph, pack.EpisodeStepper("
+                                            "inplace_dynamic=True): `dynamic` is ONE fp32 tensor -- step 0 writes it, every later "
+                                            "step zeroes the 3 rows it clears instead of re-writing all 3n (the reference's clone, "
+                                            "pack.py:368, serves autograd; a no_grad loop has no use for the earlier tensors); "
+                                            "`two_buffers` is the same graph on the default stepper; reward, the final tensor, both "
+                                            "masks, the last feature and the positions of the two runs are compared bit for bit")
+    except Exception as ex:                                  # pragma: no cover
+        out["in_place_dynamic"] = dict(error=str(ex)[:300])
     finally:
         T.pack.set_binary_check('check')
     # (e) TAP_BENCH_TWO_CHAINS=1: the same batch as TWO half-batch chains on two streams of one graph.  Measured in round 6

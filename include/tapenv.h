@@ -454,7 +454,14 @@ typedef struct tap_stepper_buffers {
     float *dyn[2];               /* (B, rows, nR): update_dynamic's result (pack.py:333-376) as the fp32 tensor model.py:378
                                     feeds the encoder.  Both NULL: the step keeps `dynamic` as bits[w] only and skips the
                                     expansion (78 % of a c2 step's bytes) -- for callers that consume the shadow; masks,
-                                    placements, features and ratio are the same either way */
+                                    placements, features and ratio are the same either way.
+                                    dyn[0] == dyn[1] (windows with a bit shadow): ONE tensor, updated IN PLACE -- step 0 writes
+                                    all of it, every later step only the rows it clears (pack.py:370-374: the result differs
+                                    from the input in rows real + n*i alone; the reference's clone, pack.py:368, is there for
+                                    autograd).  For loops under no_grad (validation, serving): the previous steps' tensors
+                                    are gone.  The lane-per-cell fused steps (containers of at most 64 cells, MACS 2D up
+                                    to 16 columns) write 3 rows per step instead of 3n; every other step form writes the whole
+                                    tensor into the one buffer -- the same values either way */
     float *current[2];           /* (B, nR): update_mask's new_mask.float() (pack.py:329-331) */
     float *mask[2];              /* (B, nR): update_mask's chosen_mask */
     float *feature;              /* (B, feature_len) nullable: add_new_block's return, layout of model.py:456-465 */

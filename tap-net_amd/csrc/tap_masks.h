@@ -34,6 +34,11 @@ struct MaskArgs {
     // 64-byte alignment of the expansion's store instructions (stream_lane_role): float4 offset of env b's slab
     // inside its 64-byte granule = (b * sb_mul + sb_add) & 3; nq = ceil(rows / rp)
     int sb_mul, sb_add, nq, nq2;   // nq2 = ceil(2 * rows / rp): a fused step's stream wave expands two slabs as one run
+    // dyn_out already HOLDS the tensor the step starts from (a stepper whose two dyn phases are one buffer, tapenv.h:
+    // tap_stepper_buffers): update_dynamic's result differs from its input in the chosen rows only (pack.py:370-374), so
+    // the kernels that know this mode write those rows' zeros and nothing else; every other kernel ignores the hint and
+    // writes the whole tensor, which is the same tensor
+    int inplace;
 };
 
 inline int tap_write_through(size_t bytes);
@@ -455,10 +460,12 @@ __device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v 
 // C4S != 0: a BASELINE window with its shape known at compile time -- C4S = 5 / 15: n = 10 nodes, rows = 30, nR = 20 (2D) /
 // 60 (3D) columns; C4S = 10: n = 20, rows = 60, nR = 40 (c4's 2D window) --: the expansion's loop unrolls, the row / column
 // arithmetic folds.  Same session, same tree: c2 1 280 -> 1 337-1 346 M env-steps/s, c3 500 -> 506 M, c4 496 -> 504 M.
-template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0>
+// INPLACE (never with BUILD): a.dyn_out holds the previous step's tensor -- only the rows this step clears are written
+template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0, bool INPLACE = false>
 __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
                                                  float *lds = nullptr)
 {
+    static_assert(!(BUILD && INPLACE), "the first step on a fresh tensor writes all of it");
     typedef unsigned long long u64;
     static_assert(NS <= 2, "a stream wave expands one or two slabs");
     if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
@@ -534,7 +541,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
 #pragma unroll
     for (int c = 0; c < NC; ++c) jm[c] = tap_mod_small(min(lane + 64 * c, nR - 1), n);
     u64 clr[NS];
-    int pm[NS];
+    int pm[NS], realk[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const bool valid = on[k] && has_ptr && praw[k] >= 0 && praw[k] < nR;  // no ptr: the initial mask (model.py:297-307)
@@ -552,6 +559,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             if (real >= 0 && r < rows) m |= 1ull << r;
         }
         clr[k] = m;
+        realk[k] = real;
         pm[k] = valid ? tap_mod_small(p, n) : -1;                             // pack.py:314-316; -1 matches no column
     }
     // the new words of this lane's column quad, per slab
@@ -561,8 +569,35 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         nw[k][0] = w[k][0].x & ~clr[k]; nw[k][1] = w[k][0].y & ~clr[k];
         nw[k][2] = w[k][1].x & ~clr[k]; nw[k][3] = w[k][1].y & ~clr[k];
     }
-    if (lane_on) {
+    if constexpr (INPLACE) {
+        // pack.py:370-374 on a tensor that is already there: rows real + n * i of the slab become zeros.  Lane = (i, column
+        // quad): ONE store instruction per slab for windows of up to 21 columns per rotation (3 * nR / 4 <= 64 lanes); the
+        // stream wave is this step's critical path and every instruction in front of its last store is paid in full
+        // (a row-by-row loop, three instructions per slab behind two nested loops: 5.60 against 5.20 us per launch at c2
+        // with the tensor switched off)
         if (a.dyn_out) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int total = a.update_rows * C4;
+            for (int idx = lane; idx < total; idx += 64) {
+                const int i = (idx * c4_magic) >> 16, c = idx - i * C4;          // idx / C4 (idx < 3 * 64)
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    const int r = realk[k] + n * i;
+                    if (!on[k] || realk[k] < 0 || r >= rows) continue;
+                    float4 *dst = reinterpret_cast<float4 *>(a.dyn_out) + ((size_t)(senv0 + k) * rows + r) * C4 + c;
+#if defined(TAP_INPLACE_STORE) && TAP_INPLACE_STORE == 1      // A/B builds: always write-through / nontemporal like the expansion
+                    store_stream(dst, z, a.wt);
+#elif defined(TAP_INPLACE_STORE) && TAP_INPLACE_STORE == 2     // A/B builds: plain
+                    *dst = z;
+#else
+                    if (a.wt) store_stream(dst, z, 1); else *dst = z;            // a row is a fraction of a line: never nontemporal
+#endif
+                }
+            }
+        }
+    }
+    if (lane_on) {
+        if (!INPLACE && a.dyn_out) {
             // the fp32 tensor: instruction i = the lane's row r0 + RP * i of the wave's run when that is a row of it (late
             // lanes skip i = 0); rows >= `rows` belong to the second slab
             const int non = (NS > 1 && on[NS - 1]) ? 2 : 1;
@@ -771,13 +806,13 @@ __device__ __forceinline__ void stream_wave_bits_r3(const MaskArgs &a, int senv0
 }
 
 #endif
-template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0>
+template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0, bool INPLACE = false>
 __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS], float *lds = nullptr)
 {
 #ifdef TAP_STREAM_R3
     stream_wave_bits_r3<NS, NC, BUILD>(a, senv0, lane, on, lds);
 #else
-    stream_wave_bits_r4<NS, NC, BUILD, MERGED, C4S>(a, senv0, lane, on, lds);
+    stream_wave_bits_r4<NS, NC, BUILD, MERGED, C4S, INPLACE>(a, senv0, lane, on, lds);
 #endif
 }
 

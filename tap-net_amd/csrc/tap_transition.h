@@ -25,7 +25,9 @@ struct TransArgs {
 // MODE & 8 / & 16 (TAP_MODE_C4_5 / _15): the window is the reference's own -- n = 10, rows = 30, nR = 20 (2D) / 60 (3D) --
 // and its shape is compiled in (stream_wave_bits_r4: C4S); the launcher checks the shape
 // (both bits, TAP_MODE_C4_10: c4's window, n = 20, rows = 60, nR = 40 -- the MACS 2D step, transition_macs.hip)
-constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16, TAP_MODE_C4_10 = 24;
+// MODE & 32 (TAP_MODE_INPLACE, with MODE & 3 == 1 only): dyn_out holds the previous step's tensor (MaskArgs::inplace) --
+// the stream waves write the cleared rows' zeros instead of expanding the slab
+constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16, TAP_MODE_C4_10 = 24, TAP_MODE_INPLACE = 32;
 __host__ __device__ constexpr int tap_mode_shape(int D) { return D == 2 ? TAP_MODE_C4_5 : TAP_MODE_C4_15; }
 inline bool tap_mode_shape_ok(const MaskArgs &m, int D) { return m.n == 10 && m.rows == 30 && m.nR == (D == 2 ? 20 : 60); }
 inline bool tap_mode_shape20_ok(const MaskArgs &m) { return m.n == 20 && m.rows == 60 && m.nR == 40; }
@@ -34,6 +36,8 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
 {
     constexpr int MODE = MODE_ & 3;
     constexpr bool MERGED = (MODE_ & TAP_MODE_MERGED) != 0;
+    constexpr bool INPLACE = (MODE_ & TAP_MODE_INPLACE) != 0;
+    static_assert(!INPLACE || MODE == 1, "in place: only on a shadow the caller hands in");
     constexpr int C4S = (MODE_ & TAP_MODE_C4_10) == TAP_MODE_C4_10 ? 10 : (MODE_ & TAP_MODE_C4_5) ? 5 : (MODE_ & TAP_MODE_C4_15) ? 15 : 0;
     static_assert(C4S == 0 || NC == 1, "the compiled-in window shapes have one column per lane");
     bool on[SPW];
@@ -41,7 +45,7 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
     TL_STAMP(0);
     if (NC > 0) {
-        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED, C4S>(m, senv0, lane, on, lds);
+        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED, C4S, INPLACE>(m, senv0, lane, on, lds);
         else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true, MERGED, C4S>(m, senv0, lane, on, lds);
         else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         TL_STAMP(2);

@@ -133,7 +133,10 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     // 2D windows (nR = 2n columns: five store instructions per run at c2) take the run-of-rows expansion while the stores
     // are write-through; 3D windows and every launch beyond the write-through limit keep the slab-by-slab loops
     const bool merged = D == 2 && a.m.wt != 0;
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) { if (D == 2 && merged) TAP_LAUNCH_T(NC_, (D == 2 ? 5 : 1), LDS_); else TAP_LAUNCH_T(NC_, 1, LDS_); } \
+    // the caller's dyn_out already holds the previous step's tensor (a stepper on ONE dyn buffer): only the cleared rows are written
+    const bool inpl = mode == 1 && a.m.inplace && a.m.dyn_out;
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (inpl) TAP_LAUNCH_T(NC_, (1 | TAP_MODE_INPLACE), LDS_); \
+        else if (mode == 1) { if (D == 2 && merged) TAP_LAUNCH_T(NC_, (D == 2 ? 5 : 1), LDS_); else TAP_LAUNCH_T(NC_, 1, LDS_); } \
         else if (mode == 2) { if (D == 2 && merged) TAP_LAUNCH_T(NC_, (D == 2 ? 6 : 2), LDS_); else TAP_LAUNCH_T(NC_, 2, LDS_); } else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
@@ -144,7 +147,7 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
 #undef TAP_LAUNCH_K
-    (void)shaped;
+    (void)shaped; (void)inpl;
     TAP_LAUNCH_CHECK(ctx, "k_transition");
     return TAP_OK;
 }
@@ -304,8 +307,10 @@ static int transition_bits_impl(tap_ctx *ctx, const tap_env_desc *d, void *state
                                 int static_rows, const int64_t *ptr, const float *mask_in,
                                 unsigned long long *bits_out, float *dyn_out, float *current_out,
                                 float *mask_out, float *feature_out, float *ratio_out, int flags,
-                                void *stream, const StepAux *aux)
+                                void *stream, const StepAux *aux, int inplace = 0)
 {
+    // inplace: dyn_out holds update_dynamic's INPUT (the stepper's previous step wrote it there) -- the lane-per-cell fused
+    // kernels then write the cleared rows only; the other paths below write the whole tensor, which is the same tensor
     if (d && d->B == 0) return tap_desc_validate(ctx, d); // an empty batch has no buffers to check
     TransArgs a = {};
     int rc = transition_common(ctx, d, state, n, R, rows, update_rows, static_, static_rows, ptr, mask_in,
@@ -328,6 +333,7 @@ static int transition_bits_impl(tap_ctx *ctx, const tap_env_desc *d, void *state
     }
     a.m = mask_finish(MaskArgs{d->B, n, R, n * R, rows, update_rows, static_rows, nullptr, dyn_out, static_, ptr,
                    mask_in, nullptr, nullptr, current_out, mask_out, bits_in, bits_out});
+    a.m.inplace = (inplace && dyn_out) ? 1 : 0;
     if (!mask_bits_ok(a.m))
         return tap_fail(ctx, TAP_E_UNSUPPORTED, "bit shadow needs nR %% 4 == 0, nR <= 256, rows <= 128, 16-byte aligned buffers");
     return transition_dispatch(ctx, d, a, stream);
@@ -419,6 +425,7 @@ struct tap_stepper {
     int k;                              // index of the next step
     int keep;                           // TAP_SB_CONTINUE: step 0 does not start from a fresh container
     int copy_form;                      // the window has no bit shadow: `dynamic` is carried as the fp32 tensor + column sums
+    int inplace;                        // dyn[0] == dyn[1]: ONE fp32 tensor, updated in place from the second step on
 };
 
 struct DeviceGuard { // the launches must be issued with the context's device current (callers may sit on another one)
@@ -456,9 +463,13 @@ extern "C" int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *sta
         // update_dynamic's result (78 % of a c2 step's bytes); masks, placements and ratio do not depend on it
         if ((buf->dyn[0] == nullptr) != (buf->dyn[1] == nullptr))
             return tap_fail(ctx, TAP_E_INVALID, "stepper needs both phases of dyn, or neither (no fp32 expansion)");
-        if ((shadow && buf->bits[0] == buf->bits[1]) || (buf->dyn[0] && buf->dyn[0] == buf->dyn[1]) || buf->current[0] == buf->current[1] ||
+        // dyn[0] == dyn[1] (windows with a bit shadow): ONE fp32 tensor for the whole episode.  The step never reads it (the
+        // shadow carries `dynamic`), and update_dynamic's result differs from its input in the chosen rows only, so from
+        // the second step on a step writes those rows' zeros instead of the whole tensor (the reference's clone, pack.py:368,
+        // exists for autograd: a loop under no_grad -- validation, serving -- has no use for the previous tensors)
+        if ((shadow && buf->bits[0] == buf->bits[1]) || (!shadow && buf->dyn[0] == buf->dyn[1]) || buf->current[0] == buf->current[1] ||
             buf->mask[0] == buf->mask[1] || !buf->ratio)
-            return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers and ratio is required");
+            return tap_fail(ctx, TAP_E_INVALID, "stepper phases must be distinct buffers (dyn may be one buffer on the bit shadow) and ratio is required");
     }
     const int nR = n * R;
     if (buf->tour_stride < 0 || buf->tour_col0 < 0 || (buf->tour_stride > 0 && buf->tour_col0 + steps > buf->tour_stride))
@@ -470,6 +481,7 @@ extern "C" int tap_stepper_create(tap_ctx *ctx, const tap_env_desc *d, void *sta
     s->b = *buf;
     s->static_ = nullptr; s->dyn_in = nullptr; s->bits0 = nullptr; s->mask0 = nullptr; s->k = 0; s->keep = 0;
     s->copy_form = (nR % 4 != 0 || nR > 256 || rows > 128) ? 1 : 0;
+    s->inplace = (!s->copy_form && buf->dyn[0] && buf->dyn[0] == buf->dyn[1]) ? 1 : 0;
     *out = s;
     return TAP_OK;
 }
@@ -553,7 +565,7 @@ extern "C" int tap_stepper_step(tap_stepper *s, const int64_t *ptr, void *stream
         rc = transition_bits_impl(s->ctx, &s->d, s->state, s->n, s->R, s->rows, s->update_rows,
                                   k == 0 ? s->bits0 : s->b.bits[r], s->static_, s->static_rows, ptr,
                                   k == 0 ? s->mask0 : s->b.mask[r], s->b.bits[w], s->b.dyn[w], s->b.current[w], s->b.mask[w],
-                                  s->b.feature, s->b.ratio, flags, stream, &aux);
+                                  s->b.feature, s->b.ratio, flags, stream, &aux, (k > 0 && s->inplace) ? 1 : 0);
     if (rc == TAP_OK) s->k = k + 1;
     return rc;
 }

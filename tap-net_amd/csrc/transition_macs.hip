@@ -195,7 +195,8 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
         hipLaunchKernelGGL((k_transition_macs3<G, NC_, M_, WL_>), dim3(grid), dim3(THREADS), LDS_, st, a); } while (0)
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr (G == 32) { if (wl5) TAP_LAUNCH_W(NC_, M_, LDS_, 5); else TAP_LAUNCH_W(NC_, M_, LDS_, 0); } \
         else TAP_LAUNCH_W(NC_, M_, LDS_, 0); } while (0)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, TAP_MACS3_M1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, TAP_MACS3_M2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
+    const bool inpl = mode == 1 && a.m.inplace && a.m.dyn_out;        // tap_masks.h: MaskArgs::inplace
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (inpl) TAP_LAUNCH_T(NC_, (1 | TAP_MODE_INPLACE), LDS_); else if (mode == 1) TAP_LAUNCH_T(NC_, TAP_MACS3_M1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, TAP_MACS3_M2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;
@@ -205,7 +206,7 @@ template <int G> static int launch_transition_macs3(tap_ctx *ctx, const TransArg
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
 #undef TAP_LAUNCH_W
-    (void)wl5;
+    (void)wl5; (void)inpl;
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs3");
     return TAP_OK;
 }
@@ -229,7 +230,8 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr (G == 8 && (NC_) == 1 && ((M_) & 3) != 0) { \
             if (c4shape) TAP_LAUNCH_K(NC_, ((M_) | TAP_MODE_C4_10), LDS_, 7); else TAP_LAUNCH_K(NC_, M_, LDS_, 0); } \
         else TAP_LAUNCH_K(NC_, M_, LDS_, 0); } while (0)
-#define TAP_LAUNCH_M(NC_, LDS_) do { if (mode == 1) TAP_LAUNCH_T(NC_, TAP_MACS_M1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, TAP_MACS_M2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
+    const bool inpl = mode == 1 && a.m.inplace && a.m.dyn_out;        // tap_masks.h: MaskArgs::inplace
+#define TAP_LAUNCH_M(NC_, LDS_) do { if (inpl) TAP_LAUNCH_T(NC_, (1 | TAP_MODE_INPLACE), LDS_); else if (mode == 1) TAP_LAUNCH_T(NC_, TAP_MACS_M1, LDS_); else if (mode == 2) TAP_LAUNCH_T(NC_, TAP_MACS_M2, LDS_); else TAP_LAUNCH_T(NC_, 0, LDS_); } while (0)
     switch (mask_fast_path_cols(a.m)) {
     case 1: TAP_LAUNCH_M(1, lds); break;
     case 2: TAP_LAUNCH_M(2, lds); break;
@@ -239,7 +241,7 @@ template <int G> static int launch_transition_macs(tap_ctx *ctx, const TransArgs
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
 #undef TAP_LAUNCH_K
-    (void)c4shape;
+    (void)c4shape; (void)inpl;
     TAP_LAUNCH_CHECK(ctx, "k_transition_macs");
     return TAP_OK;
 }

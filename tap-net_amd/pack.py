@@ -472,8 +472,8 @@ class EpisodeStepper(object):
 
     After ``begin`` / ``step`` the attributes ``dynamic``, ``current_mask``, ``mask``, ``decoder_dynamic``,
     ``decoder_static`` hold the values model.py's loop variables of the same names would; they are views of the
-    stepper's buffers: a step overwrites the phase written two steps ago, the next ``begin`` everything -- clone
-    what must outlive that.  ``static`` / ``dynamic`` given to ``begin`` are only read (the trainer re-uses them,
+    stepper's buffers: a step overwrites the phase written two steps ago (``inplace_dynamic=True``: ``dynamic`` is ONE
+    tensor that every step updates in place), the next ``begin`` everything -- clone what must outlive that.  ``static`` / ``dynamic`` given to ``begin`` are only read (the trainer re-uses them,
     trainer.py:214) and are kept referenced for the episode.
 
     Shapes are fixed at construction from the example tensors; needs a window with a bit shadow
@@ -482,7 +482,7 @@ class EpisodeStepper(object):
     the count stays on the device until ``check_binary()`` (or ``check()``) asks for it."""
 
     def __init__(self, static, dynamic, env, input_type='bot', allow_rot=True, steps=None, want_tour=True,
-                 tour=None, tour_col0=0, expand_dynamic=True):
+                 tour=None, tour_col0=0, expand_dynamic=True, inplace_dynamic=False):
         import ctypes as C
         self.block_dim = _block_dim(static, input_type)
         self.R = _rotate_types(self.block_dim, allow_rot)
@@ -510,7 +510,19 @@ class EpisodeStepper(object):
         # expand_dynamic=False: update_dynamic's result stays in its bit shadow (``dynamic_bits``) and the fp32 tensor
         # of model.py:378 is not written -- 78 % of a c2 step's bytes; ``dynamic`` is then None after a step
         self.expand_dynamic = bool(expand_dynamic)
-        self._dyn = [torch.empty(self.B, self.rows, self.nR, **f32) if expand_dynamic else None for _ in range(2)]
+        # inplace_dynamic=True (windows with a bit shadow; loops under no_grad -- validation, serving): ONE fp32 tensor for
+        # the episode instead of two alternating ones.  Step 0 writes all of it, every later step the rows it clears
+        # (update_dynamic's result differs from its input in rows real + n*i only, pack.py:370-374; the reference clones,
+        # pack.py:368, because autograd keeps each step's tensor): ``dynamic`` after a step is that one tensor, the
+        # previous steps' values are gone.  tapenv.h: tap_stepper_buffers.dyn
+        self.inplace_dynamic = bool(inplace_dynamic)
+        if self.inplace_dynamic and (self._copy or not expand_dynamic):
+            raise ValueError("inplace_dynamic=True needs the fp32 tensor (expand_dynamic=True) of a window with a bit shadow")
+        if self.inplace_dynamic:
+            one = torch.empty(self.B, self.rows, self.nR, **f32)
+            self._dyn = [one, one]
+        else:
+            self._dyn = [torch.empty(self.B, self.rows, self.nR, **f32) if expand_dynamic else None for _ in range(2)]
         self._cur = [torch.empty(self.B, self.nR, **f32) for _ in range(2)]
         self._mask = [torch.empty(self.B, self.nR, **f32) for _ in range(2)]
         # the decoder inputs are zeros before step 0 (pack.py:258-264); one flat buffer so that begin() clears both
