@@ -1094,6 +1094,8 @@ __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a, ROLL_HO
     __shared__ RollLds S[EPB];
     __shared__ int s_old[64 * ENV_WAVES];
     __shared__ int s_new[64 * ENV_WAVES];
+    // (the wave index stays a vector value here: in a scalar register -- transition.hip, where it is worth 4 % at c2 -- it
+    //  measured flat on the MACS steps and 7 % SLOWER on the rolling step, round 6)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int base = blockIdx.x * EPB;
     if (wave < ENV_WAVES) {

@@ -100,15 +100,19 @@ __host__ __device__ __forceinline__ bool mask_builds_bits(const MaskArgs &a) { r
 #define TAP_MASK_HOT_PARAMS const int64_t *h_ptr, const float *h_static, const float *h_mask_in, const void *h_src, int h_B, \
                             int h_nR, int h_static_rows, int h_c4_magic
 #define TAP_MASK_HOT_NAMES h_ptr, h_static, h_mask_in, h_src, h_B, h_nR, h_static_rows, h_c4_magic
+// (the last word also carries sb_mul and sb_add, bits 24-25 / 26-27: the rotation of the lane roles -- tap_masks.h:
+//  stream_lane_role -- enters the ADDRESS of a lane's shadow words, and read from the argument block it put one
+//  scalar-cache round trip in front of every load of the wave; c4_magic <= 2^16 + 1)
 #define TAP_MASK_HOT_ARGS(m) (m).ptr, (m).static_, (m).mask_in,                                                              \
         ((m).bits_in ? static_cast<const void *>((m).bits_in) : static_cast<const void *>((m).dyn_in)), (m).B, (m).nR,       \
-        (m).static_rows, (m).c4_magic
+        (m).static_rows, ((m).c4_magic | (((m).sb_mul & 3) << 24) | (((m).sb_add & 3) << 26))
 // src_is_bits: compile-time in the callers (MODE == 1 / 3)
 __device__ __forceinline__ MaskArgs tap_mask_hot(const MaskArgs &k, bool src_is_bits, TAP_MASK_HOT_PARAMS)
 {
     MaskArgs m = k;
     m.ptr = h_ptr; m.static_ = h_static; m.mask_in = h_mask_in;
-    m.B = h_B; m.nR = h_nR; m.static_rows = h_static_rows; m.c4_magic = h_c4_magic;
+    m.B = h_B; m.nR = h_nR; m.static_rows = h_static_rows; m.c4_magic = h_c4_magic & 0xffffff;
+    m.sb_mul = (h_c4_magic >> 24) & 3; m.sb_add = (h_c4_magic >> 26) & 3;
     if (src_is_bits) m.bits_in = static_cast<const unsigned long long *>(h_src);
     else m.dyn_in = static_cast<const float *>(h_src);
     return m;
@@ -537,30 +541,65 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     TL_STAMP(1);
 #endif
     const u64 nmask = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    // v mod n for a column index (pack.py:314-316): a division by a constant for the compiled-in windows
+    auto mod_n = [&](int v) -> int {
+        if constexpr (C4S != 0) return (int)((unsigned)v % (unsigned)(C4S == 10 ? 20 : 10));
+        else return tap_mod_small(v, n);
+    };
     int jm[NC];                                                               // this lane's columns mod n (pack.py:314-316 for a column)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) jm[c] = tap_mod_small(min(lane + 64 * c, nR - 1), n);
+    for (int c = 0; c < NC; ++c) jm[c] = mod_n(min(lane + 64 * c, nR - 1));
     u64 clr[NS];
     int pm[NS], realk[NS];
+    // A slab's pick, its block id and the rows it clears are the same on every lane of the wave: kept in SCALAR registers
+    // (v_readlane on the row-0 values the lanes hold instead of a shuffle through the LDS crossbar; the clear mask is
+    // scalar shifts), they cost the stream wave's critical path -- this launch's, at the BASELINE batches -- no vector
+    // issue slots and no LDS round trip (round 6: c2 1 440 -> 1 470 M env-steps/s, scripts/ab_transition.sh)
+    constexpr int UR_C = C4S != 0 ? 3 : 0;                 // the compiled-in windows are 'bot' windows: rows = 3 n, update_rows = 3 (checked by the launchers)
+    const int ur = UR_C ? UR_C : a.update_rows;
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-        const bool valid = on[k] && has_ptr && praw[k] >= 0 && praw[k] < nR;  // no ptr: the initial mask (model.py:297-307)
-        const int p = valid ? (int)praw[k] : 0;
-        float r0 = -1.f;                                                      // pack.py:339 via shuffle; stays -1
-#pragma unroll                                                                        // for an index outside [0, nR)
-        for (int c = 0; c < NC; ++c) {
-            const float t = __shfl(row0[k][c], p & 63);
-            if (valid && has_static && (p >> 6) == c) r0 = t;
+        const bool valid_v = on[k] && has_ptr && praw[k] >= 0 && praw[k] < nR;  // no ptr: the initial mask (model.py:297-307)
+        // (two-slab waves only: with ONE slab per wave -- 3D windows, c3 -- the vector form below measured 1 % faster,
+        //  538 against 543 M env-steps/s: there the chain is half as long and the scalar unit is the busier one)
+#ifdef TAP_STREAM_VPICK                                     // A/B builds: round 5's vector form everywhere
+        constexpr bool SPICK = false;
+#else
+        constexpr bool SPICK = NS > 1;
+#endif
+        bool valid;
+        int p, real;
+        if constexpr (!SPICK) {
+            valid = valid_v;
+            p = valid ? (int)praw[k] : 0;
+            float r0 = -1.f;                                                  // pack.py:339 via shuffle; stays -1 for an index outside [0, nR)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float t = __shfl(row0[k][c], p & 63);
+                if (valid && has_static && (p >> 6) == c) r0 = t;
+            }
+            real = (r0 > -1.f && r0 < (float)rows) ? (int)r0 : -1;            // .long() truncates; a row beyond the tensor clears nothing
+        } else {
+            const int ps = __builtin_amdgcn_readfirstlane(valid_v ? (int)praw[k] : -1);
+            valid = ps >= 0;
+            p = valid ? ps : 0;
+            float r0 = -1.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float t = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row0[k][c]), p & 63));
+                if (valid && has_static && (p >> 6) == c) r0 = t;
+            }
+            real = __builtin_amdgcn_readfirstlane((r0 > -1.f && r0 < (float)rows) ? (int)r0 : -1);
         }
-        const int real = (r0 > -1.f && r0 < (float)rows) ? (int)r0 : -1;     // .long() truncates; a row beyond the tensor clears nothing
         u64 m = 0;                                                            // pack.py:370-374
-        for (int i = 0; i < a.update_rows; ++i) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                                         // update_rows <= 3 (validated on the host)
             const int r = real + n * i;
-            if (real >= 0 && r < rows) m |= 1ull << r;
+            if (i < ur && real >= 0 && r < rows) m |= 1ull << r;
         }
         clr[k] = m;
         realk[k] = real;
-        pm[k] = valid ? tap_mod_small(p, n) : -1;                             // pack.py:314-316; -1 matches no column
+        pm[k] = valid ? mod_n(p) : -1;                                        // pack.py:314-316; -1 matches no column
     }
     // the new words of this lane's column quad, per slab
     u64 nw[NS][4];
@@ -577,7 +616,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         // with the tensor switched off)
         if (a.dyn_out) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int total = a.update_rows * C4;
+            const int total = ur * C4;
             for (int idx = lane; idx < total; idx += 64) {
                 const int i = (idx * c4_magic) >> 16, c = idx - i * C4;          // idx / C4 (idx < 3 * 64)
 #pragma unroll

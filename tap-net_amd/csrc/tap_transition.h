@@ -29,8 +29,8 @@ struct TransArgs {
 // the stream waves write the cleared rows' zeros instead of expanding the slab
 constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16, TAP_MODE_C4_10 = 24, TAP_MODE_INPLACE = 32;
 __host__ __device__ constexpr int tap_mode_shape(int D) { return D == 2 ? TAP_MODE_C4_5 : TAP_MODE_C4_15; }
-inline bool tap_mode_shape_ok(const MaskArgs &m, int D) { return m.n == 10 && m.rows == 30 && m.nR == (D == 2 ? 20 : 60); }
-inline bool tap_mode_shape20_ok(const MaskArgs &m) { return m.n == 20 && m.rows == 60 && m.nR == 40; }
+inline bool tap_mode_shape_ok(const MaskArgs &m, int D) { return m.n == 10 && m.rows == 30 && m.update_rows == 3 && m.nR == (D == 2 ? 20 : 60); }
+inline bool tap_mode_shape20_ok(const MaskArgs &m) { return m.n == 20 && m.rows == 60 && m.update_rows == 3 && m.nR == 40; }
 template <int SPW, int NC, int MODE_>
 __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, int lane, float *lds)
 {

@@ -37,7 +37,17 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TAP_
     extern __shared__ float trans_lds[];
     __shared__ int s_old[64 * ENV_WAVES];
     __shared__ int s_new[64 * ENV_WAVES];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // The wave's index in a SCALAR register (two-slab stream waves: 2D windows): everything a stream wave derives from it --
+    // its envs, every load and store address -- is then scalar arithmetic + lane offsets instead of 64-bit vector
+    // multiplies in front of the first load.  Round 6, same session (scripts/ab_transition.sh): c2 1 380 -> 1 440 M
+    // env-steps/s; c3 (one slab per wave) 545 -> 541 M, the MACS steps flat, the rolling step 530 -> 491 M -- so only here,
+    // and only for SPW > 1.  -DTAP_VWAVE: the index as the compiler sees it (a VGPR) everywhere (A/B builds).
+    const int tid = threadIdx.x, lane = tid & 63;
+#ifdef TAP_VWAVE
+    const int wave = tid >> 6;
+#else
+    const int wave = TransGeom<G, SW>::SPW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
+#endif
     const int env_base = blockIdx.x * EPB;
 
 #if defined(TAP_PROF) || defined(TAP_PROF_SWITCH)

@@ -30,6 +30,8 @@ __global__ void __launch_bounds__((TransGeom<G, TAP_MACS_SW>::THREADS)) k_transi
     using Geo = TransGeom<G, TAP_MACS_SW>;
     constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
     extern __shared__ float trans_lds[];
+    // (the wave index stays a vector value here: in a scalar register -- transition.hip, where it is worth 4 % at c2 -- it
+    //  measured flat on the MACS steps and 7 % SLOWER on the rolling step, round 6)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
     const int B = a.s.d.B, W = WC ? WC : a.s.d.W, H = a.s.d.H;
@@ -165,6 +167,8 @@ __global__ void __launch_bounds__((M3Geo<G>::THREADS)) M3_OCC k_transition_macs3
     using Geo = M3Geo<G>;
     constexpr int EPB = Geo::EPB, SPW = Geo::SPW, ENV_WAVES = Geo::ENV_WAVES;
     extern __shared__ float trans_lds[];
+    // (the wave index stays a vector value here: in a scalar register -- transition.hip, where it is worth 4 % at c2 -- it
+    //  measured flat on the MACS steps and 7 % SLOWER on the rolling step, round 6)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int env_base = blockIdx.x * EPB;
     if (wave >= ENV_WAVES) {
