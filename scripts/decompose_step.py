@@ -111,7 +111,7 @@ def run_switch(shape, slots=1):
 def run_timeline(shape):
     S = setup(shape)
     torch, np, n, B = S["torch"], S["np"], S["n"], S["B"]
-    WGS, WAVES = 2048, 8
+    WGS, WAVES = 2048, 16                                       # tap_masks.h: TAP_PROF_WGS, TAP_PROF_WAVES
     raw = (C.c_ulonglong * (WGS * WAVES * 4))()
     rd = S["L"].tap_prof_read_timeline
     for t in range(n):                                          # warm-up pass

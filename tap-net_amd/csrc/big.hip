@@ -510,7 +510,7 @@ template <bool HARD>
 __global__ void __launch_bounds__(TAP_BLOCK) TAP_BIG_REGS k_big_wave_step(StepArgs a)
 {
     extern __shared__ int32_t big_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // (a vector value: TAP_WAVE_INDEX() measured slower / flat here, tap_common.h)
     const int env = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;               // 1 .. 4 wavefronts per workgroup (tap_big_step)
     if (env >= a.d.B) return;                                                     // wave-uniform
     big_wave_step_body<HARD>(a, env, lane, big_lds + (size_t)wave * a.d.W * a.d.L * (HARD ? 4 : 1), 0, nullptr);
@@ -529,7 +529,7 @@ template <bool HARD, int NC, int MODE>
 __global__ void __launch_bounds__(384) TAP_BIG_REGS k_big_transition(TransArgs a, int PW)
 {
     extern __shared__ int32_t big_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // (a vector value: TAP_WAVE_INDEX() measured slower / flat here, tap_common.h)
     const int cells = a.s.d.W * a.s.d.L, tile = cells * (HARD ? 4 : 1);
     const int base = blockIdx.x * PW;
     if (wave < PW) {
@@ -557,7 +557,7 @@ template <bool HARD>
 __global__ void __launch_bounds__(TAP_BLOCK) TAP_BIG_REGS k_big_wave_episode(EpisodeArgs a)
 {
     extern __shared__ int32_t big_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // (a vector value: TAP_WAVE_INDEX() measured slower / flat here, tap_common.h)
     const int env = (int)(blockIdx.x * (blockDim.x >> 6)) + wave;
     const int D = a.d.D, W = a.d.W, L = a.d.L, cells = W * L, n = a.n;
     if (env >= a.B) return;                                                       // wave-uniform

@@ -187,7 +187,7 @@ template <int NC, int MODE>
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs3d_wave_transition(TransArgs a, int PW, int tile_u64)
 {
     extern __shared__ unsigned long long m3w_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;   // (a vector value: TAP_WAVE_INDEX() measured slower / flat here, tap_common.h)
     const int env = blockIdx.x * PW + wave;
     if (env >= a.s.d.B) return;                                                   // wave-uniform
     // The wave first runs its container's precedence update (one slab: inputs in one round trip, write-through stores

@@ -605,7 +605,7 @@ __device__ __forceinline__ void macs2d_wave_body(const StepArgs &a, int cap, int
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_step(StepArgs a, int cap)
 {
     extern __shared__ int32_t mw_lds[];
-    const int lane = threadIdx.x & 63, wave_in_wg = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave_in_wg = TAP_WAVE_INDEX();
     const int env = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (env >= a.d.B) return;                                                     // wave-uniform
     macs2d_wave_body(a, cap, env, lane, mw_lds + (size_t)wave_in_wg * macs_wave_tile_ints(a.d.W, cap, a.d.n_max));
@@ -618,7 +618,7 @@ template <int NC, int MODE>
 __global__ void __launch_bounds__(TAP_BLOCK) k_macs2d_wave_transition(TransArgs a, int cap, int PW, int tile_ints)
 {
     extern __shared__ int32_t mw_lds[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = TAP_WAVE_INDEX(), lane = threadIdx.x & 63;
     const int env = blockIdx.x * PW + wave;
     if (env >= a.s.d.B) return;                                                   // wave-uniform
     // The wave first runs its container's precedence update (one slab: inputs in one round trip, write-through stores

@@ -1044,7 +1044,7 @@ template <int D, int CH>
 __global__ void __launch_bounds__(TAP_BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8))) k_rolling_window(ROLL_HOT_PARAMS, RollArgs a)
 {
     __shared__ RollLds S[TAP_BLOCK / 64];
-    const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
+    const int w = TAP_WAVE_INDEX(), v = threadIdx.x & 63;
     rolling_window_wave<D, CH>(roll_hot(a, h_rel, h_state, h_remove, h_B, h_N), blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
 }
 
@@ -1053,7 +1053,7 @@ template <int D, int NW>
 __global__ void __launch_bounds__(TAP_BLOCK) k_rolling_window_wide(ROLL_HOT_PARAMS, RollArgs a)
 {
     __shared__ RollLds S[TAP_BLOCK / 64];
-    const int w = threadIdx.x >> 6, v = threadIdx.x & 63;
+    const int w = TAP_WAVE_INDEX(), v = threadIdx.x & 63;
     rolling_window_waveN<D, NW>(roll_hot(a, h_rel, h_state, h_remove, h_B, h_N), blockIdx.x * (TAP_BLOCK / 64) + w, v, S[w]);
 }
 
@@ -1094,9 +1094,15 @@ __device__ __forceinline__ void rolling_step_body(const RollStepArgs &a, ROLL_HO
     __shared__ RollLds S[EPB];
     __shared__ int s_old[64 * ENV_WAVES];
     __shared__ int s_new[64 * ENV_WAVES];
-    // (the wave index stays a vector value here: in a scalar register -- transition.hip, where it is worth 4 % at c2 -- it
-    //  measured flat on the MACS steps and 7 % SLOWER on the rolling step, round 6)
+    // The wave's index in a scalar register (as in transition.hip): the window wave's instance, and with it every address
+    // it loads from and stores to, becomes scalar arithmetic.  c5 differs by +- 5 % from process to process (buffer
+    // placement), so this A/B took eight processes per build in one session (profiles/r06_rolling_swave_ab.txt): median
+    // 507 -> 541 M env-steps/s, best 534 -> 557 M.  -DTAP_ROLL_VWAVE: the index as a vector value (A/B builds).
+#ifdef TAP_ROLL_VWAVE
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#else
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#endif
     const int base = blockIdx.x * EPB;
     if (wave < ENV_WAVES) {
         __builtin_amdgcn_s_setprio(2);

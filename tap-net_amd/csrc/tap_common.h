@@ -213,6 +213,20 @@ __device__ __forceinline__ int tap_spread_env(int lpw, int B)
     const int env = wave * lpw + lane;
     return (lane < lpw && env < B) ? env : -1;
 }
+// A wavefront's index inside its workgroup, in a SCALAR register.  threadIdx.x >> 6 is the same on every lane of a wave,
+// but the compiler only sees a vector value: for kernels in which a wave owns one unit (a container, an instance, a pair of
+// slabs) everything derived from the index -- the unit's number, every address -- then runs on the vector ALU.  Through
+// readfirstlane it is scalar arithmetic + lane offsets.  Measured per kernel family (round 6, profiles/r06_stream_wave_ab.txt,
+// r06_rolling_swave_ab.txt, r06_wave_index_big_ab.txt): the fused step with two slabs per stream wave (c2) + 4 %, the
+// rolling step (c5) + 6 %, MACS 2D one wavefront per container (c9) + 5 % -- used there; one slab per stream wave (c3)
+// - 0.7 %, the MACS lane kernels (c4, c6) and MACS 3D one wavefront per container (c8) flat, LB_GREEDY one wavefront per
+// container (c7) - 4 % -- not used there.  -DTAP_WAVE_INDEX_VECTOR for A/B builds.
+#ifdef TAP_WAVE_INDEX_VECTOR
+#define TAP_WAVE_INDEX() ((int)(threadIdx.x >> 6))
+#else
+#define TAP_WAVE_INDEX() (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+#endif
+
 // TAP_NO_WAVE_KERNELS (read once): the wave-per-container kernels of big.hip / macs_big.hip / macs3_big.hip stand aside
 // and their fallbacks -- what runs when a container's tile does not fit the LDS -- take every launch (parity tests, A/B)
 inline bool tap_wave_kernels_off() { static const bool off = getenv("TAP_NO_WAVE_KERNELS") != nullptr; return off; }

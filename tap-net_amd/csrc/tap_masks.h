@@ -124,7 +124,7 @@ __device__ __forceinline__ MaskArgs tap_mask_hot(const MaskArgs &k, bool src_is_
 // first store (all inputs have arrived), last store issued, stores acknowledged; placement waves: entry, state + block
 // loaded, placement decided, results stored.  The product build has none of this.
 #ifdef TAP_PROF
-constexpr int TAP_PROF_WGS = 2048, TAP_PROF_WAVES = 8;
+constexpr int TAP_PROF_WGS = 2048, TAP_PROF_WAVES = 16;   // 3D windows: 4 placement + 8 stream waves per workgroup (12 > 8 mixed neighbouring workgroups' stamps up to round 6)
 static __device__ unsigned long long tap_prof_tl[TAP_PROF_WGS * TAP_PROF_WAVES * 4];
 #define TL_STAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < TAP_PROF_WGS) \
         tap_prof_tl[(blockIdx.x * TAP_PROF_WAVES + (threadIdx.x >> 6)) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
