@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 #include <cstdlib>
 
 constexpr size_t TAP_WT_MAX_BYTES = 64u << 20;   // write-through up to this many bytes of fp32 tensor per launch (see store_stream)
@@ -465,11 +466,17 @@ __device__ __forceinline__ int tap_mod_small(int v, int n)     // v mod n for v 
 // 60 (3D) columns; C4S = 10: n = 20, rows = 60, nR = 40 (c4's 2D window) --: the expansion's loop unrolls, the row / column
 // arithmetic folds.  Same session, same tree: c2 1 280 -> 1 337-1 346 M env-steps/s, c3 500 -> 506 M, c4 496 -> 504 M.
 // INPLACE (never with BUILD): a.dyn_out holds the previous step's tensor -- only the rows this step clears are written
-template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0, bool INPLACE = false>
-__device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS],
+// FULL: every input is there (ptr, static, mask_in) and every slab of every wave is an env (B is a multiple of the envs per
+// workgroup) -- the launcher checks; the wave then carries no code for the absent cases (the initial mask, a stepper's
+// first step, the ragged last workgroup): ~40 of its ~550 instructions
+template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0, bool INPLACE = false, bool FULL = false>
+__device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0, int lane, const bool (&on_)[NS],
                                                  float *lds = nullptr)
 {
     static_assert(!(BUILD && INPLACE), "the first step on a fresh tensor writes all of it");
+    bool on[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) on[k] = FULL ? true : on_[k];
     typedef unsigned long long u64;
     static_assert(NS <= 2, "a stream wave expands one or two slabs");
     if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
@@ -492,7 +499,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     // a readable, 16-byte aligned address for the inputs a caller may leave out (ptr / static: the initial mask,
     // model.py:297-307; mask_in: a stepper's first step starts from ones)
     const void *any = BUILD ? static_cast<const void *>(a.dyn_in) : static_cast<const void *>(a.bits_in);
-    const bool has_ptr = a.ptr != nullptr, has_static = a.static_ != nullptr, has_mask = a.mask_in != nullptr;
+    const bool has_ptr = FULL || a.ptr != nullptr, has_static = FULL || a.static_ != nullptr, has_mask = FULL || a.mask_in != nullptr;
     const int64_t *ptrp = has_ptr ? a.ptr : static_cast<const int64_t *>(any);
     const float *stp = has_static ? a.static_ : static_cast<const float *>(any);
     const float *mip = has_mask ? a.mask_in : static_cast<const float *>(any);
@@ -500,15 +507,20 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     float row0[NS][NC], keep[NS][NC];
     u64 bj[NS][NC];
     ulonglong2 w[NS][2];
+    // Addresses as (per-env base, small lane offset): with the env in a scalar register (TAP_WAVE_INDEX, the fused 2D step) the
+    // bases are scalar arithmetic and a load costs the vector ALU one instruction instead of a 64-bit multiply-add, two
+    // selects and a shift-add
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int env = on[k] ? senv0 + k : senv0;       // an idle slab re-reads the first one's inputs
         praw[k] = ptrp[has_ptr ? env : 0];
+        const float *strow = stp + (has_static ? (size_t)env * a.static_rows * nR : (size_t)0);
+        const float *mirow = mip + (has_mask ? (size_t)env * nR : (size_t)0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int j = min(lane + 64 * c, nR - 1);
-            row0[k][c] = stp[has_static ? (size_t)env * a.static_rows * nR + j : 0];
-            keep[k][c] = mip[has_mask ? (size_t)env * nR + j : 0];
+            const unsigned j = (unsigned)min(lane + 64 * c, nR - 1);
+            row0[k][c] = strow[has_static ? j : 0u];
+            keep[k][c] = mirow[has_mask ? j : 0u];
         }
     }
 #ifdef TAP_STREAM_G2          // A/B builds: the shadow words requested only after the small inputs have arrived (round 3's order)
@@ -518,9 +530,10 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             const int env = on[k] ? senv0 + k : senv0;
+            const unsigned long long *brow = a.bits_in + (size_t)env * nR;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) bj[k][c] = a.bits_in[(size_t)env * nR + min(lane + 64 * c, nR - 1)];
-            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(a.bits_in + (size_t)env * nR + role.c4 * 4);
+            for (int c = 0; c < NC; ++c) bj[k][c] = brow[(unsigned)min(lane + 64 * c, nR - 1)];
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(brow) + (unsigned)(role.c4 * 2);
             w[k][0] = src[0];
             w[k][1] = src[1];
         }
@@ -536,6 +549,17 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             w[k][1] = src[1];
         }
     }
+    // The OUTPUT addresses and the store flavour live in the argument block and the compiler fetches each at its first use,
+    // AFTER the wait below (three scalar-cache reads inside the wave's critical path).  Forcing them into scalar registers
+    // here, while the vector loads are in flight, measured SLOWER (round 6, -DTAP_STREAM_EARLY_ARGS: c2 1 488 -> 1 450 M
+    // env-steps/s with the rolled expansion, 1 502 -> 1 464 M with the unrolled one): the wait it puts in front of the
+    // vector wait costs more than the late reads, which hit the scalar cache.
+    float *o_dyn = a.dyn_out, *o_cur = a.cur_out, *o_mask = a.mask_out;
+    unsigned long long *o_bits = a.bits_out;
+    int o_wt = a.wt;
+#ifdef TAP_STREAM_EARLY_ARGS                              // A/B builds
+    asm volatile("" : "+s"(o_dyn), "+s"(o_cur), "+s"(o_mask), "+s"(o_bits), "+s"(o_wt));
+#endif
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): every input of both slabs is here
 #ifdef TAP_PROF
     TL_STAMP(1);
@@ -614,7 +638,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         // stream wave is this step's critical path and every instruction in front of its last store is paid in full
         // (a row-by-row loop, three instructions per slab behind two nested loops: 5.60 against 5.20 us per launch at c2
         // with the tensor switched off)
-        if (a.dyn_out) {
+        if (o_dyn) {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             const int total = ur * C4;
             for (int idx = lane; idx < total; idx += 64) {
@@ -623,26 +647,26 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
                 for (int k = 0; k < NS; ++k) {
                     const int r = realk[k] + n * i;
                     if (!on[k] || realk[k] < 0 || r >= rows) continue;
-                    float4 *dst = reinterpret_cast<float4 *>(a.dyn_out) + ((size_t)(senv0 + k) * rows + r) * C4 + c;
+                    float4 *dst = reinterpret_cast<float4 *>(o_dyn) + ((size_t)(senv0 + k) * rows + r) * C4 + c;
 #if defined(TAP_INPLACE_STORE) && TAP_INPLACE_STORE == 1      // A/B builds: always write-through / nontemporal like the expansion
-                    store_stream(dst, z, a.wt);
+                    store_stream(dst, z, o_wt);
 #elif defined(TAP_INPLACE_STORE) && TAP_INPLACE_STORE == 2     // A/B builds: plain
                     *dst = z;
 #else
-                    if (a.wt) store_stream(dst, z, 1); else *dst = z;            // a row is a fraction of a line: never nontemporal
+                    if (o_wt) store_stream(dst, z, 1); else *dst = z;            // a row is a fraction of a line: never nontemporal
 #endif
                 }
             }
         }
     }
     if (lane_on) {
-        if (!INPLACE && a.dyn_out) {
+        if (!INPLACE && o_dyn) {
             // the fp32 tensor: instruction i = the lane's row r0 + RP * i of the wave's run when that is a row of it (late
             // lanes skip i = 0); rows >= `rows` belong to the second slab
             const int non = (NS > 1 && on[NS - 1]) ? 2 : 1;
             const int total = non * rows;
             const int nq = (C4S ? (non * rows + RP - 1) / RP : (non > 1 ? a.nq2 : a.nq)) + role.nq;   // role.nq: one more instruction when rotated
-            float4 *dst = reinterpret_cast<float4 *>(a.dyn_out + (size_t)senv0 * rows * nR) + role.c4;
+            float4 *dst = reinterpret_cast<float4 *>(o_dyn + (size_t)senv0 * rows * nR) + role.c4;
             int rr = role.r0;
             // MERGED = false (two-slab waves only): round 4's loops, one per slab on the lane's own rows.  Which form a
             // kernel takes is decided where it is launched (transition.hip), from these A/B runs (env-steps/s, same
@@ -662,13 +686,46 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
                         for (int r = role.rsub; r < rows; r += RP) {
                             const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
                                                          (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
-                            store_stream(&dk[(size_t)r * C4], v, a.wt);
+                            store_stream(&dk[(size_t)r * C4], v, o_wt);
                         }
                     }
                     done = true;
                 }
             }
             if (done) {
+            } else if (C4S != 0 && rows <= 32) {
+                // the compiled-in 10-node windows: the run's instructions unrolled (at most NQC of them; the guard skips the
+                // ones a lane does not have), the store flavour chosen once instead of inside the loop (round 6: c2 1 488 ->
+                // 1 502 M env-steps/s, c3 unchanged)
+                constexpr int ROWS_C = 30, RP_C = C4S ? 64 / C4S : 1, NQC = (NS * ROWS_C + RP_C - 1) / RP_C + 1;
+                auto run = [&](auto wt_c) {
+#pragma unroll
+                    for (int i = 0; i < NQC; ++i) {
+                        const int ri = rr + RP_C * i;
+                        if ((unsigned)ri >= (unsigned)total) continue;
+                        const bool up = NS > 1 && ri >= ROWS_C;
+                        const int r = up ? ri - ROWS_C : ri;
+                        const unsigned m0 = up ? (unsigned)nw[NS - 1][0] : (unsigned)nw[0][0], m1 = up ? (unsigned)nw[NS - 1][1] : (unsigned)nw[0][1],
+                                       m2 = up ? (unsigned)nw[NS - 1][2] : (unsigned)nw[0][2], m3 = up ? (unsigned)nw[NS - 1][3] : (unsigned)nw[0][3];
+                        const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
+                                                     (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
+                        store_stream(&dst[(size_t)ri * C4], v, decltype(wt_c)::value);
+                    }
+                };
+#ifdef TAP_STREAM_ROLLED                                  // A/B builds: round 5's rolled loop
+                for (int i = 0; i < nq; ++i, rr += RP) {
+                    if ((unsigned)rr >= (unsigned)total) continue;
+                    const bool up = NS > 1 && rr >= rows;
+                    const int r = up ? rr - rows : rr;
+                    const unsigned m0 = up ? (unsigned)nw[NS - 1][0] : (unsigned)nw[0][0], m1 = up ? (unsigned)nw[NS - 1][1] : (unsigned)nw[0][1],
+                                   m2 = up ? (unsigned)nw[NS - 1][2] : (unsigned)nw[0][2], m3 = up ? (unsigned)nw[NS - 1][3] : (unsigned)nw[0][3];
+                    const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
+                                                 (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
+                    store_stream(&dst[(size_t)rr * C4], v, o_wt);
+                }
+#else
+                if (o_wt) run(std::integral_constant<int, 1>{}); else run(std::integral_constant<int, 0>{});
+#endif
             } else if (rows <= 32) {
                 // n <= 10 (every BASELINE window): the column words fit 32 bits -- a bit-field extract and a
                 // convert per element, no half selection
@@ -680,7 +737,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
                                    m2 = up ? (unsigned)nw[NS - 1][2] : (unsigned)nw[0][2], m3 = up ? (unsigned)nw[NS - 1][3] : (unsigned)nw[0][3];
                     const float4 v = make_float4((float)((m0 >> r) & 1u), (float)((m1 >> r) & 1u),
                                                  (float)((m2 >> r) & 1u), (float)((m3 >> r) & 1u));
-                    store_stream(&dst[(size_t)rr * C4], v, a.wt);
+                    store_stream(&dst[(size_t)rr * C4], v, o_wt);
                 }
             } else {
                 for (int i = 0; i < nq; ++i, rr += RP) {
@@ -689,15 +746,15 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
                     const int r = up ? rr - rows : rr;
                     const float4 v = make_float4(bit_as_float(up ? nw[NS - 1][0] : nw[0][0], r), bit_as_float(up ? nw[NS - 1][1] : nw[0][1], r),
                                                  bit_as_float(up ? nw[NS - 1][2] : nw[0][2], r), bit_as_float(up ? nw[NS - 1][3] : nw[0][3], r));
-                    store_stream(&dst[(size_t)rr * C4], v, a.wt);
+                    store_stream(&dst[(size_t)rr * C4], v, o_wt);
                 }
             }
         }
-        if (first_row && a.bits_out) {
+        if (first_row && o_bits) {
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 if (!on[k]) continue;
-                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(a.bits_out + (size_t)(senv0 + k) * nR + role.c4 * 4);
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(o_bits + (size_t)(senv0 + k) * nR + role.c4 * 4);
                 dst[0] = make_ulonglong2(nw[k][0], nw[k][1]);
                 dst[1] = make_ulonglong2(nw[k][2], nw[k][3]);
             }
@@ -715,8 +772,8 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             const int move = __popcll(nb & nmask), small = n >= 64 ? 0 : __popcll((nb >> n) & nmask);
             const int large = n >= 32 ? 0 : __popcll((nb >> (2 * n)) & nmask); // rows <= 64
             const float kp = (jm[c] == pm[k]) ? 0.f : (has_mask ? keep[k][c] : 1.f);   // pack.py:320-321
-            if (a.mask_out) a.mask_out[(size_t)env * nR + j] = kp;
-            if (a.cur_out) a.cur_out[(size_t)env * nR + j] = (small * large + move) != 0 ? 0.f : kp; // :327-329
+            if (o_mask) o_mask[(size_t)env * nR + j] = kp;
+            if (o_cur) o_cur[(size_t)env * nR + j] = (small * large + move) != 0 ? 0.f : kp; // :327-329
         }
     }
 }
@@ -845,13 +902,13 @@ __device__ __forceinline__ void stream_wave_bits_r3(const MaskArgs &a, int senv0
 }
 
 #endif
-template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0, bool INPLACE = false>
+template <int NS, int NC, bool BUILD = false, bool MERGED = true, int C4S = 0, bool INPLACE = false, bool FULL = false>
 __device__ __forceinline__ void stream_wave_bits(const MaskArgs &a, int senv0, int lane, const bool (&on)[NS], float *lds = nullptr)
 {
 #ifdef TAP_STREAM_R3
     stream_wave_bits_r3<NS, NC, BUILD>(a, senv0, lane, on, lds);
 #else
-    stream_wave_bits_r4<NS, NC, BUILD, MERGED, C4S, INPLACE>(a, senv0, lane, on, lds);
+    stream_wave_bits_r4<NS, NC, BUILD, MERGED, C4S, INPLACE, FULL>(a, senv0, lane, on, lds);
 #endif
 }
 

@@ -27,7 +27,9 @@ struct TransArgs {
 // (both bits, TAP_MODE_C4_10: c4's window, n = 20, rows = 60, nR = 40 -- the MACS 2D step, transition_macs.hip)
 // MODE & 32 (TAP_MODE_INPLACE, with MODE & 3 == 1 only): dyn_out holds the previous step's tensor (MaskArgs::inplace) --
 // the stream waves write the cleared rows' zeros instead of expanding the slab
-constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16, TAP_MODE_C4_10 = 24, TAP_MODE_INPLACE = 32;
+// MODE & 64 (TAP_MODE_FULL, with MODE & 3 == 1 and a compiled-in shape only): ptr, static and mask_in are all given and B is
+// a multiple of the workgroup's envs -- the stream wave carries no code for absent inputs or idle slabs (tap_masks.h: FULL)
+constexpr int TAP_MODE_MERGED = 4, TAP_MODE_C4_5 = 8, TAP_MODE_C4_15 = 16, TAP_MODE_C4_10 = 24, TAP_MODE_INPLACE = 32, TAP_MODE_FULL = 64;
 __host__ __device__ constexpr int tap_mode_shape(int D) { return D == 2 ? TAP_MODE_C4_5 : TAP_MODE_C4_15; }
 inline bool tap_mode_shape_ok(const MaskArgs &m, int D) { return m.n == 10 && m.rows == 30 && m.update_rows == 3 && m.nR == (D == 2 ? 20 : 60); }
 inline bool tap_mode_shape20_ok(const MaskArgs &m) { return m.n == 20 && m.rows == 60 && m.update_rows == 3 && m.nR == 40; }
@@ -36,7 +38,7 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
 {
     constexpr int MODE = MODE_ & 3;
     constexpr bool MERGED = (MODE_ & TAP_MODE_MERGED) != 0;
-    constexpr bool INPLACE = (MODE_ & TAP_MODE_INPLACE) != 0;
+    constexpr bool INPLACE = (MODE_ & TAP_MODE_INPLACE) != 0, FULL = (MODE_ & TAP_MODE_FULL) != 0;
     static_assert(!INPLACE || MODE == 1, "in place: only on a shadow the caller hands in");
     constexpr int C4S = (MODE_ & TAP_MODE_C4_10) == TAP_MODE_C4_10 ? 10 : (MODE_ & TAP_MODE_C4_5) ? 5 : (MODE_ & TAP_MODE_C4_15) ? 15 : 0;
     static_assert(C4S == 0 || NC == 1, "the compiled-in window shapes have one column per lane");
@@ -45,7 +47,7 @@ __device__ __forceinline__ void trans_stream_wave(const MaskArgs &m, int senv0, 
     for (int k = 0; k < SPW; ++k) on[k] = senv0 + k < m.B;
     TL_STAMP(0);
     if (NC > 0) {
-        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED, C4S, INPLACE>(m, senv0, lane, on, lds);
+        if (MODE == 1) stream_wave_bits<SPW, (NC > 0 ? NC : 1), false, MERGED, C4S, INPLACE, FULL>(m, senv0, lane, on, lds);
         else if (MODE == 2) stream_wave_bits<SPW, (NC > 0 ? NC : 1), true, MERGED, C4S>(m, senv0, lane, on, lds);
         else stream_wave_fast<SPW, (NC > 2 ? 4 : 6), (NC > 0 ? NC : 1)>(m, senv0, lane, on, lds);
         TL_STAMP(2);

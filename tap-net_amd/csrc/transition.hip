@@ -138,7 +138,12 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     // the reference's own window (n = 10: rows = 30, nR = 20 / 60) on the bit shadow runs the instantiation with its shape
     // compiled in (tap_transition.h: TAP_MODE_C4_*)
     const bool shaped = tap_mode_shape_ok(a.m, D);
-#define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr ((NC_) == 1 && ((M_) & 3) != 0) { if (shaped) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D)), LDS_); else TAP_LAUNCH_K(NC_, M_, LDS_); } \
+    // ... and, for a step on a shadow the caller hands in, without the code for absent inputs and idle slabs when there are none
+    const bool full = mode == 1 && a.m.ptr && a.m.static_ && a.m.mask_in && a.s.d.B % EPB == 0;
+#define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr ((NC_) == 1 && ((M_) & 3) == 1) { \
+            if (shaped && full) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D) | TAP_MODE_FULL), LDS_); \
+            else if (shaped) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D)), LDS_); else TAP_LAUNCH_K(NC_, M_, LDS_); } \
+        else if constexpr ((NC_) == 1 && ((M_) & 3) != 0) { if (shaped) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D)), LDS_); else TAP_LAUNCH_K(NC_, M_, LDS_); } \
         else TAP_LAUNCH_K(NC_, M_, LDS_); } while (0)
     // 2D windows (nR = 2n columns: five store instructions per run at c2) take the run-of-rows expansion while the stores
     // are write-through; 3D windows and every launch beyond the write-through limit keep the slab-by-slab loops
@@ -157,7 +162,7 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
 #undef TAP_LAUNCH_M
 #undef TAP_LAUNCH_T
 #undef TAP_LAUNCH_K
-    (void)shaped; (void)inpl;
+    (void)shaped; (void)inpl; (void)full;
     TAP_LAUNCH_CHECK(ctx, "k_transition");
     return TAP_OK;
 }
