@@ -63,14 +63,14 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_slab(v4f *__restrict__ d
         if (rsub < 12)
             for (int k = 0; k < 2; ++k)
                 for (int r = rsub; r < 30; r += 12)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + k * 150 + r * 5 + c4), "v"(v) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(base + k * 150 + r * 5 + c4), "v"(v) : "memory");
     } else if (KIND == 8) {
         if (lane < 60)
             for (int q = lane; q < 300; q += 60)
-                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + q), "v"(v) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(base + q), "v"(v) : "memory");
     } else {
         for (int q = lane; q < 300; q += 64)
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(base + q), "v"(v) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(base + q), "v"(v) : "memory");
     }
 }
 
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(TAP_BLOCK) k_bw_probe_wt(v4f *__restrict__ dst
 #pragma unroll
     for (int u = 0; u < PROBE_UNROLL; ++u) {
         const size_t i = base + (size_t)u * TAP_BLOCK;
-        if (i < n4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst + i), "v"(v) : "memory");
+        if (i < n4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst + i), "v"(v) : "memory");
     }
 }
 

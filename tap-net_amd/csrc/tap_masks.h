@@ -164,7 +164,12 @@ __device__ __forceinline__ void store_stream(float4 *dst, const float4 &v, int w
 {
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f nv = {v.x, v.y, v.z, v.w};
-    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(nv) : "memory");
+    // The two wait states behind the store belong to it: a VMEM store of more than 8 bytes reads its data registers AFTER it
+    // issues, and a vector instruction that overwrites one of them right behind it changes what is stored (2 wait states on
+    // gfx940+).  The compiler's hazard recogniser inserts them for the stores it emits itself -- it does not look inside
+    // inline assembly.  Found in round 6 when a register allocation put the run's row counter (rr += RP) in the first data
+    // register: element 0 of a row's float4 held the integer r + RP (test_fused_transition_equals_two_launch_path[64x64]).
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(dst), "v"(nv) : "memory");
     else __builtin_nontemporal_store(nv, reinterpret_cast<v4f *>(dst));
 }
 
