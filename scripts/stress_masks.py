@@ -38,7 +38,29 @@ def one(seed):
         n = int(rs.choice([2, 4, 6, 8, 12, 14, 16, 18, 20])) if D == 2 else int(rs.choice([2, 4, 6, 8, 10, 12, 14]))
     input_type = "rot" if (kind == 3 and rs.rand() < 0.5) else "bot"
     B = int(rs.choice([8, 64, 1024, 4096])) if rs.rand() < 0.4 else int(rs.randint(1, 3000))
-    cs = [5, 4 * n + 8] if D == 2 else [5, 5, 4 * n + 8]
+    # the container family decides WHICH fused kernel carries the stream waves: lane-per-cell LB_GREEDY / MACS (k_transition,
+    # k_transition_macs*), one wavefront per container (k_big_transition, k_macs2d_wave_transition, k_macs3d_wave_transition)
+    fam = int(rs.randint(0, 6)) if seed % 2 else 0
+    H = 4 * n + 8
+    strategy, reward = "LB_GREEDY", "C+P+S-lb-soft"
+    if fam == 0:
+        cs = [5, H] if D == 2 else [5, 5, H]
+    elif fam == 1:
+        cs = [int(rs.randint(6, 17)), H] if D == 2 else [int(rs.randint(4, 9)), int(rs.randint(4, 9)), H]
+        cs = cs if D == 2 or cs[0] * cs[1] <= 64 else [8, 8, H]
+    elif fam == 2:                                               # LB_GREEDY above 64 cells
+        cs = [int(rs.choice([70, 100])), H] if D == 2 else [int(rs.choice([9, 10, 12])), int(rs.choice([9, 10])), H]
+    elif fam == 3:                                               # MACS on lanes
+        strategy, reward = "MACS", "C+P+S-mcs-soft"
+        cs = [int(rs.randint(5, 17)), H] if D == 2 else [5, 5, H]
+    elif fam == 4:                                               # MACS, one wavefront per container
+        strategy, reward = "MACS", str(rs.choice(["C+P+S-mcs-soft", "mcs-soft"]))
+        cs = [int(rs.choice([20, 40, 64])), H] if D == 2 else [int(rs.choice([9, 10])), int(rs.choice([9, 10])), H]
+    else:
+        strategy, reward = "MACS", "C+P+S-mul-hard"
+        cs = [7, H] if D == 2 else [6, 6, H]
+    if fam in (2, 4):
+        B = min(B, 600)                                          # the oracle's MACS / big-container episodes are the slow part
     static, dynamic = synth.rand_instances(B, n, D, seed=seed)
     tape = synth.random_feasible_tape(static, dynamic, n, seed=seed + 1)
     if input_type == "rot":
@@ -49,7 +71,7 @@ def one(seed):
     bad = []
     modes = [dict(), dict(inplace_dynamic=True), dict(expand_dynamic=False)]
     for mi, kw in enumerate(modes):
-        env = T.BatchedContainer(B, cs, n, "C+P+S-lb-soft", "diff", device=DEV)
+        env = T.BatchedContainer(B, cs, n, reward, "diff", packing_strategy=strategy, device=DEV)
         try:
             sp = pack.EpisodeStepper(st, dy, env, input_type=input_type, **kw)
         except ValueError:
@@ -75,11 +97,15 @@ def one(seed):
                 if not np.array_equal(sp.current_mask.cpu().numpy(), cur) or not np.array_equal(sp.mask.cpu().numpy(), mask):
                     bad.append((mi, with_mask, t, "masks"))
             blocks = np.stack([stn[np.arange(B), 1:, tpn[:, t]] for t in range(n)], axis=1).astype(np.int32)
-            ref = O.run_episodes(O.make_desc(cs, n, "C+P+S-lb-soft", "diff"), blocks, nthreads=8, want_features=False, want_heightmaps=False)
-            if ref["nerr"] == 0 and not np.array_equal(sp.ratio.cpu().numpy(), ref["ratio"].astype(np.float32)):
+            ref = O.run_episodes(O.make_desc(cs, n, reward, "diff", strategy), blocks, nthreads=8, want_features=False, want_heightmaps=False)
+            ok = ref["errs"] == 0
+            if not np.array_equal(sp.ratio.cpu().numpy()[ok], ref["ratio"].astype(np.float32)[ok]):
                 bad.append((mi, with_mask, n, "ratio"))
-        sp.check()
-    return dict(D=D, n=n, B=B, input_type=input_type, steps=B * n * len(modes)), bad
+        try:
+            sp.check()
+        except IndexError:
+            pass                                                 # containers the reference raises in too (oracle: errs != 0)
+    return dict(D=D, n=n, B=B, input_type=input_type, cs=cs, strategy=strategy, steps=B * n * len(modes)), bad
 
 
 def main():
@@ -90,7 +116,8 @@ def main():
     for seed in range(N):
         meta, bad = one(seed)
         total += meta["steps"]
-        key = "%dD %s n%s" % (meta["D"], meta["input_type"], "=10" if meta["n"] == 10 else "!=10")
+        key = "%dD %s %s n%s%s" % (meta["D"], meta["strategy"], meta["input_type"], "=10" if meta["n"] == 10 else "!=10",
+                                     " big" if (meta["cs"][0] > 16 or (meta["D"] == 3 and meta["cs"][0] * meta["cs"][1] > 64)) else "")
         fam[key] = fam.get(key, 0) + 1
         if bad:
             nbad += 1
