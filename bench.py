@@ -1558,10 +1558,17 @@ def roofline_of(hp, config, cfg, rolling, steps, graphs):
     # nothing but that kernel the graph-replayed pass / launches is the cleaner figure (it includes the gap)
     launches = hp.launches_per_pass()
     if hp.kind == "transition" and hp.fused:
+        # graph-replayed pass / ALL its launches: the episode's first step (which also reads the fresh fp32 tensor: 1.4 x a
+        # later step in the kernel trace) is averaged in, so this is an UPPER bound for the later steps' kernel, whose
+        # compulsory bytes `achieved` is computed on -- conservative.  (Up to round 5 the first step's eager event-pair time
+        # was subtracted instead; an event pair around one eager launch over-reads by ~1 us, which made the later steps
+        # look 0.1-0.3 us faster than the kernel trace says.)
         other = sum(max(kt[k]["med_us"] - empty_us, 0.0) * (kt[k]["launches"] // npass) for k in names if k != dom)
-        dom_us = (pass_us - other) / (kt[dom]["launches"] // npass)
-        how = ("(graph-replayed pass - the other kernels' event time) / launches, passes replayed %d per graph launch as "
-               "in the timed loop; includes the inter-kernel gap" % getattr(hp, "passes_per_graph", GATHER_EVERY))
+        dom_us_minus_first = (pass_us - other) / (kt[dom]["launches"] // npass)
+        dom_us = pass_us / launches
+        how = ("graph-replayed pass / all %d launches (the first step, 1.4 x a later one, averaged in: an upper bound for a later "
+               "step), passes replayed %d per graph launch as in the timed loop; includes the inter-kernel gap; with the first "
+               "step's eager event time subtracted instead: %.3f us" % (launches, getattr(hp, "passes_per_graph", GATHER_EVERY), dom_us_minus_first))
     elif hp.kind == "episode":
         dom_us, how = pass_us, "event-bracketed pass (one launch)"
     elif kt[dom].get("run_len", 1) >= 8:
