@@ -21,6 +21,12 @@ def test_kernel_names_map_to_bench_names():
     assert s("void k_transition<3, 32, 1, 8, 17>(long const*)") == "transition"
     assert s("void k_transition<3, 32, 1, 8, 18>(long const*)") == "transition_first"
     assert s("void k_transition<2, 8, 1, 4, 0>(long const*)") == "transition_copy"
+    # round 6: 32 = in place, 64 = FULL (no code for absent inputs / idle slabs)
+    assert s("void k_transition<2, 8, 1, 4, 77>(long const*, float const*)") == "transition"
+    assert s("void k_transition<3, 32, 1, 8, 81>(long const*)") == "transition"
+    assert s("void k_transition<2, 8, 1, 4, 105>(long const*)") == "transition"
+    assert s("void k_transition_macs3<32, 1, 1, 5>(TransArgs)") == "transition"
+    assert s("void k_transition_macs3<32, 1, 33, 5>(TransArgs)") == "transition"
     # k_transition_macs<G, NC, MODE[, WC]>, k_transition_macs3<G, NC, MODE[, WL]>: the width / sides come last
     assert s("void k_transition_macs<8, 1, 29, 7>(TransArgs)") == "transition"
     assert s("void k_transition_macs<8, 1, 30, 7>(TransArgs)") == "transition_first"
