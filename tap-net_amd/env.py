@@ -273,6 +273,7 @@ class lockstep_scope(object):
         return False
 
 
+_draw_warned = False
 _UNFILLED = np.iinfo(np.int64).min    # a row handed out before its round completed holds this, never stale data
 
 
@@ -474,6 +475,18 @@ class Container(object):
         if self._pool is not None:
             return self._pool.ratio(self._i)
         return float(self._b.calc_ratios64()[0].item())
+
+    def draw_container(self, save_name=None, **kwargs):
+        """tools.Container.draw_container (tools.py:3746-3822; called by rolling.py:655 for the first six instances): the
+        reference renders the packing with matplotlib.  Drawing is outside this package: the call is
+        accepted so that rolling.validate's loop runs unchanged, writes nothing and says so once; everything a drawing
+        needs is here -- ``positions``, ``blocks``, ``stable``, ``container`` (the voxel grid, rebuilt on demand)."""
+        global _draw_warned
+        if not _draw_warned:
+            import warnings
+            warnings.warn("tap_net_amd.tools.Container.draw_container writes no image (drawing is out of scope); "
+                          "positions / blocks / stable / container hold what a renderer needs", stacklevel=2)
+            _draw_warned = True
 
     def clear_container(self):
         if self._pool is not None and self._pool.members > 1:
