@@ -410,3 +410,12 @@ def generate_mix_instances(batch_size, blocks_num, block_dim=3, initial_containe
     _, _, rb, rp = generate_instances(int(batch_size) - half, blocks_num, block_dim, initial_container_width,
                                       initial_container_height, 1, size_range, seed=seed, device=device, return_aux=True)
     return torch.cat([pb, rb]).contiguous(), torch.cat([pp, rp]).contiguous()
+
+
+def __getattr__(name):
+    # generate.InitialContainer (generate.py:1589): the per-instance facade lives with the batched windows (rolling.py,
+    # which imports this module's callers); resolved on first use
+    if name == 'InitialContainer':
+        from .rolling import InitialContainer
+        return InitialContainer
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))

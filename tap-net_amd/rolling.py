@@ -121,6 +121,58 @@ class RollingWindows(object):
             raise _lib.TapError(_lib.TAP_E_INVALID, "a precedence window could not be filled")
 
 
+class InitialContainer(object):
+    """Drop-in for ``generate.InitialContainer`` (generate.py:1589-1839) as rolling.py drives it (rolling.py:501, 592, 597,
+    637): ONE instance, numpy in / numpy out, on a ``RollingWindows`` of batch 1 -- the per-instance facade of this seam, as
+    ``tools.Container`` is for S2 (one launch and one sync per call: it exists so that the unchanged loop runs, the batched
+    ``RollingWindows`` / ``RollingStepper`` are the fast path).
+
+    ``convert_to_input()`` -> (static (1 + D, child * R), dynamic (3 * child, child * R)) float64 arrays like the
+    reference's; afterwards ``sub_graph_nodes`` is the window's node list (sorted: the order of ``static``'s columns, which
+    is what rolling.py:637 indexes with the policy's pick).  ``remove_block(block_id)`` drops a node of the current window
+    before the next ``convert_to_input()``; an id that is not in the window is ignored, as the reference's ``try`` does
+    (generate.py:1832-1836).  The windows' set-order quirk (generate.py:1758-1761) is the kernels' (rolling.hip)."""
+
+    def __init__(self, blocks, positions, blocks_num, initial_container_size, allow_bot=True, child_graph_size=10,
+                 input_type='bot', device='cuda', arm_size=1):
+        import numpy as np
+        if input_type != 'bot' or not allow_bot:
+            raise NotImplementedError("rolling windows are built for input_type 'bot' (rolling.py:501 passes allow_bot=True)")
+        n = int(blocks_num)
+        b = torch.as_tensor(np.asarray(blocks)[:n].astype('int32')).unsqueeze(0)
+        p = torch.as_tensor(np.asarray(positions)[:n].astype('int32')).unsqueeze(0)
+        dev = _lib.resolve_device(device)
+        self._rw = RollingWindows(b.to(dev), p.to(dev), [int(v) for v in initial_container_size], int(child_graph_size), arm_size)
+        self.blocks_num, self.child_graph_size, self.input_type = n, int(child_graph_size), input_type
+        self.block_dim = self._rw.D
+        self.rotate_types = self._rw.R
+        self.sub_graph_nodes = []
+        self._pending = None
+
+    def remove_block(self, block_id):
+        if block_id in self.sub_graph_nodes:
+            if self._pending is not None:
+                raise NotImplementedError("one block per window step (rolling.py:637 removes the policy's pick)")
+            self._pending = self.sub_graph_nodes.index(block_id)
+
+    def convert_to_input(self):
+        rw = self._rw
+        if rw.steps_done == 0:
+            win = rw.next(None)
+        else:
+            if self._pending is None:
+                raise NotImplementedError("convert_to_input() without a removed block: the window is unchanged -- keep the "
+                                          "previous tensors (the reference would recompute the same ones)")
+            win = rw.next(torch.tensor([self._pending], dtype=torch.int64, device=rw.device))
+        self._pending = None
+        rw.check()
+        self.sub_graph_nodes = [int(v) for v in win['nodes'][0].tolist()]
+        return win['static'][0].cpu().numpy().astype('float64'), win['dynamic'][0].cpu().numpy().astype('float64')
+
+    def is_last_graph(self):
+        return self._rw.is_last_graph()
+
+
 class RollingStepper(object):
     """The step object of rolling.validate's loop (tapenv.h: tap_roller) -- ``RollingWindows.step`` for callers that
     pay per step on the host: it OWNS the window buffers (two phases of ``static`` and the node list, one of
