@@ -55,6 +55,9 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TAP_
     if (wave >= ENV_WAVES ? (a.flags & TAP_T_PROF_NOSTREAM) : (a.flags & TAP_T_PROF_NOPLACE)) return;
 #endif
     if (wave >= ENV_WAVES) {
+#ifdef TAP_STREAM_PRIO                                       // A/B builds: the stream waves' issue priority (default 0)
+        __builtin_amdgcn_s_setprio(TAP_STREAM_PRIO);
+#endif
         const MaskArgs m = tap_mask_hot(a.m, (MODE & 3) == 1, TAP_MASK_HOT_NAMES);
         trans_stream_wave<SPW, NC, MODE>(m, env_base + (wave - ENV_WAVES) * SPW, lane,
                                      trans_lds + (size_t)(wave - ENV_WAVES) * SPW * 3 * h_nR);
@@ -62,7 +65,11 @@ __global__ void __launch_bounds__((TransGeom<G, SW>::THREADS)) k_transition(TAP_
     }
 
     // ---- placement waves (tools.py:3663-3744): their latency chain runs beside the stream --------
+#ifdef TAP_PLACE_PRIO                                        // A/B builds
+    __builtin_amdgcn_s_setprio(TAP_PLACE_PRIO);
+#else
     __builtin_amdgcn_s_setprio(2);
+#endif
     const int cell = tid % G;
     TL_STAMP(0);
     StepArgs sa = a.s;       // the gather's source is the update's: ptr, static and their sizes are already in SGPRs
