@@ -146,7 +146,11 @@ static int launch_transition_v(tap_ctx *ctx, const TransArgs &a, hipStream_t st)
     // compiled in (tap_transition.h: TAP_MODE_C4_*)
     const bool shaped = tap_mode_shape_ok(a.m, D);
     // ... and, for a step on a shadow the caller hands in, without the code for absent inputs and idle slabs when there are none
+#ifdef TAP_NO_FULL                                            // A/B builds
+    const bool full = false;
+#else
     const bool full = mode == 1 && a.m.ptr && a.m.static_ && a.m.mask_in && a.s.d.B % EPB == 0;
+#endif
 #define TAP_LAUNCH_T(NC_, M_, LDS_) do { if constexpr ((NC_) == 1 && ((M_) & 3) == 1) { \
             if (shaped && full) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D) | TAP_MODE_FULL), LDS_); \
             else if (shaped) TAP_LAUNCH_K(NC_, ((M_) | tap_mode_shape(D)), LDS_); else TAP_LAUNCH_K(NC_, M_, LDS_); } \
