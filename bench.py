@@ -638,6 +638,16 @@ def time_passes(hps, steps, warmup, use_graph, world, repeats=1):
             hp.reward = acc[0]                                  # graphs[0] (event timing, verification) writes row 0
         if single and ge in group:
             hp.group_graph = (group[ge], ge)
+        if not single:
+            # the rotation over several instance sets (the cold reading) as ONE graph of one pass per set: the same
+            # launch amortisation as the headline's groups.  (Up to round 6 it was one graph launch per PASS, whose
+            # ~8 us of launch gap per 10 kernels read as part of the cold penalty: 77.8 against 69.7 us per pass at c2,
+            # the second figure from scripts/decompose_step.py's single-graph rotation.)
+            cycle = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cycle):
+                for h in hps:
+                    h.episode()
+            group["cycle"] = cycle
 
     def run(npasses):
         if single:
@@ -654,9 +664,16 @@ def time_passes(hps, steps, warmup, use_graph, world, repeats=1):
                     flush(cnt)
                 done += cnt
         else:
-            for _ in range(npasses):
+            done = 0
+            while done < npasses:
                 k = state["pass"] % len(hps)
+                if graphs is not None and k == 0 and npasses - done >= len(hps):
+                    group["cycle"].replay()                     # one pass on every set
+                    state["pass"] += len(hps)
+                    done += len(hps)
+                    continue
                 state["pass"] += 1
+                done += 1
                 if graphs is not None:
                     graphs[k].replay()
                 else:
@@ -1020,7 +1037,7 @@ def cold_reading(cfg, hp, rolling, dev, use_graph, max_slots=40, min_steps=40):
             return (hp.static[0].roll(977 * k, 0).cpu().numpy(), hp.dynamic0[0].roll(977 * k, 0).cpu().numpy())
         hps = [hp] + [HotPath(cfg, B, 0, dev, seed=777 + 1000 * k, fused=hp.fused, window=hp.nw if hp.windows > 1 else None,
                               bits=hp.bits, instances=slot_instances(k)) for k in range(1, slots)]
-        steps = max(slots * 4, min_steps)
+        steps = slots * max(4, -(-min_steps // slots))       # whole rotations: every timed pass sits in a cycle graph
     dt, _ = time_passes(hps, steps, slots, use_graph, 1)
     for h in hps:
         h.env.check()
@@ -1030,7 +1047,7 @@ def cold_reading(cfg, hp, rolling, dev, use_graph, max_slots=40, min_steps=40):
                frac_how="compulsory bytes of every launch of a pass / pass time / 8 TB/s (gaps between the launches included)",
                slots=slots, working_set_MB=round(per_slot * slots / 1e6, 1), steps=steps,
                what="pass i runs on instance set i %% %d, each with its own input and output buffers; the working set is "
-                    "several times the 256 MB Infinity Cache" % slots)
+                    "several times the 256 MB Infinity Cache; one graph launch per rotation over the sets" % slots)
     del hps
     torch.cuda.empty_cache()
     return out
