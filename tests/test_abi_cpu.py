@@ -122,3 +122,31 @@ def test_dataset_files_round_trip(tmp_path):
         assert np.array_equal(ds.dynamic.numpy(), z["dynamic"].astype(np.float32))
         raw = datafiles.read_raw(d, n, D)
         assert raw["blocks"].shape == (N, 2 if D == 2 else 6, D, n)
+
+
+def test_reference_seam_names_resolve():
+    """The names the reference's own modules look up on `tools`, `pack` and `generate` (S1-S4 and the rolling
+    loop) exist on the host mirror with the reference's parameter names -- resolved without a GPU."""
+    import inspect
+    import tap_net_amd as T
+    from tap_net_amd import generate, pack, tools
+    for mod, names in ((pack, ("update_dynamic", "update_mask", "reward", "render", "PACKDataset", "create_dataset",
+                               "create_dataset_gt", "get_mix_dataset")),
+                       (tools, ("Container", "calc_positions_lb_greedy", "lockstep_containers", "lockstep_scope")),
+                       (generate, ("InitialContainer", "generate_instances", "precedence_tensors"))):
+        for n in names:
+            assert getattr(mod, n) is not None, (mod.__name__, n)
+    assert list(inspect.signature(pack.update_dynamic).parameters) == ["dynamic", "static", "chosen_idx", "input_type", "allow_rot"]   # pack.py:333
+    assert list(inspect.signature(pack.update_mask).parameters) == ["mask", "dynamic", "static", "chosen_idx", "input_type", "allow_rot"]   # pack.py:276
+    assert list(inspect.signature(pack.reward).parameters)[:7] == ["static", "tour_indices", "reward_type", "input_type", "allow_rot",
+                                                                    "container_width", "container_height"]                                   # pack.py:378
+    assert list(inspect.signature(tools.Container.__init__).parameters)[1:8] == [
+        "container_size", "blocks_num", "reward_type", "heightmap_type", "initial_container_size", "max_height", "packing_strategy"]          # tools.py:3611
+    assert list(inspect.signature(generate.InitialContainer.__init__).parameters)[1:8] == [
+        "blocks", "positions", "blocks_num", "initial_container_size", "allow_bot", "child_graph_size", "input_type"]                        # generate.py:1590
+    for meth in ("add_new_block", "get_heightmap", "calc_ratio", "clear_container", "draw_container"):                                       # model.py:453, 424, 510; rolling.py:655-657
+        assert callable(getattr(tools.Container, meth))
+    for meth in ("convert_to_input", "remove_block", "is_last_graph"):                                                                       # rolling.py:592, 637, 597
+        assert callable(getattr(generate.InitialContainer, meth))
+    assert "inplace_dynamic" in inspect.signature(pack.EpisodeStepper.__init__).parameters
+    assert T.run_episode is not None and T.run_rolling_episode is not None
