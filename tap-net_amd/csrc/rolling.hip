@@ -1066,7 +1066,10 @@ struct RollStepArgs {
     StepArgs s;
 };
 
-constexpr int ROLL_EPB = 2;   // instances per workgroup of the fused step (2: 3-wave workgroups pack a CU's 28 wave slots
+#ifndef TAP_ROLL_EPB
+#define TAP_ROLL_EPB 2      // A/B builds (-DTAP_ROLL_EPB=1 | 4).  Round 6, six processes per build, c5 M env-steps/s: 1: 426-478, 2: 542-558, 4: 483-533
+#endif
+constexpr int ROLL_EPB = TAP_ROLL_EPB;   // instances per workgroup of the fused step (2: 3-wave workgroups pack a CU's 28 wave slots
                               // better than 6-wave ones: 9 x 3 = 27 against 4 x 6 = 24)
 
 template <int D, int G, bool SOFT, int CH>
