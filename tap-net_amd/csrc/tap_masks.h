@@ -75,6 +75,7 @@ struct LaneRole {
     int rsub, c4;    // role: rows rsub + rp*q of column quad c4
     int r0;          // row of the lane's store in instruction 0 (negative: the lane starts one instruction late)
     int nq;          // store instructions of the run: the caller's count, + 1 when the roles are rotated (wave-uniform)
+    int sb;          // the rotation: lane l plays role (l - sb) mod K, so role (0, c4) is lane c4 + sb
 };
 
 __device__ __forceinline__ LaneRole stream_lane_role(int lane, int env, int C4, int RP, int c4_magic, int sb_mul, int sb_add, int nq)
@@ -88,6 +89,7 @@ __device__ __forceinline__ LaneRole stream_lane_role(int lane, int env, int C4, 
     o.c4 = role - o.rsub * C4;
     o.r0 = o.rsub - (late ? RP : 0);
     o.nq = nq + (sb != 0);
+    o.sb = sb;
     return o;
 }
 
@@ -482,6 +484,20 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
     bool on[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) on[k] = FULL ? true : on_[k];
+    // One load instruction fewer in the wave's input burst (round 6): the per-column copy of the shadow words (lane j = column
+    // j, for the masks at the end of the wave) is the same data as the quads the expansion reads (lane (row group, quad)).
+    // Column j's NEW word sits in element j & 3 of the lane that plays role (0, j >> 2) = lane (j >> 2) + sb, so the tail
+    // fetches it with four ds_bpermute per slab, behind the stores.  30-row windows only (the low word carries every row),
+    // and one-slab waves only: same session, c3 549.6 -> 555.5 M env-steps/s, but c2 (two slabs: eight shuffles and their
+    // selects in the tail) 1 499 -> 1 483 M although a timing build WITHOUT the second load and without a replacement read
+    // + 2.2 % there.  -DTAP_STREAM_LOAD_BJ: round 5's second load everywhere; -DTAP_STREAM_BJX_ALL: the shuffles for two-slab waves too.
+#if defined(TAP_STREAM_LOAD_BJ)
+    constexpr bool BJ_X = false;
+#elif defined(TAP_STREAM_BJX_ALL)
+    constexpr bool BJ_X = !BUILD && NC == 1 && (C4S == 5 || C4S == 15);
+#else
+    constexpr bool BJ_X = !BUILD && NC == 1 && NS == 1 && (C4S == 5 || C4S == 15);
+#endif
     typedef unsigned long long u64;
     static_assert(NS <= 2, "a stream wave expands one or two slabs");
     if (!on[0]) return;                                  // on[] is a prefix and wave-uniform: no env, nothing to do
@@ -536,8 +552,12 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         for (int k = 0; k < NS; ++k) {
             const int env = on[k] ? senv0 + k : senv0;
             const unsigned long long *brow = a.bits_in + (size_t)env * nR;
+            // (BJ_X: the compiled-in 10-node windows take a column's word from the lane that holds its quad, after the
+            //  clear -- below -- instead of loading the shadow a second time in the per-column layout)
+            if constexpr (!BJ_X) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) bj[k][c] = brow[(unsigned)min(lane + 64 * c, nR - 1)];
+                for (int c = 0; c < NC; ++c) bj[k][c] = brow[(unsigned)min(lane + 64 * c, nR - 1)];
+            }
             const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(brow) + (unsigned)(role.c4 * 2);
             w[k][0] = src[0];
             w[k][1] = src[1];
@@ -765,6 +785,18 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
             }
         }
     }
+    unsigned nbx[NS];                                     // BJ_X: column `lane`'s new word, from the lane that holds its quad
+    if constexpr (BJ_X) {
+        const int jj = min(lane, nR - 1);
+        const int src = ((jj >> 2) + role.sb) << 2;       // ds_bpermute addresses lanes in bytes; every lane of the wave takes part
+        const int e = jj & 3;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int e0 = __builtin_amdgcn_ds_bpermute(src, (int)(unsigned)nw[k][0]), e1 = __builtin_amdgcn_ds_bpermute(src, (int)(unsigned)nw[k][1]);
+            const int e2 = __builtin_amdgcn_ds_bpermute(src, (int)(unsigned)nw[k][2]), e3 = __builtin_amdgcn_ds_bpermute(src, (int)(unsigned)nw[k][3]);
+            nbx[k] = (unsigned)(e == 0 ? e0 : e == 1 ? e1 : e == 2 ? e2 : e3);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         if (!on[k]) continue;
@@ -773,7 +805,7 @@ __device__ __forceinline__ void stream_wave_bits_r4(const MaskArgs &a, int senv0
         for (int c = 0; c < NC; ++c) {
             const int j = lane + 64 * c;
             if (j >= nR) continue;
-            const u64 nb = bj[k][c] & ~clr[k];
+            const u64 nb = BJ_X ? (u64)nbx[k] : (bj[k][c] & ~clr[k]);
             const int move = __popcll(nb & nmask), small = n >= 64 ? 0 : __popcll((nb >> n) & nmask);
             const int large = n >= 32 ? 0 : __popcll((nb >> (2 * n)) & nmask); // rows <= 64
             const float kp = (jm[c] == pm[k]) ? 0.f : (has_mask ? keep[k][c] : 1.f);   // pack.py:320-321
